@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the reference.
+
+Runs ONLY in the build container (needs /root/reference); the GPU box and the
+test-suite never execute this file -- they read the committed ``.npz`` data.
+
+Two sources:
+
+A. ``dumps``   -- numeric arrays extracted from the pickled ``Result`` dumps the
+   reference ships (tests/test_result_serialization/oct_result.dump and
+   docs/notebooks/*.dump), read with a restricted unpickler that only
+   reconstructs numpy arrays and stubs every other class.  The fixture stores
+   the *inputs* of the run (operators, states, time grid, controls at the
+   continuation iteration) next to the reference's recorded outputs
+   (tau_vals, pulses, info_vals).
+
+B. ``ref``     -- the reference's real ``krotov.optimize_pulses`` loop executed
+   here in its documented "numpy mode" (reference
+   docs/notebooks/09_example_numpy.ipynb), with QuTiP / glom / grapheme
+   replaced by empty stub modules (they are not installed), on the seeded
+   synthetic inputs of ``krotov_amd.configs``.  Outputs: all pulses, tau_vals.
+
+Usage:  python tests/golden/make_reference_goldens.py [dumps] [ref] [c5full]
+
+The reference is BSD-3-Clause (c) 2018-2024 Michael Goerz et al.; the fixtures
+derived from its shipped data keep that attribution (tests/golden/README.md).
+"""
+import importlib
+import os
+import pickle
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+
+
+# ---------------------------------------------------------------------------
+# A. restricted unpickler
+# ---------------------------------------------------------------------------
+
+_ALLOW = {
+    ('numpy.core.multiarray', '_reconstruct'),
+    ('numpy._core.multiarray', '_reconstruct'),
+    ('numpy.core.multiarray', 'scalar'),
+    ('numpy._core.multiarray', 'scalar'),
+    ('numpy', 'ndarray'),
+    ('numpy', 'dtype'),
+    ('time', 'struct_time'),
+    ('builtins', 'complex'),
+}
+
+
+class _Stub:
+    def __init__(self, *a, **k):
+        self._args = a
+
+    def __setstate__(self, st):
+        self.__dict__['_state'] = st
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) in _ALLOW:
+            return getattr(importlib.import_module(module), name)
+        return type(name, (_Stub,), {})
+
+
+def load_dump(path):
+    with open(path, 'rb') as fh:
+        obj = _Unpickler(fh).load()
+    return obj.__dict__['_state']
+
+
+def _lambda_ops(gamma=0.0):
+    """Lambda-system operators of reference notebooks 02/03/08 (cell 6/7)."""
+    E1, E2, E3, wP, wS = 0.0, 10.0, 5.0, 9.5, 4.5
+    dP = E1 + wP - E2
+    dS = E3 + wS - E2
+    H0 = np.array([[dP, 0, 0], [0, -1j * gamma, 0], [0, 0, dS]], dtype=np.complex128)
+    HP_re = -0.5 * np.array([[0, 1, 0], [1, 0, 0], [0, 0, 0]], dtype=np.complex128)
+    HP_im = -0.5 * np.array([[0, 1j, 0], [-1j, 0, 0], [0, 0, 0]], dtype=np.complex128)
+    HS_re = -0.5 * np.array([[0, 0, 0], [0, 0, 1], [0, 1, 0]], dtype=np.complex128)
+    HS_im = -0.5 * np.array([[0, 0, 0], [0, 0, 1j], [0, -1j, 0]], dtype=np.complex128)
+    tgt = np.exp(1j * (E2 - wS) * 5.0) * np.array([0, 0, 1], dtype=np.complex128)
+    return H0, [HP_re, HP_im, HS_re, HS_im], tgt
+
+
+def make_dump_fixtures():
+    from krotov_amd import shapes
+
+    # --- TLS, chis_ss, 19 iterations of pulses (notebook 01) ----------------
+    st = load_dump(os.path.join(REF, 'tests/test_result_serialization/oct_result.dump'))
+    np.savez_compressed(
+        os.path.join(HERE, 'dump_tls_ss.npz'),
+        tlist=np.asarray(st['tlist']),
+        all_pulses=np.array([np.array(p) for p in st['all_pulses']]),  # (19, 1, 499)
+        tau_vals=np.array(st['tau_vals']),
+        info_vals=np.array(st['info_vals'], dtype=np.float64),
+        guess_controls=np.array(st['guess_controls']),
+        optimized_controls=np.array(st['optimized_controls']),
+        iters=np.array(st['iters']),
+    )
+    print('dump_tls_ss: iters', st['iters'][:3], '...', st['iters'][-1])
+
+    # --- ensemble K=5, N=3, L=4, chis_re (notebook 08) ----------------------
+    st = load_dump(os.path.join(REF, 'docs/notebooks/ensemble_opt_result.dump'))
+    H0, Hc, tgt = _lambda_ops()
+    np.savez_compressed(
+        os.path.join(HERE, 'dump_ensemble.npz'),
+        tlist=np.asarray(st['tlist']),
+        H0=H0, Hc=np.array(Hc), target=tgt,
+        mu=np.array([0.9, 0.95, 1.0, 1.05, 1.1]),
+        controls_it12=np.array(st['guess_controls']),  # continuation overwrote them
+        tau_vals=np.array(st['tau_vals'][:40]),
+        iters=np.array(st['iters'][:40]),
+        lambda_a=0.5,
+    )
+    print('dump_ensemble: n tau', len(st['tau_vals']), 'iters[:14]', st['iters'][:14])
+
+    # --- non-Hermitian Lambda system (notebook 03) ---------------------------
+    st = load_dump(os.path.join(REF, 'docs/notebooks/non_herm_opt_result.dump'))
+    H0, Hc, tgt = _lambda_ops(gamma=0.5)
+    np.savez_compressed(
+        os.path.join(HERE, 'dump_nonherm.npz'),
+        tlist=np.asarray(st['tlist']),
+        H0=H0, Hc=np.array(Hc), target=tgt,
+        controls_it40=np.array(st['guess_controls']),
+        tau_vals=np.array(st['tau_vals'][:60]),
+        iters=np.array(st['iters'][:60]),
+        lambda_a=2.0,
+    )
+    print('dump_nonherm: n tau', len(st['tau_vals']), 'iters[38:44]', st['iters'][38:44])
+
+    # --- Lambda system RWA from the true guess (notebook 02) -----------------
+    st = load_dump(os.path.join(REF, 'docs/notebooks/lambda_rwa_opt_result.dump'))
+    H0, Hc, tgt = _lambda_ops()
+    np.savez_compressed(
+        os.path.join(HERE, 'dump_lambda_rwa.npz'),
+        tlist=np.asarray(st['tlist']),
+        H0=H0, Hc=np.array(Hc), target=tgt,
+        guess_controls=np.array(st['guess_controls']),
+        optimized_controls=np.array(st['optimized_controls']),
+        tau_vals=np.array(st['tau_vals']),
+        iters=np.array(st['iters']),
+    )
+    print('dump_lambda_rwa: iters', st['iters'])
+
+    # --- transmon X gate, K=2, N=17 (notebook 05) ---------------------------
+    st = load_dump(os.path.join(REF, 'docs/notebooks/transmonxgate_opt_result.dump'))
+    Ec, EjEc, nstates = 0.386, 45, 8
+    Ej = EjEc * Ec
+    n = np.arange(-nstates, nstates + 1)
+    up = np.diag(np.ones(2 * nstates), k=-1)
+    H0 = (np.diag(4 * Ec * (n - 0.0) ** 2) - Ej * (up + up.T) / 2.0).astype(np.complex128)
+    H1 = (-2 * np.diag(n)).astype(np.complex128)
+    import scipy.linalg
+
+    evals, evecs = scipy.linalg.eig(H0)  # as the notebook's logical_basis()
+    ndx = np.argsort(evals.real)
+    V = evecs[:, ndx]
+    np.savez_compressed(
+        os.path.join(HERE, 'dump_transmon17.npz'),
+        tlist=np.asarray(st['tlist']),
+        H0=H0, H1=H1, psi0=V[:, 0].astype(np.complex128), psi1=V[:, 1].astype(np.complex128),
+        controls_it5=np.array(st['guess_controls']),
+        tau_vals=np.array(st['tau_vals'][:12]),
+        iters=np.array(st['iters'][:12]),
+        lambda_a=1.0,
+    )
+    print('dump_transmon17: iters[:8]', st['iters'][:8])
+
+
+# ---------------------------------------------------------------------------
+# B. the real reference loop under stub third-party modules
+# ---------------------------------------------------------------------------
+
+
+def import_reference_krotov():
+    """Import /root/reference/src/krotov with QuTiP & friends stubbed out."""
+    if 'krotov' in sys.modules:
+        return sys.modules['krotov']
+    np.ComplexWarning = np.exceptions.ComplexWarning  # conversions.py:103
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _PB:
+        def __init__(self, *a, **k):
+            pass
+
+        start = update = finished = lambda self, *a, **k: None
+
+    mod('qutip', Qobj=type('Qobj', (), {}), expect=lambda *a: None)
+    mod(
+        'qutip.parallel',
+        serial_map=lambda task, values, task_args=(), task_kwargs={}, **k: [
+            task(v, *task_args, **task_kwargs) for v in values
+        ],
+    )
+    mod('qutip.cy')
+    mod('qutip.cy.spconvert', dense2D_to_fastcsr_fmode=None)
+    mod('qutip.cy.spmatfuncs', spmvpy_csr=None)
+    mod('qutip.superoperator', mat2vec=None, vec2mat=None)
+    mod('qutip.solver', Options=object, Result=object)
+    mod('qutip.ui')
+    mod('qutip.ui.progressbar', BaseProgressBar=_PB, TextProgressBar=_PB)
+    mod('glom', T=type('T', (), {'__getitem__': lambda s, i: ('T', i)})(), glom=None, GlomError=Exception)
+    mod('grapheme', length=len)
+    sys.path.insert(0, os.path.join(REF, 'src'))
+    import krotov
+
+    krotov.Objective.type_checking = False  # objectives.py:154-158
+    return krotov
+
+
+def run_reference(spec, iter_stop, krotov=None):
+    """Run the reference loop on a ProblemSpec; returns dict of outputs."""
+    import scipy.linalg as la
+
+    from krotov_amd import configs
+
+    if krotov is None:
+        krotov = import_reference_krotov()
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov)
+    is_super = spec.is_super
+
+    # numpy-mode plugins, exactly the reference's notebook 09 (cells 16, 30, 32)
+    def expm(H, state, dt, c_ops=None, backwards=False, initialize=False):
+        f = 1.0 + 0j if is_super else -1j  # propagators.py:94-99
+        if backwards:
+            f = f.conjugate()
+        A = f * H[0]
+        for part in H[1:]:
+            A = A + (f * part[1]) * part[0]
+        return la.expm(A * dt) @ state
+
+    def mu(objs, i_obj, pulses, mapping, i_pulse, n):
+        op = objs[i_obj].H[1 + i_pulse][0]
+        if is_super:  # mu.py:130-134
+            return lambda s: 1j * (op @ s)
+        return lambda s: op @ s
+
+    def overlap(a, b):
+        return complex(np.vdot(a, b))
+
+    chi = getattr(krotov.functionals, 'chis_' + spec.chi)
+    t0 = time.time()
+    res = krotov.optimize_pulses(
+        objectives, pulse_options, spec.tlist,
+        propagator=expm, chi_constructor=chi, mu=mu, overlap=overlap,
+        norm=np.linalg.norm, iter_stop=iter_stop, store_all_pulses=True,
+    )
+    secs = time.time() - t0
+    return dict(
+        all_pulses=np.array([np.array(p) for p in res.all_pulses]),
+        tau_vals=np.array(res.tau_vals),
+        fw_T=np.array([np.asarray(s).ravel() for s in res.states]),
+        optimized_controls=np.array(res.optimized_controls),
+        seconds=secs,
+    )
+
+
+REF_CASES = {
+    # name: (builder kwargs -> spec, iter_stop)
+    'ref_c1_tls': (lambda c: c.config_c1(), 3),
+    'ref_c2_hilbert': (lambda c: c.config_c2_hilbert(), 2),
+    'ref_c2_liouville': (lambda c: c.config_c2_liouville(), 2),
+    'ref_c3_iswap': (lambda c: c.config_c3(), 2),
+    'ref_c4_small': (lambda c: c.config_c4(d=5, nt=201, n_logical=2), 2),
+    'ref_c5_small': (lambda c: c.config_c5(K=6, N=16, nt=201, L=1), 2),
+    'ref_c5_small_L3': (lambda c: c.config_c5(K=5, N=12, nt=151, L=3, distinct=True), 2),
+    'ref_c5_n64': (lambda c: c.config_c5(K=8, N=64, nt=401, L=1), 2),
+}
+
+
+def make_ref_fixtures(names=None):
+    from krotov_amd import configs
+
+    krotov = import_reference_krotov()
+    for name, (builder, iters) in REF_CASES.items():
+        if names and name not in names:
+            continue
+        spec = builder(configs)
+        out = run_reference(spec, iters, krotov)
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), iter_stop=iters, **out)
+        print('%-18s K=%d N=%d nt=%d L=%d  %.1fs  tau[-1][:2]=%s' % (
+            name, spec.K, spec.N, len(spec.tlist), spec.L, out['seconds'], out['tau_vals'][-1][:2]))
+
+
+def make_c5_full():
+    """Headline configuration through the real reference loop: 1 iteration
+    (~2.5 sweeps * 256 * 4000 props at ~0.8 ms each => ~35 min, one core)."""
+    from krotov_amd import configs
+
+    spec = configs.config_c5()
+    out = run_reference(spec, 1)
+    np.savez_compressed(os.path.join(HERE, 'ref_c5_full.npz'), iter_stop=1, **out)
+    print('ref_c5_full: %.0fs' % out['seconds'])
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['dumps', 'ref']
+    if 'dumps' in what:
+        make_dump_fixtures()
+    if 'ref' in what:
+        make_ref_fixtures()
+    if 'c5full' in what:
+        make_c5_full()
+    for w in what:
+        if w in REF_CASES:
+            make_ref_fixtures([w])

@@ -1,0 +1,208 @@
+"""Pin the CPU oracle against the reference (CPU-only, no GPU).
+
+1. vectors extracted from the reference's shipped Result dumps;
+2. outputs of the reference's own optimize_pulses loop (numpy mode, stubbed
+   third-party imports) on the synthetic configs -- see
+   tests/golden/make_reference_goldens.py;
+3. the reference's known-answer values (tests/test_parallelization.py:139-140,
+   tests/test_infohooks.py:67, tests/test_krotov/oct.log of the reference).
+Tolerances: 1e-12 against reference-loop outputs, 1e-9 against dump goldens
+(QuTiP's tidyup makes the N=17 dump the less exact side).
+"""
+import numpy as np
+import pytest
+
+from krotov_amd import configs
+from oracle import krotov_oracle as ko
+
+from helpers import CHI, golden, oracle_controls, oracle_optimize, spec_to_oracle
+
+
+def _l2(prob, chi):
+    return float(np.linalg.norm(chi))
+
+
+def test_pade13_vs_series():
+    rng = np.random.default_rng(1)
+    for n, scale in [(2, 0.3), (5, 2.0), (17, 9.0)]:
+        A = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) * scale / n
+        E = ko.expm_pade13(A)
+        # scaled Taylor reference
+        s = 12
+        B = A / 2**s
+        T = np.eye(n, dtype=complex)
+        term = np.eye(n, dtype=complex)
+        for j in range(1, 25):
+            term = term @ B / j
+            T = T + term
+        for _ in range(s):
+            T = T @ T
+        assert np.abs(E - T).max() < 1e-12 * max(1.0, np.abs(T).max())
+
+
+def test_tls_dump_all_19_iterations():
+    """reference tests/test_result_serialization/oct_result.dump (notebook 01)."""
+    g = golden('dump_tls_ss')
+    spec = configs.config_c1()
+    assert np.array_equal(spec.tlist, g['tlist'])
+    n_iter = len(g['iters']) - 1
+    out = oracle_optimize(spec, n_iter)
+    # guess pulse must be reproduced exactly (same sampling + un-averaging)
+    assert np.abs(out['all_pulses'][0] - g['all_pulses'][0]).max() == 0.0
+    assert np.abs(out['all_pulses'] - g['all_pulses']).max() < 1e-9
+    assert np.abs(out['tau_vals'][:, 0] - g['tau_vals'][:, 0]).max() < 1e-9
+    J_T_ss = 1 - np.abs(out['tau_vals'][:, 0]) ** 2
+    assert np.abs(J_T_ss - g['info_vals']).max() < 1e-9
+    # measured: ~7e-15 -- keep a tighter regression bound as well
+    assert np.abs(out['all_pulses'] - g['all_pulses']).max() < 1e-12
+
+
+def _lambda_problem(g, mus, controls):
+    """Lambda-system ensemble from a dump fixture, starting at given controls."""
+    H0, Hc, tgt = g['H0'], g['Hc'], g['target']
+    ops = [[H0] + [mu * Hc[l] for l in range(4)] for mu in mus]
+    K = len(mus)
+    init = np.zeros((K, 3), dtype=complex)
+    init[:, 0] = 1
+    prob = ko.OracleProblem(ops, init, np.tile(tgt, (K, 1)), g['tlist'])
+    pulses = [ko.control_onto_interval(c) for c in controls]
+    T = g['tlist'][-1]
+    S = ko.control_onto_interval(ko.discretize(
+        lambda t: ko.flattop(t, 0.0, T, 0.3, func='sinsq'), g['tlist'], args=(), via_midpoints=True))
+    S = np.clip(S, 0, 1)
+    return prob, pulses, [S] * 4
+
+
+def test_ensemble_dump_iterations_12_to_20():
+    """reference docs/notebooks/ensemble_opt_result.dump: K=5, N=3, L=4."""
+    g = golden('dump_ensemble')
+    prob, pulses, S = _lambda_problem(g, g['mu'], g['controls_it12'])
+    lam = [float(g['lambda_a'])] * 4
+    fw_T = ko.forward_propagation(prob, pulses)
+    tau = ko.tau_vals(prob, fw_T)
+    assert np.abs(tau - g['tau_vals'][12]).max() < 1e-9
+    for it in range(13, 21):
+        pulses, fw_T, tau, _ = ko.krotov_iteration(prob, pulses, S, lam, fw_T, tau, ko.chis_re, norm=_l2)
+        assert np.abs(tau - g['tau_vals'][it]).max() < 1e-9, it
+
+
+def test_nonherm_dump_iterations_40_to_45():
+    """reference docs/notebooks/non_herm_opt_result.dump: pins exp(+i H^dag dt)."""
+    g = golden('dump_nonherm')
+    prob, pulses, S = _lambda_problem(g, [1.0], g['controls_it40'])
+    lam = [float(g['lambda_a'])] * 4
+    fw_T = ko.forward_propagation(prob, pulses)
+    tau = ko.tau_vals(prob, fw_T)
+    assert np.abs(tau - g['tau_vals'][40]).max() < 1e-9
+    for it in range(41, 46):
+        pulses, fw_T, tau, _ = ko.krotov_iteration(prob, pulses, S, lam, fw_T, tau, ko.chis_re, norm=_l2)
+        assert np.abs(tau - g['tau_vals'][it]).max() < 1e-9, it
+
+
+def test_lambda_rwa_dump_from_true_guess():
+    """reference docs/notebooks/lambda_rwa_opt_result.dump: 12 it. from the guess."""
+    g = golden('dump_lambda_rwa')
+    prob, pulses, S = _lambda_problem(g, [1.0], g['guess_controls'])
+    fw_T = ko.forward_propagation(prob, pulses)
+    tau = ko.tau_vals(prob, fw_T)
+    assert np.abs(tau - g['tau_vals'][0]).max() < 1e-9
+    lam = [0.5] * 4  # notebook 02, cell 26
+    for it in range(1, 6):
+        pulses, fw_T, tau, _ = ko.krotov_iteration(prob, pulses, S, lam, fw_T, tau, ko.chis_re, norm=_l2)
+        assert np.abs(tau - g['tau_vals'][it]).max() < 1e-9, it
+
+
+def test_transmon17_dump_iterations_5_to_8():
+    """reference docs/notebooks/transmonxgate_opt_result.dump: K=2, N=17."""
+    g = golden('dump_transmon17')
+    H0, H1, psi0, psi1 = g['H0'], g['H1'], g['psi0'], g['psi1']
+    prob = ko.OracleProblem([[H0, H1], [H0, H1]], np.array([psi0, psi1]), np.array([psi1, psi0]), g['tlist'])
+    pulses = [ko.control_onto_interval(g['controls_it5'][0])]
+    S = [np.clip(ko.control_onto_interval(ko.discretize(
+        lambda t: ko.flattop(t, 0.0, 10.0, 0.5, func='sinsq'), g['tlist'], args=(), via_midpoints=True)), 0, 1)]
+    fw_T = ko.forward_propagation(prob, pulses)
+    tau = ko.tau_vals(prob, fw_T)
+    # eigenvector signs are LAPACK's choice: tau of an X gate flips with them
+    sgn = np.sign((tau * np.conj(g['tau_vals'][5])).real)
+    assert np.abs(sgn * tau - g['tau_vals'][5]).max() < 1e-8
+    if not np.all(sgn > 0):
+        pytest.skip("eigenvector sign convention differs from the dump's")
+    for it in range(6, 9):
+        pulses, fw_T, tau, _ = ko.krotov_iteration(prob, pulses, S, [1.0], fw_T, tau, ko.chis_re, norm=_l2)
+        assert np.abs(tau - g['tau_vals'][it]).max() < 1e-8, it
+
+
+REF_CASES = {
+    'ref_c1_tls': lambda: configs.config_c1(),
+    'ref_c2_hilbert': lambda: configs.config_c2_hilbert(),
+    'ref_c2_liouville': lambda: configs.config_c2_liouville(),
+    'ref_c3_iswap': lambda: configs.config_c3(),
+    'ref_c4_small': lambda: configs.config_c4(d=5, nt=201, n_logical=2),
+    'ref_c5_small': lambda: configs.config_c5(K=6, N=16, nt=201, L=1),
+    'ref_c5_small_L3': lambda: configs.config_c5(K=5, N=12, nt=151, L=3, distinct=True),
+    'ref_c5_n64': lambda: configs.config_c5(K=8, N=64, nt=401, L=1),
+}
+
+
+@pytest.mark.parametrize('name', sorted(REF_CASES))
+@pytest.mark.parametrize('use_scipy', [False, True])
+def test_against_real_reference_loop(name, use_scipy):
+    """Outputs of the reference's optimize_pulses (numpy mode) on the same inputs.
+
+    With SciPy's expm (what the reference run used) the restatement is
+    bit-identical here (measured 0.0 on every case); with the oracle's own
+    Pade-13 it agrees to <= 2.3e-12 (worst: the stiff N=25 Liouvillian)."""
+    if use_scipy:
+        pytest.importorskip('scipy')
+    g = golden(name)
+    spec = REF_CASES[name]()
+    out = oracle_optimize(spec, int(g['iter_stop']), use_scipy=use_scipy)
+    tol = 1e-13 if use_scipy else (1e-11 if name == 'ref_c4_small' else 1e-12)
+    scale = max(1.0, np.abs(g['all_pulses']).max())
+    assert np.abs(out['all_pulses'] - g['all_pulses']).max() < tol * scale
+    assert np.abs(out['tau_vals'] - g['tau_vals']).max() < tol
+    assert np.abs(out['fw_T'] - g['fw_T']).max() < tol
+
+
+def test_kat_parallelization_transmon5():
+    """reference tests/test_parallelization.py:113-140: |tau| = 0.9693, 0.7743 +- 1e-3
+    after ONE iteration with skip_initial_forward_propagation (tau_vals[0] is
+    iteration 1's)."""
+    Ec, EjEc, nstates = 0.386, 45, 2
+    Ej = EjEc * Ec
+    n = np.arange(-nstates, nstates + 1)
+    up = np.diag(np.ones(2 * nstates), k=-1)
+    H0 = (np.diag(4 * Ec * n**2) - Ej * (up + up.T) / 2.0).astype(complex)
+    H1 = (-2 * np.diag(n)).astype(complex)
+    ev, V = np.linalg.eigh(H0)
+    psi0, psi1 = V[:, 0].astype(complex), V[:, 1].astype(complex)
+    tlist = np.linspace(0, 10, 100)
+    prob = ko.OracleProblem([[H0, H1], [H0, H1]], np.array([psi0, psi1]), np.array([psi1, psi0]), tlist)
+    _, gp, S = ko.initialize_controls(
+        [lambda t, args: 4 * np.exp(-40.0 * (t / 10 - 0.5) ** 2)],
+        [lambda t: ko.flattop(t, 0.0, 10.0, 0.5, func='sinsq')], tlist)
+    # chis_re ignores fw_T/tau, so skipping the initial propagation is immaterial
+    pulses, fw_T, tau, _ = ko.krotov_iteration(prob, gp, S, [1.0], None, None, ko.chis_re, norm=_l2)
+    assert abs(abs(tau[0]) - 0.9693) < 1e-3
+    assert abs(abs(tau[1]) - 0.7743) < 1e-3
+    # SURVEY.md appendix D probe values
+    assert abs(abs(tau[0]) - 0.96931427) < 1e-7
+    assert abs(abs(tau[1]) - 0.77432511) < 1e-7
+
+
+def test_kat_oct_log_J_T_re():
+    """reference tests/test_krotov/oct.log:2-5 (TLS, chis_re, const guess 0.2,
+    sinsq shape, lambda=5, tests/test_krotov.py:137-163): J_T_re to 3 s.f."""
+    H0 = -0.5 * np.diag([1.0, -1.0]).astype(complex)
+    H1 = np.array([[0, 1], [1, 0]], dtype=complex)
+    tlist = np.linspace(0, 5, 500)
+    prob = ko.OracleProblem([[H0, H1]], np.array([[1, 0]], dtype=complex), np.array([[0, 1]], dtype=complex), tlist)
+    _, gp, S = ko.initialize_controls(
+        [lambda t, args: 0.2],
+        [lambda t: ko.flattop(t, 0.0, 5.0, 0.3, func='sinsq')], tlist)
+    out = ko.optimize(prob, gp, S, [5.0], ko.chis_re, 3, norm=_l2)
+    J = 1 - out['tau_vals'][:, 0].real
+    for got, want in zip(J, [1.00e+00, 7.65e-01, 5.56e-01, 3.89e-01]):
+        assert abs(got - want) < 0.006 * max(want, 1e-3) + 5e-3, (got, want)
+    for got, want in zip(out['g_a'][1:, 0], [1.18e-01, 1.04e-01, 8.37e-02]):
+        assert abs(got - want) < 0.006 * want
