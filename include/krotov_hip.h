@@ -1,0 +1,186 @@
+/*
+ * krotov_hip.h -- C ABI of the MI355X Krotov engine (libkrotov_hip.so).
+ *
+ * The library replaces ONE path of qucontrol/krotov: the per-iteration
+ * backward/forward time propagation and sequential pulse-update loop of
+ * krotov.optimize_pulses (reference src/krotov/optimize.py:393-510), which the
+ * reference dispatches per objective through parallel_map
+ * (src/krotov/parallelization.py:233-495) to krotov.propagators.expm
+ * (src/krotov/propagators.py:79-122).  The reference has no native FFI for
+ * this path (it is pure Python); each entry point below names the Python call
+ * site it stands in for.  INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary: every call returns 0 on
+ *     success or a negative kh_status; kh_last_error() gives the text.
+ *   - complex128 = interleaved (re, im) doubles (numpy/torch layout).
+ *   - operators: dense N x N, row-major.  States: length-N vectors; density
+ *     matrices are column-stacked vec(rho) and operators Liouvillians
+ *     (propagators.py:255-257, 306-307).
+ *   - "dev" pointers are device (HBM) addresses owned by the caller (e.g.
+ *     torch tensors); "host" pointers are ordinary host memory read during the
+ *     call.  stream is a hipStream_t passed as void* (NULL = default stream).
+ *     All sweeps are asynchronous on that stream.
+ *   - not thread-safe per engine; one engine per device per stream.
+ */
+#ifndef KROTOV_HIP_H
+#define KROTOV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kh_engine kh_engine;
+
+typedef struct kh_cdouble {
+    double re, im;
+} kh_cdouble;
+
+enum kh_status {
+    KH_OK = 0,
+    KH_ERR_INVALID = -1,     /* bad argument */
+    KH_ERR_HIP = -2,         /* a HIP runtime call failed */
+    KH_ERR_UNSUPPORTED = -3, /* size outside what the kernels handle */
+    KH_ERR_TIMEOUT = -4,     /* in-kernel exchange gave up (see kh_check) */
+    KH_ERR_NOMEM = -5
+};
+
+/* Problem description handed to kh_engine_create (all host memory, read once).
+ *
+ * ops[k*(1+L) + 0]   : drift operator of objective k   (sum of the non-list
+ *                      entries of Objective.H)
+ * ops[k*(1+L) + 1+l] : operator multiplying control l in objective k (sum over
+ *                      every nested-list entry that carries control l,
+ *                      mu.py:123-134), or NULL when the control does not occur
+ *                      in objective k (mu.py:126-127).
+ * Entries are DEVICE pointers; equal pointers mean a shared operator (the
+ * engine stages each distinct operator, and its adjoint, once).
+ */
+typedef struct kh_problem {
+    int32_t K;        /* objectives handled by this engine (this GPU's shard) */
+    int32_t N;        /* state dimension */
+    int32_t L;        /* controls */
+    int32_t nt;       /* len(tlist); nt-1 intervals */
+    int32_t is_super; /* 0: Hilbert space, eqm factor -i (propagators.py:94);
+                         1: Liouville space, factor 1 (propagators.py:96-98),
+                            and mu = i * dL/d eps (mu.py:130-134) */
+    int32_t reserved;
+    const double *dt;              /* host [nt-1] interval lengths (may vary,
+                                      optimize.py:450) */
+    const kh_cdouble *const *ops;  /* host [K*(1+L)] of dev pointers */
+    const double *op_norms;        /* host [K*(1+L)] upper bounds on the
+                                      spectral norms, or NULL (engine then uses
+                                      Frobenius norms: safe, slower) */
+    double tol;       /* truncation tolerance of the exponential action per
+                         step; 0 -> 2^-53 */
+    double theta_max; /* largest ||A dt|| handled by one Taylor sub-step;
+                         0 -> 1.0 */
+} kh_problem;
+
+/* Last error text of the calling thread ("" if none). */
+const char *kh_last_error(void);
+
+/* Library/kernels build info, e.g. "krotov_hip 0.1 gfx950". */
+const char *kh_version(void);
+
+/* Create an engine on the current HIP device.  Stages adjoint copies of every
+ * distinct operator (the adjoint objectives of optimize.py:263,
+ * objectives.py:240-258) and the exchange workspace. */
+int kh_engine_create(const kh_problem *problem, kh_engine **out);
+void kh_engine_destroy(kh_engine *engine);
+
+/* Which kernel family the engine selected: "tile64" or "generic". */
+const char *kh_engine_kernel(const kh_engine *engine);
+
+/* Forward propagation of K states over the whole grid under fixed pulses.
+ * Replaces parallel_map[0](_forward_propagation, ...) (optimize.py:302-313,
+ * 806-846).
+ *   pulses_dev   [L][nt-1] doubles
+ *   init_dev     [K][N]
+ *   states_dev   [K][nt][N] all stored states (index 0 = init), or NULL to
+ *                store nothing (first-order Krotov discards them, :329)
+ *   psi_T_dev    [K][N] final states
+ */
+int kh_forward_store(kh_engine *engine, const double *pulses_dev,
+                     const kh_cdouble *init_dev, kh_cdouble *states_dev,
+                     kh_cdouble *psi_T_dev, void *stream);
+
+/* Backward propagation of the (normalised) co-states under the guess pulses,
+ * storing chi_k(t_n) for every n.  Replaces parallel_map[1](
+ * _backward_propagation, ...) (optimize.py:413-425, 849-886): adjoint
+ * operators, conjugated (real) pulse values, backwards=True.
+ *   chi_T_dev    [K][N]
+ *   chi_store_dev[K][nt][N]; [:, nt-1] = chi_T
+ */
+int kh_backward_store(kh_engine *engine, const kh_cdouble *chi_T_dev,
+                      const double *pulses_dev, kh_cdouble *chi_store_dev,
+                      void *stream);
+
+/* Forward sweep with the sequential pulse update, whole grid, one launch.
+ * Replaces the time loop optimize.py:444-501 (mu() / overlap() per
+ * (step, pulse, objective), the cross-objective sum at :470, the update at
+ * :471-477 and parallel_map[2](_forward_propagation_step, ...) at :479-491).
+ *   chi_store_dev [K][nt][N] from kh_backward_store
+ *   chi_norms_dev [K]       norms taken out of chi before the backward sweep
+ *   init_dev      [K][N]
+ *   guess_dev     [L][nt-1]
+ *   shape_dev     [L][nt-1] update shapes S_l on the intervals
+ *   lambda_dev    [L]
+ *   opt_dev       [L][nt-1] OUT optimized pulses
+ *   psi_T_dev     [K][N]    OUT
+ *   g_a_dev       [L]       OUT integrals of g_a (optimize.py:475)
+ * The cross-objective sum is evaluated in a fixed order (bitwise repeatable).
+ */
+int kh_forward_update(kh_engine *engine, const kh_cdouble *chi_store_dev,
+                      const double *chi_norms_dev, const kh_cdouble *init_dev,
+                      const double *guess_dev, const double *shape_dev,
+                      const double *lambda_dev, double *opt_dev,
+                      kh_cdouble *psi_T_dev, double *g_a_dev, void *stream);
+
+/* The same sweep cut at the cross-objective sum, for objectives sharded over
+ * several GPUs: the caller all-reduces `partial` (L doubles, Im parts) across
+ * ranks between two calls (RCCL over xGMI).
+ *
+ *   kh_update_begin : phi <- init, opt <- guess, g_a <- 0, and the local
+ *                     partial sums of interval 0 -> partial_dev[L]
+ *   kh_update_step  : given the all-reduced sums D of interval n: update
+ *                     eps[n] (optimize.py:471-477), propagate every local phi
+ *                     over interval n (:479-491) and emit the local partial
+ *                     sums of interval n+1 -> partial_dev[L] (untouched after
+ *                     the last interval)
+ *   kh_update_end   : psi_T <- phi
+ */
+int kh_update_begin(kh_engine *engine, const kh_cdouble *chi_store_dev,
+                    const double *chi_norms_dev, const kh_cdouble *init_dev,
+                    const double *guess_dev, double *opt_dev, double *g_a_dev,
+                    double *partial_dev, void *stream);
+int kh_update_step(kh_engine *engine, int32_t n, const double *D_dev,
+                   const kh_cdouble *chi_store_dev, const double *chi_norms_dev,
+                   const double *shape_dev, const double *lambda_dev,
+                   double *opt_dev, double *g_a_dev, double *partial_dev,
+                   void *stream);
+int kh_update_end(kh_engine *engine, kh_cdouble *psi_T_dev, void *stream);
+
+/* tau_k = <target_k | psi_k(T)> (optimize.py:316-322, 502-508;
+ * second_order.py:69-83).  targets_dev, psi_T_dev [K][N]; tau_dev [K]. */
+int kh_tau(kh_engine *engine, const kh_cdouble *targets_dev,
+           const kh_cdouble *psi_T_dev, kh_cdouble *tau_dev, void *stream);
+
+/* After synchronising the stream: returns KH_ERR_TIMEOUT if an in-kernel
+ * exchange gave up since the last call (outputs are then invalid), else 0. */
+int kh_check(kh_engine *engine);
+
+/* Statistics of the last sweep launched (for the roofline accounting):
+ * stats[0] = Taylor matrix-vector products issued per objective, summed over
+ * the grid (host-side estimate from the pulses is not possible for the update
+ * sweep, so kernels count them), stats[1] = intervals, stats[2] = workgroups. */
+int kh_last_stats(kh_engine *engine, double stats[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KROTOV_HIP_H */

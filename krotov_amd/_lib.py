@@ -1,0 +1,85 @@
+"""ctypes binding of libkrotov_hip.so (the C ABI declared in include/krotov_hip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load,
+:func:`load` raises ``RuntimeError`` and so does everything that needs the
+engine.  ``python __graft_entry__.py`` (or ``krotov_amd.build.build()``)
+compiles it in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libkrotov_hip.so')
+
+KH_OK = 0
+KH_ERR_TIMEOUT = -4
+
+
+class kh_problem(ctypes.Structure):
+    _fields_ = [
+        ('K', ctypes.c_int32),
+        ('N', ctypes.c_int32),
+        ('L', ctypes.c_int32),
+        ('nt', ctypes.c_int32),
+        ('is_super', ctypes.c_int32),
+        ('reserved', ctypes.c_int32),
+        ('dt', ctypes.POINTER(ctypes.c_double)),
+        ('ops', ctypes.POINTER(ctypes.c_void_p)),
+        ('op_norms', ctypes.POINTER(ctypes.c_double)),
+        ('tol', ctypes.c_double),
+        ('theta_max', ctypes.c_double),
+    ]
+
+
+# every symbol include/krotov_hip.h declares: name -> (restype, argtypes)
+_P = ctypes.c_void_p
+SYMBOLS = {
+    'kh_last_error': (ctypes.c_char_p, []),
+    'kh_version': (ctypes.c_char_p, []),
+    'kh_engine_create': (ctypes.c_int, [ctypes.POINTER(kh_problem), ctypes.POINTER(_P)]),
+    'kh_engine_destroy': (None, [_P]),
+    'kh_engine_kernel': (ctypes.c_char_p, [_P]),
+    'kh_forward_store': (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
+    'kh_backward_store': (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    'kh_forward_update': (ctypes.c_int, [_P] * 11),
+    'kh_update_begin': (ctypes.c_int, [_P] * 9),
+    'kh_update_step': (ctypes.c_int, [_P, ctypes.c_int32] + [_P] * 9),
+    'kh_update_end': (ctypes.c_int, [_P, _P, _P]),
+    'kh_tau': (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    'kh_check': (ctypes.c_int, [_P]),
+    'kh_last_stats': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "krotov_amd: %s is missing. Build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise RuntimeError("krotov_amd: cannot load %s: %s" % (LIB_PATH, exc))
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+class KrotovHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != KH_OK:
+        msg = load().kh_last_error().decode('utf-8', 'replace')
+        raise KrotovHipError("libkrotov_hip error %d: %s" % (rc, msg))

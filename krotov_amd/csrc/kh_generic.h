@@ -1,0 +1,357 @@
+// Generic sweep kernels: any state dimension N, any number of controls L.
+//
+// One 256-thread workgroup works on one objective at a time.  Vectors live in
+// LDS; operators are streamed from HBM/L2 every matrix-vector product, 16 lanes
+// per matrix row (256 contiguous bytes per row segment), four rows per wave.
+// This is the correctness path for every shape; N <= 64 problems take the
+// register-resident tile kernels of kh_tile64.h instead.
+#pragma once
+
+#include "kh_common.h"
+
+#define KH_GEN_THREADS 256
+
+struct KhSweepArgs {
+    int K, N, L, nt;
+    const cplx *const *ops;   // [K*(1+L)] operator pointers for this direction
+    const double *op_norms;   // [K*(1+L)]
+    const double *dt;         // [nt-1]
+    double fre, fim;          // equation-of-motion factor f (propagators.py:94-99)
+    double tol, theta_max;
+    double *stats;            // [0] += matvecs issued (per objective, summed)
+};
+
+// LDS layout (dynamic): xa[N] xb[N] acc[N] chi[N] + scratch
+struct KhGenLds {
+    cplx *xa, *xb, *acc, *chi;
+    double *red;  // [KH_GEN_THREADS/64 * 2 * KH_MAX_L] reduction scratch
+    double *D;    // [KH_MAX_L] cross-objective sums of the current interval
+    int *ok;      // exchange status broadcast
+};
+
+__device__ __forceinline__ KhGenLds kh_gen_carve(char *smem, int N) {
+    KhGenLds s;
+    s.xa = (cplx *)smem;
+    s.xb = s.xa + N;
+    s.acc = s.xb + N;
+    s.chi = s.acc + N;
+    s.red = (double *)(s.chi + N);
+    s.D = s.red + (KH_GEN_THREADS / 64) * 2 * KH_MAX_L;
+    s.ok = (int *)(s.D + KH_MAX_L);
+    return s;
+}
+
+__host__ inline size_t kh_gen_lds_bytes(int N) {
+    return (size_t)4 * N * sizeof(cplx) + ((KH_GEN_THREADS / 64) * 2 * KH_MAX_L + KH_MAX_L) * sizeof(double) + 64;
+}
+
+// y[row] = sum_c (h0[row][c] + sum_l eps_l h_l[row][c]) * x[c] for the rows this
+// 16-lane group owns in this pass.  Returns the row sum in every lane of the
+// group (undefined for row >= N).
+__device__ __forceinline__ cplx kh_gen_row_dot(const cplx *const *ops_k, const double *eps, int L, int N, int row,
+                                               int c16, const cplx *x) {
+    cplx sum = c_make(0.0, 0.0);
+    if (row < N) {
+        const size_t off = (size_t)row * N;
+        for (int c = c16; c < N; c += 16) {
+            cplx a = ops_k[0][off + c];
+            for (int l = 0; l < L; ++l) {
+                const cplx *h = ops_k[1 + l];
+                if (h != nullptr) {
+                    const cplx v = h[off + c];
+                    a.x = fma(eps[l], v.x, a.x);
+                    a.y = fma(eps[l], v.y, a.y);
+                }
+            }
+            c_fma(sum, a, x[c]);
+        }
+    }
+    sum.x = sum16(sum.x);
+    sum.y = sum16(sum.y);
+    return sum;
+}
+
+// acc <- exp(f * A(eps) * dt) acc, A = H0 + sum eps_l H_l, by s Taylor
+// sub-steps of degree m.  All threads of the workgroup call this.
+__device__ __forceinline__ int kh_gen_expm_action(const KhSweepArgs &p, const cplx *const *ops_k,
+                                                  const double *norms_k, const double *eps, double dt,
+                                                  const KhGenLds &s) {
+    const int tid = threadIdx.x, N = p.N, L = p.L;
+    const int grp = tid >> 4, c16 = tid & 15;  // 16 groups of 16 lanes
+    double theta = norms_k[0];
+    for (int l = 0; l < L; ++l) theta += fabs(eps[l]) * norms_k[1 + l];
+    theta *= dt;
+    int nsub, m;
+    kh_choose_degree(theta, p.tol, p.theta_max, &nsub, &m);
+    const double h = dt / nsub;
+    for (int sub = 0; sub < nsub; ++sub) {
+        for (int i = tid; i < N; i += KH_GEN_THREADS) s.xa[i] = s.acc[i];
+        __syncthreads();
+        cplx *xin = s.xa, *xout = s.xb;
+        for (int j = 1; j <= m; ++j) {
+            const cplx coef = c_make(p.fre * h / j, p.fim * h / j);
+            for (int row0 = 0; row0 < N; row0 += 16) {
+                const int row = row0 + grp;
+                const cplx d = kh_gen_row_dot(ops_k, eps, L, N, row, c16, xin);
+                if (c16 == 0 && row < N) {
+                    const cplx t = c_mul(coef, d);
+                    xout[row] = t;
+                    s.acc[row].x += t.x;
+                    s.acc[row].y += t.y;
+                }
+            }
+            __syncthreads();
+            cplx *tmp = xin;
+            xin = xout;
+            xout = tmp;
+        }
+    }
+    return nsub * m;
+}
+
+// ---------------------------------------------------------------------------
+// plain propagation with storage (backward sweep, iteration-0 forward sweep)
+// ---------------------------------------------------------------------------
+// direction +1: n = 0..nt-2, state index n -> n+1 (optimize.py:806-846)
+// direction -1: n = nt-2..0, state index n+1 -> n (optimize.py:849-886)
+__global__ void __launch_bounds__(KH_GEN_THREADS)
+kh_gen_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx *__restrict__ state_in,
+                   cplx *__restrict__ store, cplx *__restrict__ state_out, int direction) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KhGenLds s = kh_gen_carve(smem, p.N);
+    const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
+    double matvecs = 0.0;
+    for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
+        const cplx *const *ops_k = p.ops + (size_t)k * (1 + L);
+        const double *norms_k = p.op_norms + (size_t)k * (1 + L);
+        for (int i = tid; i < N; i += KH_GEN_THREADS) s.acc[i] = state_in[(size_t)k * N + i];
+        __syncthreads();
+        if (store != nullptr) {
+            const int idx0 = direction > 0 ? 0 : nt - 1;
+            for (int i = tid; i < N; i += KH_GEN_THREADS) store[((size_t)k * nt + idx0) * N + i] = s.acc[i];
+        }
+        for (int step = 0; step < nt - 1; ++step) {
+            const int n = direction > 0 ? step : nt - 2 - step;
+            double eps[KH_MAX_L];
+            for (int l = 0; l < L; ++l) eps[l] = pulses[(size_t)l * (nt - 1) + n];
+            matvecs += kh_gen_expm_action(p, ops_k, norms_k, eps, p.dt[n], s);
+            if (store != nullptr) {
+                const int idx = direction > 0 ? n + 1 : n;
+                for (int i = tid; i < N; i += KH_GEN_THREADS) store[((size_t)k * nt + idx) * N + i] = s.acc[i];
+            }
+        }
+        if (state_out != nullptr)
+            for (int i = tid; i < N; i += KH_GEN_THREADS) state_out[(size_t)k * N + i] = s.acc[i];
+        __syncthreads();
+    }
+    if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
+}
+
+// ---------------------------------------------------------------------------
+// forward sweep with sequential pulse update (optimize.py:444-508)
+// ---------------------------------------------------------------------------
+struct KhUpdateArgs {
+    // dH/d eps_l of objective k is the forward control operator ops[k*(1+L)+1+l]
+    // itself (mu.py:123-134: linear controls), times:
+    double mu_re, mu_im;        // 1 (Hilbert) or i (Liouville), mu.py:130-134
+    const cplx *chi_store;      // [K][nt][N]
+    const double *chi_norms;    // [K]
+    cplx *phi;                  // [K][N] running forward states (engine workspace)
+    const double *guess;        // [L][nt-1]
+    const double *shape;        // [L][nt-1]
+    const double *lambda;       // [L]
+    double *opt;                // [L][nt-1]
+    double *g_a;                // [L]
+    double *wg_partial;         // [G][L] per-workgroup partial sums (stepwise mode)
+    const double *D_in;         // [L] all-reduced sums (stepwise mode)
+    int n_begin, n_end;         // intervals [n_begin, n_end) are applied; partials of n_end are emitted
+    int internal_exchange;      // 1: gather in-kernel (single launch over the grid)
+};
+
+// Im( mu * norm_k * <chi_k(t_n) | H_l phi_k> ) summed over this workgroup's
+// objectives, for every control l -> part[l] (valid in every thread).
+__device__ __forceinline__ void kh_gen_partials(const KhSweepArgs &p, const KhUpdateArgs &u, int n,
+                                                const KhGenLds &s, double (&part)[KH_MAX_L]) {
+    const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
+    const int grp = tid >> 4, c16 = tid & 15, wave = tid >> 6, lane = tid & 63;
+    for (int l = 0; l < KH_MAX_L; ++l) part[l] = 0.0;
+    const double zero_eps[1] = {0.0};
+    for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
+        for (int i = tid; i < N; i += KH_GEN_THREADS) {
+            s.xa[i] = u.phi[(size_t)k * N + i];
+            s.chi[i] = u.chi_store[((size_t)k * nt + n) * N + i];
+        }
+        __syncthreads();
+        const double nrm = u.chi_norms[k];
+        for (int l = 0; l < L; ++l) {
+            const cplx *h = p.ops[(size_t)k * (1 + L) + 1 + l];
+            cplx ov = c_make(0.0, 0.0);  // <chi | H_l phi>, partial over this thread's rows
+            if (h != nullptr) {
+                const cplx *one_op[1] = {h};
+                for (int row0 = 0; row0 < N; row0 += 16) {
+                    const int row = row0 + grp;
+                    const cplx d = kh_gen_row_dot(one_op, zero_eps, 0, N, row, c16, s.xa);
+                    if (c16 == 0 && row < N) c_fma_conj(ov, s.chi[row], d);
+                }
+            }
+            // workgroup reduction in a fixed order: lanes (sum64) then waves
+            const double re = sum64(ov.x), im = sum64(ov.y);
+            if (lane == 0) {
+                s.red[(wave * KH_MAX_L + l) * 2 + 0] = re;
+                s.red[(wave * KH_MAX_L + l) * 2 + 1] = im;
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < L; ++l) {
+            double re = 0.0, im = 0.0;
+            for (int w = 0; w < KH_GEN_THREADS / 64; ++w) {
+                re += s.red[(w * KH_MAX_L + l) * 2 + 0];
+                im += s.red[(w * KH_MAX_L + l) * 2 + 1];
+            }
+            // Im(mu * ov) * norm  (optimize.py:466-467, 473)
+            part[l] += nrm * (u.mu_re * im + u.mu_im * re);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(KH_GEN_THREADS)
+kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KhGenLds s = kh_gen_carve(smem, p.N);
+    double *D_sh = s.D;  // all LDS in the dynamic region (keeps its base 16-byte aligned)
+    int *ok_sh_p = s.ok;
+    const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
+    const int wave = tid >> 6, lane = tid & 63;
+    double matvecs = 0.0;
+    double part[KH_MAX_L];
+    double g_a_loc[KH_MAX_L];
+    for (int l = 0; l < KH_MAX_L; ++l) g_a_loc[l] = 0.0;
+
+    // partial sums of the first interval handled by this launch
+    if (u.internal_exchange || u.n_begin == u.n_end) {
+        // (stepwise mode enters with the partials of n_begin already reduced in D_in,
+        //  except for the begin call n_begin == n_end == 0 which only emits them)
+        if (u.n_begin < nt - 1) kh_gen_partials(p, u, u.n_begin, s, part);
+    }
+    if (!u.internal_exchange && u.n_begin == u.n_end) {
+        if (tid == 0)
+            for (int l = 0; l < L; ++l) u.wg_partial[(size_t)blockIdx.x * L + l] = part[l];
+        return;
+    }
+
+    for (int n = u.n_begin; n < u.n_end; ++n) {
+        // ---- cross-objective sum D_l (optimize.py:470) ----
+        if (u.internal_exchange) {
+            if (wave == 0) {
+                if (lane == 0)
+                    for (int l = 0; l < L; ++l) kh_publish(ex, n & 1, blockIdx.x, L, l, part[l], (unsigned)(n + 1));
+                double D[KH_MAX_L];
+                const bool ok = kh_gather<KH_MAX_L>(ex, n & 1, L, (unsigned)(n + 1), lane, D);
+                if (lane == 0) {
+                    *ok_sh_p = ok ? 1 : 0;
+                    for (int l = 0; l < L; ++l) D_sh[l] = D[l];
+                }
+            }
+            __syncthreads();
+            if (!*ok_sh_p) return;
+        } else {
+            if (tid == 0)
+                for (int l = 0; l < L; ++l) D_sh[l] = u.D_in[l];
+            __syncthreads();
+        }
+        // ---- pulse update (optimize.py:471-477) ----
+        const double dt = p.dt[n];
+        double eps[KH_MAX_L];
+        for (int l = 0; l < L; ++l) {
+            const double S = u.shape[(size_t)l * (nt - 1) + n];
+            const double lam = u.lambda[l];
+            const double d1 = D_sh[l];
+            eps[l] = u.guess[(size_t)l * (nt - 1) + n] + (S / lam) * d1;
+            g_a_loc[l] += (S / lam) * (d1 * d1) * dt;
+        }
+        if (blockIdx.x == 0 && tid == 0)
+            for (int l = 0; l < L; ++l) u.opt[(size_t)l * (nt - 1) + n] = eps[l];
+        // ---- propagate every local objective over interval n (optimize.py:479-491) ----
+        for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
+            const cplx *const *ops_k = p.ops + (size_t)k * (1 + L);
+            const double *norms_k = p.op_norms + (size_t)k * (1 + L);
+            for (int i = tid; i < N; i += KH_GEN_THREADS) s.acc[i] = u.phi[(size_t)k * N + i];
+            __syncthreads();
+            matvecs += kh_gen_expm_action(p, ops_k, norms_k, eps, dt, s);
+            for (int i = tid; i < N; i += KH_GEN_THREADS) u.phi[(size_t)k * N + i] = s.acc[i];
+            __syncthreads();
+        }
+        // ---- partial sums of the next interval ----
+        if (n + 1 < nt - 1) {
+            // phi written above by this same workgroup: visible after the barrier
+            kh_gen_partials(p, u, n + 1, s, part);
+            matvecs += (double)L;
+        }
+    }
+    if (!u.internal_exchange && u.n_end < nt - 1 && tid == 0)
+        for (int l = 0; l < L; ++l) u.wg_partial[(size_t)blockIdx.x * L + l] = part[l];
+    if (blockIdx.x == 0 && tid == 0)
+        for (int l = 0; l < L; ++l) u.g_a[l] = (u.internal_exchange ? 0.0 : u.g_a[l]) + g_a_loc[l];
+    if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
+}
+
+// sum of per-workgroup partials in workgroup order -> out[L]  (stepwise mode)
+__global__ void kh_reduce_partials(const double *__restrict__ wg_partial, int G, int L, double *__restrict__ out) {
+    const int l = threadIdx.x;
+    if (l < L) {
+        double acc = 0.0;
+        for (int g = 0; g < G; ++g) acc += wg_partial[(size_t)g * L + l];
+        out[l] = acc;
+    }
+}
+
+// tau_k = <target_k | psi_k>  (second_order.py:69-83); one wave per objective
+__global__ void kh_tau_kernel(const cplx *__restrict__ targets, const cplx *__restrict__ psi, cplx *__restrict__ tau,
+                              int K, int N) {
+    const int k = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    cplx acc = c_make(0.0, 0.0);
+    for (int i = lane; i < N; i += 64) c_fma_conj(acc, targets[(size_t)k * N + i], psi[(size_t)k * N + i]);
+    const double re = sum64(acc.x), im = sum64(acc.y);
+    if (lane == 0) tau[k] = c_make(re, im);
+}
+
+// Frobenius norms of the operators (fallback when the caller gives no bounds)
+__global__ void kh_fro_norms(const cplx *const *ops, int count, int N, double *norms) {
+    const int idx = blockIdx.x;
+    if (idx >= count) return;
+    const cplx *a = ops[idx];
+    double acc = 0.0;
+    if (a != nullptr)
+        for (size_t i = threadIdx.x; i < (size_t)N * N; i += blockDim.x) acc += a[i].x * a[i].x + a[i].y * a[i].y;
+    acc = sum64(acc);
+    __shared__ double red[16];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) t += red[w];
+        norms[idx] = sqrt(t);
+    }
+}
+
+// out[c][r] = conj(in[r][c]); 32x32 tiles through LDS
+__global__ void kh_adjoint_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, int N) {
+    __shared__ cplx tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        if (r < N && c < N) tile[j][tx] = in[(size_t)r * N + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = bx + j, c = by + tx;  // out row = in col
+        if (r < N && c < N) {
+            const cplx v = tile[tx][j];
+            out[(size_t)r * N + c] = c_make(v.x, -v.y);
+        }
+    }
+}

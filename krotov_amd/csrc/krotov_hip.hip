@@ -1,0 +1,452 @@
+// libkrotov_hip.so -- C ABI of the MI355X Krotov engine (include/krotov_hip.h).
+//
+// Host side: engine object, operator staging (adjoint copies), kernel-family
+// selection and launches.  Device side: kh_tile64.h (N <= 64, operators in
+// registers) and kh_generic.h (any N).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/krotov_hip.h"
+#include "kh_common.h"
+#include "kh_generic.h"
+#include "kh_tile64.h"
+
+static thread_local std::string g_last_error;
+
+static int kh_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define KH_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (call);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return kh_fail(KH_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                               \
+    } while (0)
+
+enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2 };
+
+struct kh_engine {
+    int K, N, L, nt, is_super;
+    double tol, theta_max;
+    int device, num_cus;
+    KernelKind kind;
+    int grid_update;  // workgroups of the single-launch update sweep
+    // device-side problem data
+    const cplx **d_ops_fw = nullptr;  // [K*(1+L)]
+    const cplx **d_ops_bw = nullptr;  // [K*(1+L)] adjoints
+    double *d_norms = nullptr;        // [K*(1+L)]
+    double *d_dt = nullptr;           // [nt-1]
+    std::vector<void *> owned;        // adjoint operator copies
+    // workspaces
+    cplx *d_phi = nullptr;            // [K][N]
+    kh_u64 *d_slots = nullptr;        // [2][G][L][2]
+    unsigned int *d_abort = nullptr;
+    double *d_stats = nullptr;        // [4]
+    double *d_wg_partial = nullptr;   // [G][L]
+    const double *guess_dev = nullptr;  // remembered by kh_update_begin
+    size_t slots_bytes = 0;
+    double last_intervals = 0, last_wgs = 0;
+};
+
+extern "C" const char *kh_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char *kh_version(void) { return "krotov_hip 0.1 (gfx950; tile64 + generic kernels)"; }
+
+extern "C" const char *kh_engine_kernel(const kh_engine *e) {
+    if (e == nullptr) return "";
+    switch (e->kind) {
+        case KIND_TILE_RPT2: return "tile64/256";
+        case KIND_TILE_RPT1: return "tile64/512";
+        default: return "generic";
+    }
+}
+
+static KhSweepArgs sweep_args(const kh_engine *e, bool backward) {
+    KhSweepArgs p;
+    p.K = e->K;
+    p.N = e->N;
+    p.L = e->L;
+    p.nt = e->nt;
+    p.ops = backward ? e->d_ops_bw : e->d_ops_fw;
+    p.op_norms = e->d_norms;
+    p.dt = e->d_dt;
+    // equation-of-motion factor (propagators.py:94-99): -i, conj for backwards; 1 for Liouvillians
+    if (e->is_super) {
+        p.fre = 1.0;
+        p.fim = 0.0;
+    } else {
+        p.fre = 0.0;
+        p.fim = backward ? 1.0 : -1.0;
+    }
+    p.tol = e->tol;
+    p.theta_max = e->theta_max;
+    p.stats = e->d_stats;
+    return p;
+}
+
+extern "C" void kh_engine_destroy(kh_engine *e) {
+    if (e == nullptr) return;
+    for (void *ptr : e->owned) (void)hipFree(ptr);
+    (void)hipFree((void *)e->d_ops_fw);
+    (void)hipFree((void *)e->d_ops_bw);
+    (void)hipFree(e->d_norms);
+    (void)hipFree(e->d_dt);
+    (void)hipFree(e->d_phi);
+    (void)hipFree(e->d_slots);
+    (void)hipFree(e->d_abort);
+    (void)hipFree(e->d_stats);
+    (void)hipFree(e->d_wg_partial);
+    delete e;
+}
+
+extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
+    if (pr == nullptr || out == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (pr->K < 1 || pr->N < 1 || pr->L < 0 || pr->nt < 2)
+        return kh_fail(KH_ERR_INVALID, "bad sizes K=%d N=%d L=%d nt=%d", pr->K, pr->N, pr->L, pr->nt);
+    if (pr->L > KH_MAX_L) return kh_fail(KH_ERR_UNSUPPORTED, "L=%d controls > %d", pr->L, KH_MAX_L);
+    if (pr->dt == nullptr || pr->ops == nullptr) return kh_fail(KH_ERR_INVALID, "dt/ops missing");
+    for (int n = 0; n < pr->nt - 1; ++n)
+        if (!(pr->dt[n] > 0.0)) return kh_fail(KH_ERR_INVALID, "dt[%d] = %g is not positive", n, pr->dt[n]);
+    const size_t nops = (size_t)pr->K * (1 + pr->L);
+    for (int k = 0; k < pr->K; ++k)
+        if (pr->ops[(size_t)k * (1 + pr->L)] == nullptr)
+            return kh_fail(KH_ERR_INVALID, "objective %d has no drift operator", k);
+
+    kh_engine *e = new kh_engine();
+    e->K = pr->K;
+    e->N = pr->N;
+    e->L = pr->L;
+    e->nt = pr->nt;
+    e->is_super = pr->is_super ? 1 : 0;
+    e->tol = pr->tol > 0.0 ? pr->tol : ldexp(1.0, -53);
+    e->theta_max = pr->theta_max > 0.0 ? pr->theta_max : 1.0;
+#define KH_HIP_E(call)                                                                   \
+    do {                                                                                 \
+        hipError_t _e = (call);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            kh_engine_destroy(e);                                                        \
+            return kh_fail(KH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e));   \
+        }                                                                                \
+    } while (0)
+    KH_HIP_E(hipGetDevice(&e->device));
+    hipDeviceProp_t prop;
+    KH_HIP_E(hipGetDeviceProperties(&prop, e->device));
+    e->num_cus = prop.multiProcessorCount;
+    if (kh_gen_lds_bytes(e->N) > (size_t)prop.sharedMemPerBlock && kh_gen_lds_bytes(e->N) > 160 * 1024) {
+        kh_engine_destroy(e);
+        return kh_fail(KH_ERR_UNSUPPORTED, "N=%d needs %zu bytes of LDS", pr->N, kh_gen_lds_bytes(pr->N));
+    }
+
+    // ---- operator tables: forward pointers as given, adjoints staged once per distinct operator
+    std::vector<const cplx *> fw(nops), bw(nops);
+    std::map<const void *, cplx *> adj_of;
+    for (size_t i = 0; i < nops; ++i) {
+        const cplx *src = (const cplx *)pr->ops[i];
+        fw[i] = src;
+        if (src == nullptr) {
+            bw[i] = nullptr;
+            continue;
+        }
+        auto it = adj_of.find(src);
+        if (it == adj_of.end()) {
+            cplx *dst = nullptr;
+            KH_HIP_E(hipMalloc(&dst, sizeof(cplx) * (size_t)e->N * e->N));
+            e->owned.push_back(dst);
+            const int tiles = (e->N + 31) / 32;
+            kh_adjoint_kernel<<<dim3(tiles, tiles), 256>>>(src, dst, e->N);
+            it = adj_of.emplace(src, dst).first;
+        }
+        bw[i] = it->second;
+    }
+    KH_HIP_E(hipGetLastError());
+    KH_HIP_E(hipMalloc((void **)&e->d_ops_fw, sizeof(cplx *) * nops));
+    KH_HIP_E(hipMalloc((void **)&e->d_ops_bw, sizeof(cplx *) * nops));
+    KH_HIP_E(hipMemcpy((void *)e->d_ops_fw, fw.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
+    KH_HIP_E(hipMemcpy((void *)e->d_ops_bw, bw.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
+    KH_HIP_E(hipMalloc(&e->d_norms, sizeof(double) * nops));
+    if (pr->op_norms != nullptr) {
+        KH_HIP_E(hipMemcpy(e->d_norms, pr->op_norms, sizeof(double) * nops, hipMemcpyHostToDevice));
+    } else {
+        kh_fro_norms<<<(unsigned)nops, 256>>>(e->d_ops_fw, (int)nops, e->N, e->d_norms);
+        KH_HIP_E(hipGetLastError());
+    }
+    KH_HIP_E(hipMalloc(&e->d_dt, sizeof(double) * (e->nt - 1)));
+    KH_HIP_E(hipMemcpy(e->d_dt, pr->dt, sizeof(double) * (e->nt - 1), hipMemcpyHostToDevice));
+
+    // ---- kernel family
+    e->kind = KIND_GENERIC;
+    e->grid_update = e->K < e->num_cus ? e->K : e->num_cus;
+    const char *force = getenv("KH_KERNEL");  // "generic" | "tile256" | "tile512" (testing)
+    const bool tile_ok = e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && e->K <= e->num_cus;
+    if (tile_ok && !(force && strcmp(force, "generic") == 0)) {
+        e->kind = (e->L == 1) ? KIND_TILE_RPT2 : KIND_TILE_RPT1;
+        if (force && strcmp(force, "tile512") == 0) e->kind = KIND_TILE_RPT1;
+        if (force && strcmp(force, "tile256") == 0 && e->L <= 2) e->kind = KIND_TILE_RPT2;
+        e->grid_update = e->K;
+    }
+
+    // ---- workspaces
+    KH_HIP_E(hipMalloc(&e->d_phi, sizeof(cplx) * (size_t)e->K * e->N));
+    const int Lx = e->L > 0 ? e->L : 1;
+    e->slots_bytes = sizeof(kh_u64) * 2 * (size_t)e->grid_update * Lx * 2;
+    KH_HIP_E(hipMalloc(&e->d_slots, e->slots_bytes));
+    KH_HIP_E(hipMalloc(&e->d_abort, sizeof(unsigned int)));
+    KH_HIP_E(hipMemset(e->d_abort, 0, sizeof(unsigned int)));
+    KH_HIP_E(hipMalloc(&e->d_stats, sizeof(double) * 4));
+    KH_HIP_E(hipMemset(e->d_stats, 0, sizeof(double) * 4));
+    KH_HIP_E(hipMalloc(&e->d_wg_partial, sizeof(double) * (size_t)e->grid_update * Lx));
+    KH_HIP_E(hipDeviceSynchronize());
+#undef KH_HIP_E
+    *out = e;
+    return KH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------
+
+template <int RPT, int LT>
+static void launch_tile_store(const kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in,
+                              cplx *store, cplx *out, int direction, hipStream_t st) {
+    kh_tile_sweep_store<RPT, LT><<<e->K, 512 / RPT, 0, st>>>(p, pulses, in, store, out, direction);
+}
+
+template <int RPT>
+static int dispatch_tile_store(const kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in,
+                               cplx *store, cplx *out, int direction, hipStream_t st) {
+    switch (e->L) {
+        case 1: launch_tile_store<RPT, 1>(e, p, pulses, in, store, out, direction, st); break;
+        case 2: launch_tile_store<RPT, 2>(e, p, pulses, in, store, out, direction, st); break;
+        case 3: launch_tile_store<1, 3>(e, p, pulses, in, store, out, direction, st); break;
+        case 4: launch_tile_store<1, 4>(e, p, pulses, in, store, out, direction, st); break;
+        default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");
+    }
+    return KH_OK;
+}
+
+static int sweep_store(kh_engine *e, bool backward, const double *pulses, const cplx *in, cplx *store, cplx *out,
+                       hipStream_t st) {
+    const KhSweepArgs p = sweep_args(e, backward);
+    const int direction = backward ? -1 : +1;
+    KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
+    int rc = KH_OK;
+    if (e->kind == KIND_TILE_RPT2) {
+        rc = dispatch_tile_store<2>(e, p, pulses, in, store, out, direction, st);
+    } else if (e->kind == KIND_TILE_RPT1) {
+        rc = dispatch_tile_store<1>(e, p, pulses, in, store, out, direction, st);
+    } else {
+        const size_t lds = kh_gen_lds_bytes(e->N);
+        if (lds > 64 * 1024)
+            KH_HIP(hipFuncSetAttribute((const void *)kh_gen_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+        kh_gen_sweep_store<<<e->K, KH_GEN_THREADS, lds, st>>>(p, pulses, in, store, out, direction);
+    }
+    if (rc != KH_OK) return rc;
+    KH_HIP(hipGetLastError());
+    e->last_intervals = e->nt - 1;
+    e->last_wgs = e->K;
+    return KH_OK;
+}
+
+extern "C" int kh_forward_store(kh_engine *e, const double *pulses_dev, const kh_cdouble *init_dev,
+                                kh_cdouble *states_dev, kh_cdouble *psi_T_dev, void *stream) {
+    if (e == nullptr || pulses_dev == nullptr && e->L > 0 || init_dev == nullptr)
+        return kh_fail(KH_ERR_INVALID, "null argument");
+    return sweep_store(e, false, pulses_dev, (const cplx *)init_dev, (cplx *)states_dev, (cplx *)psi_T_dev,
+                       (hipStream_t)stream);
+}
+
+extern "C" int kh_backward_store(kh_engine *e, const kh_cdouble *chi_T_dev, const double *pulses_dev,
+                                 kh_cdouble *chi_store_dev, void *stream) {
+    if (e == nullptr || chi_T_dev == nullptr || chi_store_dev == nullptr)
+        return kh_fail(KH_ERR_INVALID, "null argument");
+    return sweep_store(e, true, pulses_dev, (const cplx *)chi_T_dev, (cplx *)chi_store_dev, nullptr,
+                       (hipStream_t)stream);
+}
+
+template <int RPT, int LT>
+static void launch_tile_update(const kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u, const KhExchange &ex,
+                               hipStream_t st) {
+    kh_tile_forward_update<RPT, LT><<<e->K, 512 / RPT, 0, st>>>(p, u, ex);
+}
+
+static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
+    const KhSweepArgs p = sweep_args(e, false);
+    KhExchange ex;
+    ex.slots = e->d_slots;
+    ex.abort_flag = e->d_abort;
+    ex.G = e->grid_update;
+    ex.timeout_ticks = 100000000LL;  // 1 s of the 100 MHz wall clock
+    if (u.internal_exchange) KH_HIP(hipMemsetAsync(e->d_slots, 0, e->slots_bytes, st));
+    if (e->kind == KIND_TILE_RPT2 || e->kind == KIND_TILE_RPT1) {
+        const bool rpt2 = e->kind == KIND_TILE_RPT2;
+        switch (e->L) {
+            case 1: rpt2 ? launch_tile_update<2, 1>(e, p, u, ex, st) : launch_tile_update<1, 1>(e, p, u, ex, st); break;
+            case 2: rpt2 ? launch_tile_update<2, 2>(e, p, u, ex, st) : launch_tile_update<1, 2>(e, p, u, ex, st); break;
+            case 3: launch_tile_update<1, 3>(e, p, u, ex, st); break;
+            case 4: launch_tile_update<1, 4>(e, p, u, ex, st); break;
+            default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");
+        }
+    } else {
+        const size_t lds = kh_gen_lds_bytes(e->N);
+        if (lds > 64 * 1024)
+            KH_HIP(hipFuncSetAttribute((const void *)kh_gen_forward_update,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kh_gen_forward_update<<<e->grid_update, KH_GEN_THREADS, lds, st>>>(p, u, ex);
+    }
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
+static KhUpdateArgs update_args(kh_engine *e, const kh_cdouble *chi_store, const double *chi_norms,
+                                const double *guess, const double *shape, const double *lambda, double *opt,
+                                double *g_a) {
+    KhUpdateArgs u;
+    u.mu_re = e->is_super ? 0.0 : 1.0;  // mu.py:130-134
+    u.mu_im = e->is_super ? 1.0 : 0.0;
+    u.chi_store = (const cplx *)chi_store;
+    u.chi_norms = chi_norms;
+    u.phi = e->d_phi;
+    u.guess = guess;
+    u.shape = shape;
+    u.lambda = lambda;
+    u.opt = opt;
+    u.g_a = g_a;
+    u.wg_partial = e->d_wg_partial;
+    u.D_in = nullptr;
+    u.n_begin = 0;
+    u.n_end = e->nt - 1;
+    u.internal_exchange = 1;
+    return u;
+}
+
+extern "C" int kh_forward_update(kh_engine *e, const kh_cdouble *chi_store_dev, const double *chi_norms_dev,
+                                 const kh_cdouble *init_dev, const double *guess_dev, const double *shape_dev,
+                                 const double *lambda_dev, double *opt_dev, kh_cdouble *psi_T_dev, double *g_a_dev,
+                                 void *stream) {
+    if (e == nullptr || chi_store_dev == nullptr || chi_norms_dev == nullptr || init_dev == nullptr ||
+        guess_dev == nullptr || shape_dev == nullptr || lambda_dev == nullptr || opt_dev == nullptr ||
+        psi_T_dev == nullptr || g_a_dev == nullptr)
+        return kh_fail(KH_ERR_INVALID, "null argument");
+    if (e->L < 1) return kh_fail(KH_ERR_INVALID, "no controls to update");
+    if (opt_dev == guess_dev) return kh_fail(KH_ERR_INVALID, "opt_dev must not alias guess_dev");
+    hipStream_t st = (hipStream_t)stream;
+    KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
+    KH_HIP(hipMemcpyAsync(e->d_phi, init_dev, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice, st));
+    KhUpdateArgs u =
+        update_args(e, chi_store_dev, chi_norms_dev, guess_dev, shape_dev, lambda_dev, opt_dev, g_a_dev);
+    int rc = launch_update(e, u, st);
+    if (rc != KH_OK) return rc;
+    KH_HIP(hipMemcpyAsync(psi_T_dev, e->d_phi, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice, st));
+    e->last_intervals = e->nt - 1;
+    e->last_wgs = e->grid_update;
+    return KH_OK;
+}
+
+extern "C" int kh_update_begin(kh_engine *e, const kh_cdouble *chi_store_dev, const double *chi_norms_dev,
+                               const kh_cdouble *init_dev, const double *guess_dev, double *opt_dev,
+                               double *g_a_dev, double *partial_dev, void *stream) {
+    if (e == nullptr || chi_store_dev == nullptr || chi_norms_dev == nullptr || init_dev == nullptr ||
+        guess_dev == nullptr || opt_dev == nullptr || g_a_dev == nullptr || partial_dev == nullptr)
+        return kh_fail(KH_ERR_INVALID, "null argument");
+    if (e->L < 1) return kh_fail(KH_ERR_INVALID, "no controls to update");
+    hipStream_t st = (hipStream_t)stream;
+    e->guess_dev = guess_dev;
+    KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
+    KH_HIP(hipMemcpyAsync(e->d_phi, init_dev, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice, st));
+    KH_HIP(hipMemcpyAsync(opt_dev, guess_dev, sizeof(double) * (size_t)e->L * (e->nt - 1),
+                          hipMemcpyDeviceToDevice, st));
+    KH_HIP(hipMemsetAsync(g_a_dev, 0, sizeof(double) * e->L, st));
+    KhUpdateArgs u = update_args(e, chi_store_dev, chi_norms_dev, guess_dev, nullptr, nullptr, opt_dev, g_a_dev);
+    u.internal_exchange = 0;
+    u.n_begin = u.n_end = 0;
+    int rc = launch_update(e, u, st);
+    if (rc != KH_OK) return rc;
+    kh_reduce_partials<<<1, 64, 0, st>>>(e->d_wg_partial, e->grid_update, e->L, partial_dev);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
+extern "C" int kh_update_step(kh_engine *e, int32_t n, const double *D_dev, const kh_cdouble *chi_store_dev,
+                              const double *chi_norms_dev, const double *shape_dev, const double *lambda_dev,
+                              double *opt_dev, double *g_a_dev, double *partial_dev, void *stream) {
+    if (e == nullptr || D_dev == nullptr || chi_store_dev == nullptr || chi_norms_dev == nullptr ||
+        shape_dev == nullptr || lambda_dev == nullptr || opt_dev == nullptr || g_a_dev == nullptr ||
+        partial_dev == nullptr)
+        return kh_fail(KH_ERR_INVALID, "null argument");
+    if (e->guess_dev == nullptr) return kh_fail(KH_ERR_INVALID, "kh_update_begin was not called");
+    if (n < 0 || n >= e->nt - 1) return kh_fail(KH_ERR_INVALID, "interval %d out of range", n);
+    hipStream_t st = (hipStream_t)stream;
+    KhUpdateArgs u =
+        update_args(e, chi_store_dev, chi_norms_dev, e->guess_dev, shape_dev, lambda_dev, opt_dev, g_a_dev);
+    u.internal_exchange = 0;
+    u.D_in = D_dev;
+    u.n_begin = n;
+    u.n_end = n + 1;
+    int rc = launch_update(e, u, st);
+    if (rc != KH_OK) return rc;
+    if (n + 1 < e->nt - 1) {
+        kh_reduce_partials<<<1, 64, 0, st>>>(e->d_wg_partial, e->grid_update, e->L, partial_dev);
+        KH_HIP(hipGetLastError());
+    }
+    return KH_OK;
+}
+
+extern "C" int kh_update_end(kh_engine *e, kh_cdouble *psi_T_dev, void *stream) {
+    if (e == nullptr || psi_T_dev == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
+    KH_HIP(hipMemcpyAsync(psi_T_dev, e->d_phi, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
+    e->guess_dev = nullptr;
+    return KH_OK;
+}
+
+extern "C" int kh_tau(kh_engine *e, const kh_cdouble *targets_dev, const kh_cdouble *psi_T_dev,
+                      kh_cdouble *tau_dev, void *stream) {
+    if (e == nullptr || targets_dev == nullptr || psi_T_dev == nullptr || tau_dev == nullptr)
+        return kh_fail(KH_ERR_INVALID, "null argument");
+    const int waves_per_block = 4;
+    const int blocks = (e->K + waves_per_block - 1) / waves_per_block;
+    kh_tau_kernel<<<blocks, 64 * waves_per_block, 0, (hipStream_t)stream>>>(
+        (const cplx *)targets_dev, (const cplx *)psi_T_dev, (cplx *)tau_dev, e->K, e->N);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
+extern "C" int kh_check(kh_engine *e) {
+    if (e == nullptr) return kh_fail(KH_ERR_INVALID, "null engine");
+    unsigned int flag = 0;
+    KH_HIP(hipMemcpy(&flag, e->d_abort, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag != 0) {
+        KH_HIP(hipMemset(e->d_abort, 0, sizeof(flag)));
+        return kh_fail(KH_ERR_TIMEOUT, "in-kernel exchange timed out: outputs of the last update sweep are invalid");
+    }
+    return KH_OK;
+}
+
+extern "C" int kh_last_stats(kh_engine *e, double stats[4]) {
+    if (e == nullptr || stats == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
+    double d[4] = {0, 0, 0, 0};
+    KH_HIP(hipMemcpy(d, e->d_stats, sizeof(d), hipMemcpyDeviceToHost));
+    stats[0] = d[0];
+    stats[1] = e->last_intervals;
+    stats[2] = e->last_wgs;
+    stats[3] = 0.0;
+    return KH_OK;
+}

@@ -1,0 +1,221 @@
+"""Python handle on the HIP Krotov engine (thin layer over the C ABI).
+
+PyTorch-ROCm is used for device memory and streams only: every array the
+engine touches is a ``torch`` tensor in HBM whose ``data_ptr()`` is handed to
+``libkrotov_hip.so``; all arithmetic happens in the HIP kernels.
+
+The three sweeps map onto the reference's three ``parallel_map`` dispatches
+(reference src/krotov/optimize.py:302-313, 413-425, 444-501).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ['HipKrotovEngine']
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "krotov_amd: no HIP device visible (torch.cuda.is_available() is False); "
+            "the engine has no CPU fallback"
+        )
+
+
+class HipKrotovEngine:
+    """K objectives x N-dimensional states x L controls on one GPU.
+
+    Args:
+        ops: list (K) of lists ``[H0, H_1, ..., H_L]`` of (N, N) complex arrays
+            (NumPy or torch); ``None`` where a control does not occur in an
+            objective.  Entries that are the *same object* are uploaded once
+            and shared on the device.
+        dt: (nt-1,) interval lengths.
+        is_super: operators are Liouvillians acting on column-stacked vec(rho).
+        op_norms: optional (K, 1+L) spectral-norm bounds; computed on the host
+            with ``numpy.linalg.norm(., 2)`` per distinct operator when omitted.
+        device: torch device (default: current CUDA/HIP device).
+    """
+
+    def __init__(self, ops, dt, is_super=False, op_norms=None, device=None, tol=0.0, theta_max=0.0):
+        _require_gpu()
+        self._lib = _lib.load()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.K = len(ops)
+        self.L = len(ops[0]) - 1
+        self.is_super = bool(is_super)
+        dt = np.ascontiguousarray(np.asarray(dt, dtype=np.float64))
+        self.nt = len(dt) + 1
+        self._dt = dt
+        self._handle = ctypes.c_void_p()
+        # upload each distinct operator once
+        self._op_tensors = {}
+        norms_cache = {}
+        ptrs = (ctypes.c_void_p * (self.K * (1 + self.L)))()
+        norms = np.zeros(self.K * (1 + self.L), dtype=np.float64)
+        self.N = None
+        with torch.cuda.device(self.device):
+            for k, row in enumerate(ops):
+                if len(row) != 1 + self.L:
+                    raise ValueError("objective %d has %d operators, expected %d" % (k, len(row), 1 + self.L))
+                for j, op in enumerate(row):
+                    idx = k * (1 + self.L) + j
+                    if op is None:
+                        ptrs[idx] = None
+                        continue
+                    key = id(op)
+                    if key not in self._op_tensors:
+                        if isinstance(op, torch.Tensor):
+                            host = op.detach().cpu().numpy()
+                        else:
+                            host = np.asarray(op)
+                        host = np.ascontiguousarray(host, dtype=np.complex128)
+                        if host.ndim != 2 or host.shape[0] != host.shape[1]:
+                            raise ValueError("operators must be square matrices")
+                        if self.N is None:
+                            self.N = host.shape[0]
+                        elif host.shape[0] != self.N:
+                            raise ValueError("all operators must have the same dimension")
+                        t = torch.from_numpy(host).to(self.device)
+                        self._op_tensors[key] = (t, op)  # keep `op` alive: id() stays unique
+                        norms_cache[key] = float(np.linalg.norm(host, 2)) if host.size else 0.0
+                    ptrs[idx] = self._op_tensors[key][0].data_ptr()
+                    norms[idx] = norms_cache[key]
+            if op_norms is not None:
+                norms = np.ascontiguousarray(np.asarray(op_norms, dtype=np.float64).reshape(-1))
+                if norms.size != self.K * (1 + self.L):
+                    raise ValueError("op_norms must have K*(1+L) entries")
+            pr = _lib.kh_problem()
+            pr.K, pr.N, pr.L, pr.nt = self.K, self.N, self.L, self.nt
+            pr.is_super = 1 if self.is_super else 0
+            pr.dt = dt.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+            pr.ops = ctypes.cast(ptrs, ctypes.POINTER(ctypes.c_void_p))
+            pr.op_norms = norms.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+            pr.tol = float(tol)
+            pr.theta_max = float(theta_max)
+            _lib.check(self._lib.kh_engine_create(ctypes.byref(pr), ctypes.byref(self._handle)))
+        self.op_norms = norms.reshape(self.K, 1 + self.L)
+        self.kernel = self._lib.kh_engine_kernel(self._handle).decode()
+
+    # -- helpers -----------------------------------------------------------
+    def close(self):
+        if getattr(self, '_handle', None) is not None and self._handle.value:
+            self._lib.kh_engine_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def dev(self, x, dtype):
+        """Contiguous tensor of ``dtype`` on the engine's device."""
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(x)), dtype=dtype).to(self.device).contiguous()
+
+    def _c(self, x, shape):
+        t = self.dev(x, torch.complex128)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (shape, tuple(t.shape)))
+        return t
+
+    def _f(self, x, shape):
+        t = self.dev(x, torch.float64)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (shape, tuple(t.shape)))
+        return t
+
+    # -- sweeps ------------------------------------------------------------
+    def forward(self, pulses, init, store=False):
+        """Propagate ``init`` (K, N) over the grid under ``pulses`` (L, nt-1).
+
+        Returns ``psi_T`` or ``(psi_T, states)`` with states (K, nt, N).
+        """
+        pulses = self._f(pulses, (self.L, self.nt - 1))
+        init = self._c(init, (self.K, self.N))
+        psi_T = torch.empty_like(init)
+        states = torch.empty((self.K, self.nt, self.N), dtype=torch.complex128, device=self.device) if store else None
+        _lib.check(self._lib.kh_forward_store(
+            self._handle, pulses.data_ptr(), init.data_ptr(),
+            states.data_ptr() if store else None, psi_T.data_ptr(), self._stream()))
+        return (psi_T, states) if store else psi_T
+
+    def backward(self, chi_T, pulses, out=None):
+        """Backward sweep storing chi(t_n); returns (K, nt, N)."""
+        pulses = self._f(pulses, (self.L, self.nt - 1))
+        chi_T = self._c(chi_T, (self.K, self.N))
+        if out is None:
+            out = torch.empty((self.K, self.nt, self.N), dtype=torch.complex128, device=self.device)
+        _lib.check(self._lib.kh_backward_store(
+            self._handle, chi_T.data_ptr(), pulses.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def forward_update(self, chi_store, chi_norms, init, guess, shape, lambdas):
+        """Forward sweep with sequential update; returns ``(opt, psi_T, g_a)``."""
+        chi_store = self._c(chi_store, (self.K, self.nt, self.N))
+        chi_norms = self._f(chi_norms, (self.K,))
+        init = self._c(init, (self.K, self.N))
+        guess = self._f(guess, (self.L, self.nt - 1))
+        shape = self._f(shape, (self.L, self.nt - 1))
+        lambdas = self._f(lambdas, (self.L,))
+        opt = torch.empty_like(guess)
+        psi_T = torch.empty_like(init)
+        g_a = torch.empty((self.L,), dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.kh_forward_update(
+            self._handle, chi_store.data_ptr(), chi_norms.data_ptr(), init.data_ptr(), guess.data_ptr(),
+            shape.data_ptr(), lambdas.data_ptr(), opt.data_ptr(), psi_T.data_ptr(), g_a.data_ptr(),
+            self._stream()))
+        return opt, psi_T, g_a
+
+    def forward_update_sharded(self, chi_store, chi_norms, init, guess, shape, lambdas, all_reduce):
+        """The same sweep cut at the cross-objective sum: after every interval
+        ``all_reduce(partial)`` (in place, L doubles on the device) must return
+        the sum over all ranks -- ``torch.distributed.all_reduce`` on the
+        ``nccl`` (= RCCL over xGMI) backend."""
+        chi_store = self._c(chi_store, (self.K, self.nt, self.N))
+        chi_norms = self._f(chi_norms, (self.K,))
+        init = self._c(init, (self.K, self.N))
+        guess = self._f(guess, (self.L, self.nt - 1))
+        shape = self._f(shape, (self.L, self.nt - 1))
+        lambdas = self._f(lambdas, (self.L,))
+        opt = torch.empty_like(guess)
+        psi_T = torch.empty_like(init)
+        g_a = torch.empty((self.L,), dtype=torch.float64, device=self.device)
+        partial = torch.zeros((self.L,), dtype=torch.float64, device=self.device)
+        lib, h = self._lib, self._handle
+        _lib.check(lib.kh_update_begin(
+            h, chi_store.data_ptr(), chi_norms.data_ptr(), init.data_ptr(), guess.data_ptr(),
+            opt.data_ptr(), g_a.data_ptr(), partial.data_ptr(), self._stream()))
+        for n in range(self.nt - 1):
+            all_reduce(partial)
+            _lib.check(lib.kh_update_step(
+                h, n, partial.data_ptr(), chi_store.data_ptr(), chi_norms.data_ptr(), shape.data_ptr(),
+                lambdas.data_ptr(), opt.data_ptr(), g_a.data_ptr(), partial.data_ptr(), self._stream()))
+        _lib.check(lib.kh_update_end(h, psi_T.data_ptr(), self._stream()))
+        return opt, psi_T, g_a
+
+    def tau(self, targets, psi_T):
+        targets = self._c(targets, (self.K, self.N))
+        psi_T = self._c(psi_T, (self.K, self.N))
+        out = torch.empty((self.K,), dtype=torch.complex128, device=self.device)
+        _lib.check(self._lib.kh_tau(self._handle, targets.data_ptr(), psi_T.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def check(self):
+        """Synchronise and raise if an in-kernel exchange timed out."""
+        torch.cuda.synchronize(self.device)
+        _lib.check(self._lib.kh_check(self._handle))
+
+    def stats(self):
+        buf = (ctypes.c_double * 4)()
+        torch.cuda.synchronize(self.device)
+        _lib.check(self._lib.kh_last_stats(self._handle, buf))
+        return dict(matvecs=buf[0], intervals=buf[1], workgroups=buf[2])

@@ -1,0 +1,153 @@
+"""Final-time functionals and the chi boundary conditions derived from them.
+
+Same names, signatures and values as ``krotov.functionals`` (reference
+src/krotov/functionals.py:82-437): a ``chi_constructor`` receives
+``fw_states_T``, ``objectives``, ``tau_vals`` and returns one co-state per
+objective.  They run once per iteration on K states (O(K N) work).
+
+When every objective's states are plain vectors the optimiser evaluates the
+four constructors below in stacked (K, N) array form (:func:`chi_stacked`),
+avoiding a K-long Python loop; the list forms are what user code calls.
+"""
+import numpy as np
+
+from .second_order import _overlap
+
+__all__ = [
+    'f_tau',
+    'F_ss',
+    'J_T_ss',
+    'chis_ss',
+    'F_sm',
+    'J_T_sm',
+    'chis_sm',
+    'F_re',
+    'J_T_re',
+    'chis_re',
+    'J_T_hs',
+    'chis_hs',
+]
+
+
+def _weight(obj):
+    return getattr(obj, 'weight', None)
+
+
+def _taus(fw_states_T, objectives, tau_vals):
+    if tau_vals is None:
+        return [_overlap(obj.target, psi) for psi, obj in zip(fw_states_T, objectives)]
+    return tau_vals
+
+
+def f_tau(fw_states_T, objectives, tau_vals=None, **kwargs):
+    """(1/K) sum_k w_k tau_k  (reference functionals.py:82-113)."""
+    total = 0
+    for obj, tau in zip(objectives, _taus(fw_states_T, objectives, tau_vals)):
+        w = _weight(obj)
+        total += tau if w is None else w * tau
+    return total / len(objectives)
+
+
+def F_ss(fw_states_T, objectives, tau_vals=None, **kwargs):
+    """(1/K) sum_k w_k |tau_k|^2  (reference functionals.py:116-162)."""
+    abssq = [abs(t) ** 2 for t in _taus(fw_states_T, objectives, tau_vals)]
+    F = f_tau(fw_states_T, objectives, abssq)
+    assert abs(complex(F).imag) < 1e-10
+    return complex(F).real
+
+
+def J_T_ss(fw_states_T, objectives, tau_vals=None, **kwargs):
+    return 1 - F_ss(fw_states_T, objectives, tau_vals)
+
+
+def F_sm(fw_states_T, objectives, tau_vals=None, **kwargs):
+    return abs(f_tau(fw_states_T, objectives, tau_vals)) ** 2
+
+
+def J_T_sm(fw_states_T, objectives, tau_vals=None, **kwargs):
+    return 1 - F_sm(fw_states_T, objectives, tau_vals)
+
+
+def F_re(fw_states_T, objectives, tau_vals=None, **kwargs):
+    return complex(f_tau(fw_states_T, objectives, tau_vals)).real
+
+
+def J_T_re(fw_states_T, objectives, tau_vals=None, **kwargs):
+    return 1 - F_re(fw_states_T, objectives, tau_vals)
+
+
+def J_T_hs(fw_states_T, objectives, tau_vals=None, **kwargs):
+    """Hilbert-Schmidt distance functional (reference functionals.py:320-386)."""
+    taus = _taus(fw_states_T, objectives, tau_vals)
+    total = 0.0
+    for rho, obj, tau in zip(fw_states_T, objectives, taus):
+        w = _weight(obj)
+        nr = complex(_overlap(rho, rho)).real
+        nt = complex(_overlap(obj.target, obj.target)).real
+        term = nr + nt - 2 * complex(tau).real
+        total += term if w is None else w * term
+    return total / (2 * len(objectives))
+
+
+def chis_ss(fw_states_T, objectives, tau_vals):
+    """chi_k = (tau_k / K) w_k target_k  (reference functionals.py:177-197)."""
+    K = len(objectives)
+    out = []
+    for obj, tau in zip(objectives, tau_vals):
+        w = _weight(obj)
+        out.append((tau / K) * obj.target if w is None else (tau / K) * w * obj.target)
+    return out
+
+
+def chis_sm(fw_states_T, objectives, tau_vals):
+    """chi_k = w_k / K^2 (sum_j w_j tau_j) target_k  (reference functionals.py:225-253)."""
+    s = 0
+    for obj, tau in zip(objectives, tau_vals):
+        w = _weight(obj)
+        s += tau if w is None else w * tau
+    c = 1.0 / len(objectives) ** 2
+    out = []
+    for obj in objectives:
+        w = _weight(obj)
+        out.append(c * obj.target * s if w is None else c * w * obj.target * s)
+    return out
+
+
+def chis_re(fw_states_T, objectives, tau_vals):
+    """chi_k = w_k / (2K) target_k  (reference functionals.py:293-317)."""
+    c = 1.0 / (2 * len(objectives))
+    out = []
+    for obj in objectives:
+        w = _weight(obj)
+        out.append(c * obj.target if w is None else c * w * obj.target)
+    return out
+
+
+def chis_hs(fw_states_T, objectives, tau_vals):
+    """chi_k = w_k / (2K) (rho_target_k - rho_k(T))  (reference functionals.py:389-437)."""
+    c = 1.0 / (2 * len(objectives))
+    out = []
+    for obj, rho in zip(objectives, fw_states_T):
+        w = _weight(obj)
+        out.append(c * (obj.target - rho) if w is None else c * w * (obj.target - rho))
+    return out
+
+
+def chi_stacked(chi_constructor, targets, weights, fw_T, tau):
+    """(K, N) array form of the four constructors above, or None for any other
+    ``chi_constructor``.  ``targets``, ``fw_T``: (K, N); ``weights``: (K,) or
+    None; ``tau``: (K,) complex.  Same operation order as the list forms."""
+    K = targets.shape[0]
+    w = np.ones(K) if weights is None else weights
+    if chi_constructor is chis_re:
+        return ((1.0 / (2 * K)) * w)[:, None] * targets
+    if chi_constructor is chis_ss:
+        return ((np.asarray(tau) / K) * w)[:, None] * targets
+    if chi_constructor is chis_sm:
+        s = 0
+        for wk, t in zip(w, tau):
+            s += wk * t
+        return ((1.0 / K**2) * w)[:, None] * targets * s
+    if chi_constructor is chis_hs:
+        return ((1.0 / (2 * K)) * w)[:, None] * (targets - fw_T)
+    return None

@@ -1,0 +1,299 @@
+"""Control objectives: the problem container the optimiser consumes.
+
+API-compatible with ``krotov.objectives`` (reference src/krotov/objectives.py:
+96-258 ``Objective``, 704-1051 ``gate_objectives``, 1054-1094
+``ensemble_objectives``, 1097-1121 ``liouvillian``) for the parts on or next to
+the hot path.  Operators and states may be QuTiP-like objects (anything with
+``.full()`` / ``.dag()``) or NumPy arrays; QuTiP itself is never imported, so
+there is no type checking, ``mesolve`` delegation or pretty printing here.
+"""
+import copy
+import itertools
+
+import numpy as np
+
+__all__ = ['Objective', 'gate_objectives', 'ensemble_objectives', 'liouvillian']
+
+
+def _shallow_nested(l):
+    if isinstance(l, list):
+        return [list(h) if isinstance(h, list) else h for h in l]
+    return l
+
+
+def _adjoint(op, ignore_errors=False):
+    """Adjoint of an operator/state or of a nested-list operator; controls stay
+    untouched (reference objectives.py:51-93)."""
+    if isinstance(op, list):
+        out = []
+        for item in op:
+            if isinstance(item, list):
+                if len(item) != 2:
+                    if ignore_errors:
+                        return op
+                    raise ValueError(
+                        "%s is not the in the expected format of the "
+                        "two-element list '[operator, control]'" % item
+                    )
+                out.append([_adjoint(item[0]), item[1]])
+            else:
+                out.append(_adjoint(item))
+        return out
+    if op is None or isinstance(op, str):
+        return op
+    if hasattr(op, 'dag'):
+        return op.dag()
+    if hasattr(op, 'conj') and hasattr(op, 'T'):
+        return op.conj().T
+    if hasattr(op, 'conjugate') and hasattr(op, 'transpose'):
+        return op.conjugate().transpose()
+    if ignore_errors:
+        return op
+    raise ValueError("Cannot calculate adjoint of %s" % op)
+
+
+def _same(a, b):
+    """Equality that also works for arrays and nested lists."""
+    if a is b:
+        return True
+    if isinstance(a, list) or isinstance(b, list):
+        if not (isinstance(a, list) and isinstance(b, list)) or len(a) != len(b):
+            return False
+        return all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        try:
+            return np.shape(a) == np.shape(b) and bool(np.all(np.asarray(a) == np.asarray(b)))
+        except Exception:
+            return False
+    try:
+        return bool(a == b)
+    except Exception:
+        return False
+
+
+class Objective:
+    """One control objective: ``initial_state`` evolving under ``H`` (nested
+    list ``[H0, [H1, control], ...]``, or Liouvillian in the same format)
+    should reach ``target``; ``c_ops`` are Lindblad operators.
+
+    Custom attributes (e.g. ``weight``) survive copies and ``adjoint()``.
+    ``type_checking`` exists for source compatibility with scripts that set it
+    (reference objectives.py:154-158); no type checks are ever performed here.
+    """
+
+    type_checking = False
+    _default_attribs = ['initial_state', 'H', 'target', 'c_ops']
+
+    def __init__(self, *, initial_state, H, target, c_ops=None):
+        self.H = H
+        self.initial_state = initial_state
+        self.target = target
+        self.c_ops = [] if c_ops is None else c_ops
+
+    def _extras(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._default_attribs}
+
+    def __copy__(self):
+        new = Objective(
+            H=_shallow_nested(self.H),
+            initial_state=self.initial_state,
+            target=self.target,
+            c_ops=[_shallow_nested(c) for c in self.c_ops],
+        )
+        new.__dict__.update(self._extras())
+        return new
+
+    def __deepcopy__(self, memo):
+        new = Objective(
+            H=copy.deepcopy(self.H, memo),
+            initial_state=copy.deepcopy(self.initial_state, memo),
+            target=copy.deepcopy(self.target, memo),
+            c_ops=[copy.deepcopy(c, memo) for c in self.c_ops],
+        )
+        for k, v in self._extras().items():
+            setattr(new, k, copy.deepcopy(v, memo))
+        return new
+
+    def __eq__(self, other):
+        if other.__class__ is not self.__class__:
+            return NotImplemented
+        if self.__dict__.keys() != other.__dict__.keys():
+            return False
+        return all(_same(getattr(self, k), getattr(other, k)) for k in self.__dict__)
+
+    def __ne__(self, other):
+        res = self.__eq__(other)
+        return res if res is NotImplemented else not res
+
+    __hash__ = None
+
+    def adjoint(self):
+        """Objective with the adjoint of every component; controls are assumed
+        real and are kept; a non-state ``target`` is kept as is (reference
+        objectives.py:240-258)."""
+        adj = Objective(
+            H=_adjoint(self.H),
+            initial_state=_adjoint(self.initial_state),
+            target=_adjoint(self.target, ignore_errors=True),
+            c_ops=[_adjoint(op) for op in self.c_ops],
+        )
+        adj.__dict__.update(self._extras())
+        return adj
+
+    def __repr__(self):
+        return "Objective(initial_state=%r, target=%r, H=<%d terms>, c_ops=<%d>)" % (
+            type(self.initial_state).__name__,
+            type(self.target).__name__,
+            len(self.H) if isinstance(self.H, list) else 1,
+            len(self.c_ops),
+        )
+
+
+# ---------------------------------------------------------------------------
+# constructors
+# ---------------------------------------------------------------------------
+
+
+def _ketbra(a, b):
+    """|a><b| for Qobj-like or array kets."""
+    if hasattr(a, 'dag') and hasattr(b, 'dag'):
+        return a * b.dag()
+    return np.outer(np.asarray(a).reshape(-1), np.conj(np.asarray(b).reshape(-1)))
+
+
+def _rho1(basis):
+    d = len(basis)
+    return sum((2 * (d - i) / (d * (d + 1))) * _ketbra(p, p) for i, p in enumerate(basis))
+
+
+def _rho2(basis):
+    d = len(basis)
+    return (1.0 / d) * sum(_ketbra(pi, pj) for pi, pj in itertools.product(basis, repeat=2))
+
+
+def _rho3(basis):
+    d = len(basis)
+    return (1.0 / d) * sum(_ketbra(p, p) for p in basis)
+
+
+def _li_pe_objectives(basis_states, gate, H, c_ops):
+    """Bell-basis objectives for local-invariants / perfect-entangler
+    optimisation (reference objectives.py:1035-1051)."""
+    if len(basis_states) != 4:
+        raise ValueError("Optimization towards a two-qubit gate requires 4 basis_states")
+    b = basis_states
+    psis = [
+        (b[0] + b[3]) / np.sqrt(2),
+        (1j * b[1] + 1j * b[2]) / np.sqrt(2),
+        (b[1] - b[2]) / np.sqrt(2),
+        (1j * b[0] - 1j * b[3]) / np.sqrt(2),
+    ]
+    return [Objective(initial_state=psi, target=gate, H=H, c_ops=c_ops) for psi in psis]
+
+
+def gate_objectives(
+    basis_states,
+    gate,
+    H,
+    *,
+    c_ops=None,
+    local_invariants=False,
+    liouville_states_set=None,
+    weights=None,
+    normalize_weights=True,
+):
+    """Objectives for optimising towards a quantum gate (reference
+    objectives.py:704-1032).
+
+    ``gate`` is an ``n x n`` matrix-like (``gate[i, j]``, ``.shape``), or the
+    string ``'PE'`` / ``'perfect_entangler'``.  ``liouville_states_set`` in
+    {None, 'full', '3states', 'd+1'} selects density-matrix objectives.
+    """
+    if isinstance(gate, str):
+        if gate.lower().replace(' ', '_') in ('pe', 'perfect_entangler'):
+            return _li_pe_objectives(basis_states, 'PE', H, c_ops)
+        raise ValueError(
+            "gate must be either a square matrix, or one of the strings "
+            "'PE' or 'perfect_entangler', not '" + gate + "'"
+        )
+    if local_invariants:
+        if tuple(gate.shape) != (4, 4):
+            raise ValueError(
+                "If local_invariants is True, gate must be a 4 × 4 matrix, not " + str(gate.shape)
+            )
+        return _li_pe_objectives(basis_states, gate, H, c_ops)
+    n = len(basis_states)
+    if not (gate.shape[0] == gate.shape[1] == n):
+        raise ValueError("gate must be a matrix of the same dimension as the number of basis states")
+    mapped = [sum(complex(gate[i, j]) * basis_states[i] for i in range(n)) for j in range(n)]
+    for i, state in enumerate(mapped):  # reuse identical basis objects (permutation gates)
+        for basis_state in basis_states:
+            if _same(state, basis_state):
+                mapped[i] = basis_state
+    if liouville_states_set is None:
+        initial, target = list(basis_states), mapped
+    else:
+        key = liouville_states_set.replace(' ', '').lower()
+        if key == 'full':
+            initial = [_ketbra(a, b) for a, b in itertools.product(basis_states, repeat=2)]
+            target = [_ketbra(a, b) for a, b in itertools.product(mapped, repeat=2)]
+        elif key == '3states':
+            initial = [_rho1(basis_states), _rho2(basis_states), _rho3(basis_states)]
+            target = [_rho1(mapped), _rho2(mapped), _rho3(mapped)]
+        elif key == 'd+1':
+            initial = [_ketbra(p, p) for p in basis_states] + [_rho2(basis_states)]
+            target = [_ketbra(p, p) for p in mapped] + [_rho2(mapped)]
+        else:
+            raise ValueError("Invalid `liouville_states_set`: %s" % liouville_states_set)
+    objectives = [
+        Objective(initial_state=psi, target=tgt, H=H, c_ops=c_ops) for psi, tgt in zip(initial, target)
+    ]
+    if weights is not None:
+        if len(weights) != len(objectives):
+            raise ValueError("If weight are given, there must be a weight for each objective")
+        if normalize_weights:
+            weights = len(objectives) * np.array(weights) / np.sum(weights)
+        for i in reversed(range(len(objectives))):
+            w = float(weights[i])
+            if w < 0:
+                raise ValueError("weights must be greater than zero")
+            objectives[i].weight = w
+            if w == 0:
+                del objectives[i]
+    return objectives
+
+
+def ensemble_objectives(objectives, Hs, *, keep_original_objectives=True):
+    """One copy of every objective per Hamiltonian in ``Hs`` (robustness
+    ensemble; reference objectives.py:1054-1094)."""
+    out = list(objectives) if keep_original_objectives else []
+    for H in Hs:
+        for obj in objectives:
+            out.append(Objective(H=H, initial_state=obj.initial_state, target=obj.target, c_ops=obj.c_ops))
+    return out
+
+
+def _dense_liouvillian(H, c_ops):
+    """Column-stacking Liouvillian of dense arrays (cf. configs.liouvillian_dense)."""
+    from .configs import liouvillian_dense
+    from ._ingest import to_dense
+
+    return liouvillian_dense(to_dense(H), [to_dense(c) for c in c_ops])
+
+
+def liouvillian(H, c_ops):
+    """Liouvillian of a (possibly nested-list) Hamiltonian and constant
+    Lindblad operators, as dense arrays for column-stacked vec(rho)
+    (reference objectives.py:1097-1121 delegates to qutip.liouvillian)."""
+    c_ops = list(c_ops or [])
+    if not isinstance(H, list):
+        return _dense_liouvillian(H, c_ops)
+    out = []
+    for spec in H:
+        if isinstance(spec, list):
+            out.append([_dense_liouvillian(spec[0], []), spec[1]])
+        else:
+            out.append(_dense_liouvillian(spec, c_ops))
+            c_ops = []
+    assert len(c_ops) == 0, "No drift Hamiltonian"
+    return out

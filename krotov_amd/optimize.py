@@ -1,0 +1,727 @@
+"""``optimize_pulses``: Krotov's method behind the reference's plugin surface.
+
+Same signature, keyword semantics, error behaviour and ``Result`` as
+``krotov.optimize_pulses`` (reference src/krotov/optimize.py:33-590).  Two
+execution paths share all bookkeeping:
+
+* **device path** -- taken when ``propagator`` is this package's
+  :func:`krotov_amd.propagators.expm` / :class:`~krotov_amd.propagators.HipExpm`
+  and ``mu``, ``overlap``, ``sigma``, ``storage`` are the defaults.  Per
+  iteration the three objective-parallel dispatches of the reference
+  (optimize.py:302-313, 413-425, 449-501) become three calls into
+  ``libkrotov_hip.so``: all objectives are batched in one launch per sweep,
+  the co-states never leave HBM, and the K*L*(nt-1) Python ``mu``/``overlap``
+  calls of optimize.py:454-470 disappear into the kernel.  Objectives can be
+  sharded over the GPUs of a node with ``process_group=`` (one rank per GPU,
+  one all-reduce of the L update sums per interval).
+
+* **plugin path** -- any other ``propagator`` (a user's own callable, in
+  whatever arithmetic it implements) runs through a host loop with the
+  reference's call structure, so custom ``propagator`` / ``mu`` / ``overlap`` /
+  ``norm`` / ``parallel_map`` / ``storage`` plugins keep working.  This path
+  does no arithmetic of its own.
+
+There is no CPU fallback for the device path: without a GPU or without the
+built library, requesting it raises.
+"""
+import copy
+import inspect
+import logging
+import time
+from functools import partial
+
+import numpy as np
+
+from . import functionals as _functionals
+from ._ingest import obj_type, state_to_vector, to_dense, vector_to_state
+from .conversions import (
+    control_onto_interval,
+    discretize,
+    extract_controls,
+    extract_controls_mapping,
+    plug_in_pulse_values,
+    pulse_onto_tlist,
+    pulse_options_dict_to_list,
+)
+from .info_hooks import chain
+from .mu import derivative_wrt_pulse
+from .parallelization import serial_map
+from .propagators import HipExpm, Propagator, expm
+from .result import Result
+from .second_order import _overlap
+from .shapes import one_shape, zero_shape
+
+__all__ = ['optimize_pulses']
+
+
+# ---------------------------------------------------------------------------
+# control initialisation (reference optimize.py:593-704)
+# ---------------------------------------------------------------------------
+
+
+def _shape_callable(val):
+    if callable(val):
+        return val
+    if val == 1:
+        return one_shape
+    if val == 0:
+        return zero_shape
+    raise ValueError("update_shape must be a callable")
+
+
+def _checked_shape(arr):
+    """Shapes must lie in [0, 1] up to the rounding of the un-averaging; then
+    clip (reference optimize.py:605-620)."""
+    lo, hi = np.min(arr), np.max(arr)
+    if lo < -0.01 or hi > 1.01:
+        raise ValueError(
+            "Update shapes ('update_shape' in pulse options-dict) must have "
+            "values in the range [0, 1], not [%s, %s]" % (lo, hi)
+        )
+    return np.clip(arr, a_min=0.0, a_max=1.0)
+
+
+def _initialize_krotov_controls(objectives, pulse_options, tlist):
+    guess_controls = extract_controls(objectives)
+    pulses_mapping = extract_controls_mapping(objectives, guess_controls)
+    options_list = pulse_options_dict_to_list(pulse_options, guess_controls)
+    try:
+        guess_controls = [
+            discretize(c, tlist, args=(options_list[i].get('args', None),), via_midpoints=True)
+            for i, c in enumerate(guess_controls)
+        ]
+    except TypeError as exc:
+        raise ValueError(
+            "Cannot discretize controls: %s. Note that "
+            "all controls must be real-valued. Complex controls must be "
+            "split into an independent real and imaginary part in the "
+            "objectives before passing them to the optimization" % exc
+        )
+    guess_pulses = [control_onto_interval(c) for c in guess_controls]
+    try:
+        lambda_vals = np.array([float(o['lambda_a']) for o in options_list])
+    except KeyError:
+        raise ValueError("Each value in pulse_options must be a dict that contains the key 'lambda_a'.")
+    shape_arrays = []
+    for o in options_list:
+        try:
+            S = discretize(_shape_callable(o['update_shape']), tlist, args=(), via_midpoints=True)
+        except KeyError:
+            raise ValueError("Each value in pulse_options must be a dict that contains the key 'update_shape'.")
+        except TypeError as exc:
+            raise ValueError(
+                "Update shapes ('update_shape' in pulse options-dict) must be real-valued: %s" % exc
+            )
+        shape_arrays.append(_checked_shape(control_onto_interval(S)))
+    return guess_controls, guess_pulses, pulses_mapping, lambda_vals, shape_arrays
+
+
+def _restore_from_previous_result(result, objectives, tlist, store_all_pulses):
+    """Guess controls/pulses of a continued optimisation (reference
+    optimize.py:707-774), with the same compatibility checks."""
+    if not isinstance(result, Result):
+        raise ValueError("Continuation is only possible from a Result object")
+    if len(objectives) != len(result.objectives):
+        raise ValueError("When continuing from a previous Result, the number of objectives must be the same")
+    for a, b in zip(objectives, result.objectives):
+        if a != b:
+            raise ValueError("When continuing from a previous Result, the objectives must remain unchanged")
+    if store_all_pulses and len(result.all_pulses) == 0:
+        raise ValueError(
+            "The store_all_pulses parameter cannot be changed when continuing from a previous Result. "
+            "Pass it as False."
+        )
+    if not store_all_pulses and len(result.all_pulses) > 0:
+        raise ValueError(
+            "The store_all_pulses parameter cannot be changed when continuing from a previous Result. "
+            "Pass it as True."
+        )
+    same_grid = len(tlist) == len(result.tlist) and np.max(np.abs(np.array(tlist) - np.array(result.tlist))) <= 1e-5
+    if not same_grid:
+        raise ValueError("When continuing from a previous Result, the controls must be defined on the same time grid")
+    nt = len(tlist)
+    guess_controls = []
+    for control in result.optimized_controls:
+        if len(control) == nt - 1:  # dumped mid-optimisation: these are pulses
+            guess_controls.append(pulse_onto_tlist(control))
+        elif len(control) == nt:
+            guess_controls.append(control)
+        else:
+            raise ValueError("Invalid Result: optimized_controls and tlist are incongruent")
+    return guess_controls, [control_onto_interval(c) for c in guess_controls]
+
+
+def _check_propagators_interface(propagators, logger):
+    """Warn about propagators whose signature is neither ``expm``'s nor
+    ``Propagator.__call__``'s (reference optimize.py:623-638)."""
+    ok = (inspect.getfullargspec(expm), inspect.getfullargspec(Propagator.__call__))
+    for p in propagators:
+        try:
+            spec = inspect.getfullargspec(p)
+        except TypeError:
+            spec = None
+        if spec not in ok:
+            logger.warning("The propagator %s does not have the expected interface.", p)
+
+
+# ---------------------------------------------------------------------------
+# plugin path: the reference's call structure around user callables
+# ---------------------------------------------------------------------------
+
+
+def _forward_propagation(i_objective, objectives, pulses, pulses_mapping, tlist, propagators, storage,
+                         store_all=True):
+    """Task for ``parallel_map[0]`` (reference optimize.py:806-846)."""
+    obj = objectives[i_objective]
+    state = obj.initial_state
+    mapping = pulses_mapping[i_objective]
+    out = None
+    if store_all:
+        out = storage(len(tlist))
+        out[0] = state
+    for n in range(len(tlist) - 1):
+        H = plug_in_pulse_values(obj.H, pulses, mapping[0], n)
+        c_ops = [plug_in_pulse_values(c, pulses, mapping[ic + 1], n) for ic, c in enumerate(obj.c_ops)]
+        state = propagators[i_objective](H, state, tlist[n + 1] - tlist[n], c_ops, initialize=(n == 0))
+        if store_all:
+            out[n + 1] = state
+    return out if store_all else state
+
+
+def _backward_propagation(i_state, chi_states, adjoint_objectives, pulses, pulses_mapping, tlist, propagators,
+                          storage):
+    """Task for ``parallel_map[1]`` (reference optimize.py:849-886)."""
+    state = chi_states[i_state]
+    obj = adjoint_objectives[i_state]
+    mapping = pulses_mapping[i_state]
+    nt = len(tlist)
+    out = storage(nt)
+    out[-1] = state
+    for n in range(nt - 2, -1, -1):
+        H = plug_in_pulse_values(obj.H, pulses, mapping[0], n, conjugate=True)
+        c_ops = [plug_in_pulse_values(c, pulses, mapping[ic + 1], n) for ic, c in enumerate(obj.c_ops)]
+        state = propagators[i_state](
+            H, state, tlist[n + 1] - tlist[n], c_ops, backwards=True, initialize=(n == nt - 2)
+        )
+        out[n] = state
+    return out
+
+
+def _forward_propagation_step(i_state, states, objectives, pulses, pulses_mapping, tlist, time_index, propagators):
+    """Task for ``parallel_map[2]`` (reference optimize.py:889-911)."""
+    obj = objectives[i_state]
+    mapping = pulses_mapping[i_state]
+    H = plug_in_pulse_values(obj.H, pulses, mapping[0], time_index)
+    c_ops = [plug_in_pulse_values(c, pulses, mapping[ic + 1], time_index) for ic, c in enumerate(obj.c_ops)]
+    dt = tlist[time_index + 1] - tlist[time_index]
+    return propagators[i_state](H, states[i_state], dt, c_ops, initialize=(time_index == 0))
+
+
+class _PluginBackend:
+    """Host loop over user callables, call-for-call like the reference."""
+
+    device = False
+
+    def __init__(self, objectives, adjoint_objectives, pulses_mapping, tlist, propagators, storage, parallel_map,
+                 mu, overlap):
+        self.objectives = objectives
+        self.adjoint_objectives = adjoint_objectives
+        self.mapping = pulses_mapping
+        self.tlist = tlist
+        self.propagators = propagators
+        self.storage = storage
+        self.pmap = parallel_map
+        self.mu = mu
+        self.overlap = overlap
+
+    def initial_forward(self, pulses):
+        K = len(self.objectives)
+        forward_states = self.pmap[0](
+            _forward_propagation, list(range(K)),
+            (self.objectives, pulses, self.mapping, self.tlist, self.propagators, self.storage),
+        )
+        return [s[-1] for s in forward_states], forward_states
+
+    def tau_vals(self, fw_states_T):
+        return np.array([self.overlap(obj.target, s) for s, obj in zip(fw_states_T, self.objectives)])
+
+    def iterate(self, chi_states, chi_norms, guess_pulses, lambda_vals, shape_arrays):
+        objectives, tlist = self.objectives, self.tlist
+        K, nt = len(objectives), len(tlist)
+        backward_states = self.pmap[1](
+            _backward_propagation, list(range(K)),
+            (chi_states, self.adjoint_objectives, guess_pulses, self.mapping, tlist, self.propagators, self.storage),
+        )
+        g_a = np.zeros(len(guess_pulses))
+        optimized = copy.deepcopy(guess_pulses)
+        fw_states = [obj.initial_state for obj in objectives]
+        for n in range(nt - 1):
+            dt = tlist[n + 1] - tlist[n]
+            for l in range(len(guess_pulses)):
+                total = 0j
+                for k in range(K):  # optimize.py:455-470
+                    mu_op = self.mu(objectives, k, guess_pulses, self.mapping, l, n)
+                    update = self.overlap(backward_states[k][n], mu_op(fw_states[k]))
+                    update *= chi_norms[k]
+                    total += update
+                step = shape_arrays[l][n] / lambda_vals[l]
+                d1 = total.imag
+                g_a[l] += step * abs(d1) ** 2 * dt
+                optimized[l][n] += step * d1
+            fw_states = self.pmap[2](
+                _forward_propagation_step, list(range(K)),
+                (fw_states, objectives, optimized, self.mapping, tlist, n, self.propagators),
+            )
+        return backward_states, optimized, fw_states, g_a
+
+
+# ---------------------------------------------------------------------------
+# device path
+# ---------------------------------------------------------------------------
+
+
+class _LazyStates:
+    """List-like view of per-objective states held as one (K, N) host array;
+    elements are converted to the caller's state type on access."""
+
+    def __init__(self, array, likes):
+        self._array = array
+        self._likes = likes
+
+    def __len__(self):
+        return len(self._likes)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        return vector_to_state(self._array[k], self._likes[k])
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
+class _DeviceTrajectories:
+    """``backward_states[k][n]`` for ``info_hook``: fetched from HBM on access."""
+
+    def __init__(self, tensor, likes, k0=0):
+        self._t, self._likes, self._k0 = tensor, likes, k0
+
+    def __len__(self):
+        return self._t.shape[0]
+
+    def __getitem__(self, k):
+        traj = self._t[k].cpu().numpy()
+        like = self._likes[self._k0 + k]
+        return [vector_to_state(traj[n], like) for n in range(traj.shape[0])]
+
+
+def _use_device_path(propagator, mu, overlap, sigma, storage, objectives):
+    if isinstance(propagator, list):
+        if not propagator or any(not (p is expm or isinstance(p, HipExpm)) for p in propagator):
+            return False
+    elif not (propagator is expm or isinstance(propagator, HipExpm)):
+        return False
+    if mu is not None and mu is not derivative_wrt_pulse:
+        return False
+    if overlap is not None and overlap is not _overlap:
+        return False
+    if sigma is not None or storage != 'array':
+        return False
+    return all(len(obj.c_ops) == 0 for obj in objectives)
+
+
+class _HipBackend:
+    """All objectives of this rank resident on one GPU."""
+
+    device = True
+
+    def __init__(self, objectives, pulses_mapping, tlist, n_controls, propagator, process_group=None):
+        import torch
+
+        from .engine import HipKrotovEngine
+
+        self.torch = torch
+        self.group = process_group
+        self.objectives = objectives
+        K_total = len(objectives)
+        self.rank, self.world = 0, 1
+        if process_group is not None:
+            import torch.distributed as dist
+
+            self.dist = dist
+            self.rank = dist.get_rank(process_group)
+            self.world = dist.get_world_size(process_group)
+        # contiguous shard of objectives for this rank
+        per = (K_total + self.world - 1) // self.world
+        self.k0 = min(self.rank * per, K_total)
+        self.k1 = min(self.k0 + per, K_total)
+        if self.k1 <= self.k0:
+            raise ValueError("rank %d has no objectives (K=%d, world=%d)" % (self.rank, K_total, self.world))
+        self.K_total = K_total
+        L = n_controls
+        dense = {}
+
+        def dense_of(op):
+            key = id(op)
+            if key not in dense:
+                dense[key] = (to_dense(op), op)
+            return dense[key][0]
+
+        sums = {}
+
+        def summed(terms):
+            """Dense sum of several operators, cached on their identities so
+            objectives sharing the same nested list share one device copy."""
+            if len(terms) == 1:
+                return dense_of(terms[0])
+            key = tuple(id(t) for t in terms)
+            if key not in sums:
+                total = dense_of(terms[0]).copy()
+                for t in terms[1:]:
+                    total = total + dense_of(t)
+                sums[key] = (total, terms)
+            return sums[key][0]
+
+        liouville = None
+        props = propagator if isinstance(propagator, list) else [propagator]
+        for p in props:
+            if isinstance(p, HipExpm) and p.liouville is not None:
+                liouville = bool(p.liouville)
+        ops, first_op = [], None
+        for k in range(self.k0, self.k1):
+            obj = objectives[k]
+            H = obj.H if isinstance(obj.H, list) else [obj.H]
+            drift = [t for t in H if not isinstance(t, list)]
+            if len(drift) == 0:
+                raise ValueError("objective %d has no drift term in H" % k)
+            if first_op is None:
+                first_op = drift[0]
+            row = [summed(drift)]
+            for l in range(L):
+                where = pulses_mapping[k][0][l]
+                row.append(summed([H[i][0] for i in where]) if len(where) else None)
+            ops.append(row)
+        N = ops[0][0].shape[0]
+        if liouville is None:
+            if obj_type(first_op) is not None:
+                liouville = obj_type(first_op) == 'super'
+            else:
+                s0 = np.asarray(objectives[self.k0].initial_state)
+                liouville = bool(s0.ndim == 2 and s0.shape[0] == s0.shape[1] and s0.shape[0] > 1 and s0.size == N)
+        self.is_super = liouville
+        self.N, self.L = N, L
+        tlist = np.asarray(tlist, dtype=np.float64)
+        self.engine = HipKrotovEngine(ops, np.diff(tlist), is_super=self.is_super)
+        self.nt = len(tlist)
+        self.likes = [obj.initial_state for obj in objectives]
+        init = [state_to_vector(obj.initial_state, N, self.is_super) for obj in objectives[self.k0:self.k1]]
+        if any(v is None for v in init):
+            raise ValueError("initial states do not match the operator dimension %d" % N)
+        self.init_host = np.array(init)
+        self.init = self.engine.dev(self.init_host, torch.complex128)
+        tg = [state_to_vector(obj.target, N, self.is_super) for obj in objectives]
+        self.targets_host = None if any(v is None for v in tg) else np.array(tg)
+        self.targets = (
+            None if self.targets_host is None
+            else self.engine.dev(self.targets_host[self.k0:self.k1], torch.complex128)
+        )
+        w = [getattr(obj, 'weight', None) for obj in objectives]
+        self.weights = None if all(x is None for x in w) else np.array([1.0 if x is None else x for x in w])
+        self.chi_store = None
+        self.fw_T_dev = None
+
+    # -- helpers -----------------------------------------------------------
+    def _pulses(self, pulses):
+        return self.engine.dev(np.array(pulses, dtype=np.float64).reshape(self.L, self.nt - 1), self.torch.float64)
+
+    def _gather_rows(self, local):
+        """(K_loc, ...) host array on every rank -> (K_total, ...) on every rank."""
+        if self.world == 1:
+            return local
+        per = (self.K_total + self.world - 1) // self.world
+        t = self.torch
+        pad = np.zeros((per,) + local.shape[1:], dtype=local.dtype)
+        pad[: local.shape[0]] = local
+        send = t.from_numpy(np.ascontiguousarray(pad)).to(self.engine.device)
+        recv = [t.empty_like(send) for _ in range(self.world)]
+        self.dist.all_gather(recv, send, group=self.group)
+        full = np.concatenate([r.cpu().numpy() for r in recv], axis=0)
+        return full[: self.K_total]
+
+    def initial_forward(self, pulses):
+        self.fw_T_dev = self.engine.forward(self._pulses(pulses), self.init)
+        fw_T = self._gather_rows(self.fw_T_dev.cpu().numpy())
+        return _LazyStates(fw_T, self.likes), None
+
+    def fw_T_host(self, fw_states_T):
+        return fw_states_T._array if isinstance(fw_states_T, _LazyStates) else None
+
+    def tau_vals(self, fw_states_T):
+        if self.targets is None:
+            return np.array([None] * self.K_total)
+        tau = self.engine.tau(self.targets, self.fw_T_dev).cpu().numpy()
+        return self._gather_rows(tau)
+
+    def iterate(self, chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays):
+        """chi_T: (K_total, N) normalised co-states (host); chi_norms (K_total,)."""
+        t = self.torch
+        eng = self.engine
+        guess = self._pulses(guess_pulses)
+        chi_loc = eng.dev(chi_T[self.k0:self.k1], t.complex128)
+        norms_loc = eng.dev(np.asarray(chi_norms, dtype=np.float64)[self.k0:self.k1], t.float64)
+        self.chi_store = eng.backward(chi_loc, guess, out=self.chi_store)
+        shapes = eng.dev(np.array(shape_arrays, dtype=np.float64).reshape(self.L, self.nt - 1), t.float64)
+        lambdas = eng.dev(np.asarray(lambda_vals, dtype=np.float64), t.float64)
+        if self.world == 1:
+            opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
+        else:
+            def all_reduce(x):
+                self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM, group=self.group)
+
+            opt, psi_T, g_a = eng.forward_update_sharded(
+                self.chi_store, norms_loc, self.init, guess, shapes, lambdas, all_reduce)
+        self.fw_T_dev = psi_T
+        eng.check()
+        fw_T = self._gather_rows(psi_T.cpu().numpy())
+        opt_host = opt.cpu().numpy()
+        optimized = [opt_host[l].copy() for l in range(self.L)]
+        backward_states = _DeviceTrajectories(self.chi_store, self.likes, self.k0)
+        return backward_states, optimized, _LazyStates(fw_T, self.likes), g_a.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------
+# the driver
+# ---------------------------------------------------------------------------
+
+
+def optimize_pulses(
+    objectives,
+    pulse_options,
+    tlist,
+    *,
+    propagator,
+    chi_constructor,
+    mu=None,
+    sigma=None,
+    iter_start=0,
+    iter_stop=5000,
+    check_convergence=None,
+    info_hook=None,
+    modify_params_after_iter=None,
+    storage='array',
+    parallel_map=None,
+    store_all_pulses=False,
+    continue_from=None,
+    skip_initial_forward_propagation=False,
+    norm=None,
+    overlap=None,
+    limit_thread_pool=None,
+    process_group=None,
+):
+    """Optimise all controls in ``objectives`` with Krotov's method.
+
+    Arguments, callbacks, returned :class:`~krotov_amd.result.Result` and raised
+    ``ValueError`` s are those of ``krotov.optimize_pulses`` (reference
+    optimize.py:33-228).  Differences:
+
+    * ``propagator=krotov_amd.propagators.expm`` runs on the GPU (see module
+      docstring); ``parallel_map`` is then unused -- objectives are batched in
+      the kernels.
+    * ``process_group`` (extension): a ``torch.distributed`` group with one
+      rank per GPU; every rank passes the full objective list and gets the
+      full result, objectives are sharded contiguously over the ranks.
+    * ``sigma`` (second order) is not supported (NotImplementedError).
+    * ``limit_thread_pool`` is accepted and ignored (no BLAS on the hot path).
+    """
+    logger = logging.getLogger('krotov')
+    logger.info("Initializing optimization with Krotov's method")
+    if sigma is not None:
+        raise NotImplementedError("second-order Krotov (sigma) is outside the accelerated path")
+    device_path = _use_device_path(propagator, mu, overlap, sigma, storage, objectives)
+    if process_group is not None and not device_path:
+        raise ValueError("process_group requires the device path (propagator=krotov_amd.propagators.expm)")
+    if mu is None:
+        mu = derivative_wrt_pulse
+    default_norm = norm is None
+    if norm is None:
+        def norm(state):
+            return state.norm() if hasattr(state, 'norm') else float(np.linalg.norm(np.asarray(state)))
+    if overlap is None:
+        overlap = _overlap
+    if modify_params_after_iter is not None:
+        info_hook = modify_params_after_iter if info_hook is None else chain(modify_params_after_iter, info_hook)
+    if isinstance(propagator, list):
+        propagators = propagator
+        assert len(propagators) == len(objectives)
+    else:
+        propagators = [copy.deepcopy(propagator) for _ in objectives]
+    _check_propagators_interface(propagators, logger)
+
+    adjoint_objectives = [obj.adjoint() for obj in objectives]
+    if storage == 'array':
+        storage = partial(np.empty, dtype=object)
+    if parallel_map is None:
+        parallel_map = serial_map
+    if not isinstance(parallel_map, (tuple, list)):
+        parallel_map = (parallel_map, parallel_map, parallel_map)
+
+    (guess_controls, guess_pulses, pulses_mapping, lambda_vals, shape_arrays) = _initialize_krotov_controls(
+        objectives, pulse_options, tlist
+    )
+    if continue_from is not None:
+        guess_controls, guess_pulses = _restore_from_previous_result(
+            continue_from, objectives, tlist, store_all_pulses
+        )
+    g_a_integrals = np.zeros(len(guess_pulses))
+
+    if continue_from is None:
+        result = Result()
+        result.start_local_time = time.localtime()
+    else:
+        result = copy.deepcopy(continue_from)
+
+    if device_path:
+        backend = _HipBackend(objectives, pulses_mapping, tlist, len(guess_pulses), propagator, process_group)
+    else:
+        backend = _PluginBackend(
+            objectives, adjoint_objectives, pulses_mapping, tlist, propagators, storage, parallel_map, mu, overlap
+        )
+
+    # ---- iteration 0: forward propagation under the guess (optimize.py:295-322)
+    tic = time.time()
+    if skip_initial_forward_propagation:
+        if continue_from is not None:
+            fw_states_T = list(continue_from.states)
+        else:
+            logger.warning(
+                "You should not use `skip_initial_forward_propagation` unless you are also passing `continue_from`"
+            )
+            fw_states_T = [None for _ in objectives]
+        if device_path:
+            backend.fw_T_dev = None
+        tau_vals = np.array([overlap(obj.target, s) for s, obj in zip(fw_states_T, objectives)])
+    else:
+        fw_states_T, _ = backend.initial_forward(guess_pulses)
+        tau_vals = backend.tau_vals(fw_states_T)
+    toc = time.time()
+
+    info = None
+    optimized_pulses = copy.deepcopy(guess_pulses)
+    static_args = dict(
+        objectives=objectives, adjoint_objectives=adjoint_objectives, lambda_vals=lambda_vals,
+        shape_arrays=shape_arrays, tlist=tlist, propagator=propagator, chi_constructor=chi_constructor,
+        mu=mu, sigma=sigma, iter_start=iter_start, iter_stop=iter_stop,
+    )
+    if info_hook is not None:
+        info = info_hook(
+            backward_states=None, forward_states=None, forward_states0=None, guess_pulses=guess_pulses,
+            optimized_pulses=optimized_pulses, g_a_integrals=g_a_integrals, fw_states_T=fw_states_T,
+            tau_vals=tau_vals, start_time=tic, stop_time=toc, iteration=0, info_vals=[], shared_data={},
+            **static_args,
+        )
+
+    result.tlist = tlist
+    result.objectives = objectives
+    result.guess_controls = guess_controls
+    result.optimized_controls = optimized_pulses
+    result.controls_mapping = pulses_mapping
+    if continue_from is None:
+        if info is not None:
+            result.info_vals.append(info)
+        result.iters.append(0)
+        result.iter_seconds.append(int(toc - tic))
+        if not np.all(tau_vals == None):  # noqa: E711
+            result.tau_vals.append(tau_vals)
+        if store_all_pulses:
+            result.all_pulses.append(guess_pulses)
+    else:
+        iter_start = continue_from.iters[-1]
+        logger.info("Continuing from previous result, with iteration %d", iter_start + 1)
+    result.states = fw_states_T
+
+    # ---- main loop (optimize.py:392-581)
+    for krotov_iteration in range(iter_start + 1, iter_stop + 1):
+        logger.info("Started Krotov iteration %d", krotov_iteration)
+        tic = time.time()
+
+        chi_T = None
+        if device_path:
+            # stacked form of the built-in functionals: no K-long Python loop
+            fw_host = backend.fw_T_host(fw_states_T)
+            if (
+                default_norm
+                and backend.targets_host is not None
+                and (fw_host is not None or chi_constructor is _functionals.chis_re)
+            ):
+                chi_T = _functionals.chi_stacked(
+                    chi_constructor, backend.targets_host, backend.weights, fw_host, tau_vals
+                )
+        if chi_T is None:
+            chi_states = chi_constructor(fw_states_T=fw_states_T, objectives=objectives, tau_vals=tau_vals)
+            chi_norms = [norm(chi) for chi in chi_states]
+            chi_states = [chi / nrm for chi, nrm in zip(chi_states, chi_norms)]
+            if device_path:
+                vecs = [state_to_vector(c, backend.N, backend.is_super) for c in chi_states]
+                if any(v is None for v in vecs):
+                    raise ValueError("chi_constructor returned states that do not match the state dimension")
+                chi_T = np.array(vecs)
+        else:
+            # default norm on vectors: L2 (any norm gives the same update; optimize.py:407-410, 467)
+            chi_norms = np.linalg.norm(chi_T, axis=1)
+            chi_T = chi_T / chi_norms[:, None]
+            chi_states = None
+
+        g_a_integrals[:] = 0.0
+        if device_path:
+            backward_states, optimized_pulses, fw_states_T, g_a = backend.iterate(
+                chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays
+            )
+        else:
+            backward_states, optimized_pulses, fw_states_T, g_a = backend.iterate(
+                chi_states, chi_norms, guess_pulses, lambda_vals, shape_arrays
+            )
+        g_a_integrals[:] = g_a
+        tau_vals = backend.tau_vals(fw_states_T)
+        toc = time.time()
+
+        if info_hook is not None:
+            info = info_hook(
+                backward_states=backward_states, forward_states=None, forward_states0=None,
+                fw_states_T=fw_states_T, guess_pulses=guess_pulses, optimized_pulses=optimized_pulses,
+                g_a_integrals=g_a_integrals, tau_vals=tau_vals, start_time=tic, stop_time=toc,
+                info_vals=result.info_vals, shared_data={}, iteration=krotov_iteration, **static_args,
+            )
+        result.iters.append(krotov_iteration)
+        result.iter_seconds.append(int(toc - tic))
+        if info is not None:
+            result.info_vals.append(info)
+        if not np.all(tau_vals == None):  # noqa: E711
+            result.tau_vals.append(tau_vals)
+        result.optimized_controls = optimized_pulses
+        if store_all_pulses:
+            result.all_pulses.append(copy.deepcopy(optimized_pulses))
+        result.states = fw_states_T
+        logger.info("Finished Krotov iteration %d", krotov_iteration)
+
+        msg = None
+        if check_convergence is not None:
+            msg = check_convergence(result)
+        if krotov_iteration >= static_args['iter_stop']:  # a hook may have changed it
+            iter_stop = static_args['iter_stop']
+            result.message = "Reached %d iterations" % iter_stop
+            break
+        if bool(msg) is True:
+            result.message = "Reached convergence"
+            if isinstance(msg, str):
+                result.message += ": " + msg
+            break
+        guess_pulses = optimized_pulses
+    else:
+        result.message = "Reached %d iterations" % max(iter_start, iter_stop)
+
+    # ---- finalize (optimize.py:583-590)
+    result.end_local_time = time.localtime()
+    result.optimized_controls = [pulse_onto_tlist(np.asarray(p)) for p in optimized_pulses]
+    if isinstance(result.states, _LazyStates):
+        result.states = list(result.states)
+    return result

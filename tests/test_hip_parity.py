@@ -1,0 +1,310 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle,
+the committed reference goldens, and size-independent properties at the full
+BASELINE sizes.  fp64 tolerances: 1e-12 relative on pulses / 1e-12
+on tau vs the oracle after 1-2 iterations of the small cases, 1e-9 vs dump goldens.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import krotov_amd
+from krotov_amd import configs
+from oracle import krotov_oracle as ko
+
+from helpers import CHI, golden, oracle_controls, oracle_optimize, spec_to_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(spec, **kw):
+    from krotov_amd.engine import HipKrotovEngine
+
+    ops = [[spec.H0[k]] + [spec.Hc[k][l] for l in range(spec.L)] for k in range(spec.K)]
+    return HipKrotovEngine(ops, np.diff(spec.tlist), is_super=spec.is_super, **kw)
+
+
+SMALL = {
+    'c1': lambda: configs.config_c1(nt=200),
+    'c2h': lambda: configs.config_c2_hilbert(nt=150),
+    'c2l': lambda: configs.config_c2_liouville(nt=150),
+    'c3': lambda: configs.config_c3(nt=301),
+    'c4_d5': lambda: configs.config_c4(d=5, nt=101, n_logical=2),
+    'c5_n16': lambda: configs.config_c5(K=6, N=16, nt=101),
+    'c5_n12_L3': lambda: configs.config_c5(K=5, N=12, nt=81, L=3, distinct=True),
+    'c5_n64': lambda: configs.config_c5(K=8, N=64, nt=61),
+    'c5_n64_L2': lambda: configs.config_c5(K=4, N=64, nt=41, L=2, distinct=True),
+    'c5_n80': lambda: configs.config_c5(K=3, N=80, nt=31, L=2),
+    'c5_n33': lambda: configs.config_c5(K=5, N=33, nt=41),
+}
+
+
+@pytest.mark.parametrize('name', sorted(SMALL))
+def test_sweeps_match_oracle(name):
+    """Each of the three sweeps, called through the C ABI, vs the oracle's."""
+    spec = SMALL[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    eng = _engine(spec)
+    pulses = np.array(gp)
+    # forward sweep with storage (optimize.py:302-313)
+    fw_T, states = eng.forward(pulses, spec.init, store=True)
+    ref_T, ref_states = ko.forward_propagation(prob, gp, store=True)
+    assert np.abs(states.cpu().numpy() - ref_states).max() < 1e-12
+    assert np.abs(fw_T.cpu().numpy() - ref_T).max() < 1e-12
+    tau = eng.tau(spec.target, fw_T).cpu().numpy()
+    assert np.abs(tau - ko.tau_vals(prob, ref_T)).max() < 1e-12
+    # backward sweep (optimize.py:413-425)
+    chi_T = CHI[spec.chi](prob, ref_T, ko.tau_vals(prob, ref_T))
+    norms = np.linalg.norm(chi_T, axis=1)
+    chi_T = chi_T / norms[:, None]
+    chi = eng.backward(chi_T, pulses)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-12
+    # forward sweep with sequential update (optimize.py:444-508)
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * scale
+    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+    assert np.abs(g_a.cpu().numpy() - ref_ga).max() < 1e-12 * max(1.0, np.abs(ref_ga).max())
+    # the sweep cut at the cross-objective sum (multi-GPU form) with a 1-rank "all-reduce"
+    opt2, psi2, ga2 = eng.forward_update_sharded(chi, norms, spec.init, pulses, np.array(S), np.array(lam),
+                                                 lambda x: x)
+    assert np.abs((opt2 - opt).cpu().numpy()).max() < 1e-13 * scale
+    assert np.abs((psi2 - psi_T).cpu().numpy()).max() < 1e-13
+    assert np.abs((ga2 - g_a).cpu().numpy()).max() < 1e-13 * max(1.0, np.abs(ref_ga).max())
+    assert eng.kernel.startswith('tile64') == (spec.N <= 64)
+    eng.close()
+
+
+@pytest.mark.parametrize('name', ['c5_n16', 'c5_n64', 'c5_n64_L2', 'c5_n33'])
+@pytest.mark.parametrize('kernel', ['generic', 'tile512', 'tile256'])
+def test_kernel_families_agree(name, kernel, monkeypatch):
+    """generic and both register-tile variants give the same sweeps (<= 1e-13)."""
+    spec = SMALL[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    monkeypatch.setenv('KH_KERNEL', kernel)
+    eng = _engine(spec)
+    if kernel == 'generic':
+        assert eng.kernel == 'generic'
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.37)
+    chi = eng.backward(chi_T, pulses)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-12
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * max(1.0, np.abs(np.array(ref_opt)).max())
+    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+    eng.close()
+
+
+GOLDEN_CASES = {
+    'ref_c1_tls': lambda: configs.config_c1(),
+    'ref_c2_hilbert': lambda: configs.config_c2_hilbert(),
+    'ref_c2_liouville': lambda: configs.config_c2_liouville(),
+    'ref_c3_iswap': lambda: configs.config_c3(),
+    'ref_c4_small': lambda: configs.config_c4(d=5, nt=201, n_logical=2),
+    'ref_c5_small': lambda: configs.config_c5(K=6, N=16, nt=201, L=1),
+    'ref_c5_small_L3': lambda: configs.config_c5(K=5, N=12, nt=151, L=3, distinct=True),
+    'ref_c5_n64': lambda: configs.config_c5(K=8, N=64, nt=401, L=1),
+}
+
+
+def _optimize_on_device(spec, iters, **kw):
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    prop = krotov_amd.propagators.HipExpm(liouville=True) if spec.is_super else krotov_amd.propagators.expm
+    return krotov_amd.optimize_pulses(
+        objectives, pulse_options, spec.tlist, propagator=prop,
+        chi_constructor=getattr(krotov_amd.functionals, 'chis_' + spec.chi),
+        iter_stop=iters, store_all_pulses=True, **kw)
+
+
+@pytest.mark.parametrize('name', sorted(GOLDEN_CASES))
+def test_optimize_pulses_vs_reference_loop_goldens(name):
+    """optimize_pulses(propagator=expm) on the GPU vs the outputs of the
+    reference's own optimize_pulses on the same inputs (committed fixtures)."""
+    g = golden(name)
+    spec = GOLDEN_CASES[name]()
+    res = _optimize_on_device(spec, int(g['iter_stop']))
+    got = np.array([np.array(p) for p in res.all_pulses])
+    tol = 2e-11 if name == 'ref_c4_small' else 2e-12
+    scale = max(1.0, np.abs(g['all_pulses']).max())
+    assert np.abs(got - g['all_pulses']).max() < tol * scale
+    assert np.abs(np.array(res.tau_vals) - g['tau_vals']).max() < tol
+    fw_T = np.array([np.asarray(s).ravel(order='F') for s in res.states])
+    assert np.abs(fw_T - g['fw_T']).max() < tol
+    assert np.abs(np.array(res.optimized_controls) - g['optimized_controls']).max() < tol * scale
+
+
+def test_tls_dump_18_iterations_on_device():
+    """reference tests/test_result_serialization/oct_result.dump: every pulse of
+    all 18 iterations (4.5k sequential steps each way per iteration) to 1e-9."""
+    g = golden('dump_tls_ss')
+    res = _optimize_on_device(configs.config_c1(), len(g['iters']) - 1)
+    got = np.array([np.array(p) for p in res.all_pulses])
+    assert np.abs(got[0] - g['all_pulses'][0]).max() == 0.0
+    assert np.abs(got - g['all_pulses']).max() < 1e-9
+    assert np.abs(np.array(res.tau_vals)[:, 0] - g['tau_vals'][:, 0]).max() < 1e-9
+    assert np.abs(got - g['all_pulses']).max() < 1e-11  # measured ~1e-13
+
+
+def test_transmon17_dump_on_device():
+    """reference docs/notebooks/transmonxgate_opt_result.dump, iterations 5 -> 8."""
+    g = golden('dump_transmon17')
+    H0, H1, psi0, psi1 = g['H0'], g['H1'], g['psi0'], g['psi1']
+    ctrl = g['controls_it5'][0].copy()
+    H = [H0, [H1, ctrl]]
+    objs = [krotov_amd.Objective(initial_state=psi0, target=psi1, H=H),
+            krotov_amd.Objective(initial_state=psi1, target=psi0, H=H)]
+    S = lambda t: krotov_amd.shapes.flattop(t, 0.0, 10.0, 0.5, func='sinsq')  # noqa: E731
+    res = krotov_amd.optimize_pulses(
+        objs, {id(ctrl): dict(lambda_a=1.0, update_shape=S)}, g['tlist'],
+        propagator=krotov_amd.propagators.expm, chi_constructor=krotov_amd.functionals.chis_re, iter_stop=3)
+    tau = np.array(res.tau_vals)
+    sgn = np.sign((tau[0] * np.conj(g['tau_vals'][5])).real)
+    assert np.abs(sgn * tau[0] - g['tau_vals'][5]).max() < 1e-8
+    if np.all(sgn > 0):
+        assert np.abs(tau - g['tau_vals'][5:9]).max() < 1e-8
+
+
+def test_ensemble_dump_on_device():
+    """reference docs/notebooks/ensemble_opt_result.dump: K=5, N=3, L=4, it. 12 -> 16."""
+    g = golden('dump_ensemble')
+    ctrls = [c.copy() for c in g['controls_it12']]
+    T = g['tlist'][-1]
+    S = lambda t: krotov_amd.shapes.flattop(t, 0.0, T, 0.3, func='sinsq')  # noqa: E731
+    objs = []
+    psi0 = np.array([1, 0, 0], dtype=complex)
+    for mu in g['mu']:
+        H = [g['H0']] + [[mu * g['Hc'][l], ctrls[l]] for l in range(4)]
+        objs.append(krotov_amd.Objective(initial_state=psi0, target=g['target'], H=H))
+    opts = {id(c): dict(lambda_a=float(g['lambda_a']), update_shape=S) for c in ctrls}
+    res = krotov_amd.optimize_pulses(objs, opts, g['tlist'], propagator=krotov_amd.propagators.expm,
+                                     chi_constructor=krotov_amd.functionals.chis_re, iter_stop=4)
+    assert np.abs(np.array(res.tau_vals) - g['tau_vals'][12:17]).max() < 1e-9
+
+
+def test_runs_are_bitwise_repeatable():
+    spec = configs.config_c5(K=24, N=64, nt=101)
+    a = _optimize_on_device(spec, 2)
+    b = _optimize_on_device(spec, 2)
+    assert np.array_equal(np.array(a.all_pulses), np.array(b.all_pulses))
+    assert np.array_equal(np.array(a.tau_vals), np.array(b.tau_vals))
+
+
+def test_edge_cases():
+    from krotov_amd.engine import HipKrotovEngine
+
+    rng = np.random.default_rng(5)
+    # non-uniform dt, control absent from one objective, K > number of CUs (generic persistent loop)
+    K, N, nt = 300, 6, 21
+    tl = np.cumsum(np.concatenate([[0.0], rng.uniform(0.01, 0.05, nt - 1)]))
+    H0 = [configs.herm(rng, N, 3.0) for _ in range(K)]
+    H1 = configs.herm(rng, N, 1.0)
+    ops = [[H0[k], (None if k == 7 else H1)] for k in range(K)]
+    init = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
+    init /= np.linalg.norm(init, axis=1)[:, None]
+    target = np.roll(init, 1, axis=0)
+    prob = ko.OracleProblem(ops, init, target, tl)
+    gp = [0.3 * np.sin(np.arange(nt - 1))]
+    S = [np.ones(nt - 1)]
+    eng = HipKrotovEngine(ops, np.diff(tl))
+    assert eng.kernel == 'generic'
+    chi_T = target / np.linalg.norm(target, axis=1)[:, None]
+    norms = np.full(K, 1.0 / (2 * K))
+    chi = eng.backward(chi_T, np.array(gp))
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-12
+    opt, psi_T, g_a = eng.forward_update(chi, norms, init, np.array(gp), np.array(S), np.array([2.0]))
+    eng.check()
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, [2.0])
+    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12
+    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+    eng.close()
+    # N = 1 and a large step norm (several Taylor sub-steps)
+    ops1 = [[np.array([[2.5 + 0j]]), np.array([[40.0 + 0j]])]]
+    eng = HipKrotovEngine(ops1, [0.5, 0.25])
+    out = eng.forward(np.array([[0.3, -0.2]]), np.array([[1.0 + 0j]])).cpu().numpy()
+    want = np.exp(-1j * (2.5 + 40 * 0.3) * 0.5) * np.exp(-1j * (2.5 - 40 * 0.2) * 0.25)
+    assert abs(out[0, 0] - want) < 1e-13
+    eng.close()
+    # the single-step drop-in of krotov.propagators.expm, forwards / backwards / Liouville
+    H = [H0[0], [H1, 0.7]]
+    v = init[0]
+    got = krotov_amd.propagators.expm(H, v.reshape(-1, 1), 0.03)
+    assert got.shape == (N, 1)
+    assert np.abs(got.ravel() - ko.step([H0[0], H1], [0.7], 0.03, v)).max() < 1e-13
+    got = krotov_amd.propagators.expm(H, v, 0.03, backwards=True)
+    assert np.abs(got - ko.step([H0[0], H1], [0.7], 0.03, v, backwards=True)).max() < 1e-13
+    rho = np.outer(v, v.conj())
+    Ls = [configs.liouvillian_dense(H0[0]), [configs.liouvillian_dense(H1), 0.7]]
+    got = krotov_amd.propagators.expm(Ls, rho, 0.03)
+    U = ko.expm_pade13(-1j * (H0[0] + 0.7 * H1) * 0.03)
+    assert got.shape == (N, N) and np.abs(got - U @ rho @ U.conj().T).max() < 1e-13
+    with pytest.raises(NotImplementedError):
+        krotov_amd.propagators.expm(H, v, 0.03, c_ops=[H1])
+
+
+def test_unitary_liouville_cross_check():
+    """Liouville-space expm has no reference golden: propagating
+    rho = |psi><psi| with L = -i[H, .] must equal the Hilbert-space result."""
+    spec_h = configs.config_c3(nt=201)
+    eng_h = _engine(spec_h)
+    gp, _, _ = oracle_controls(spec_h)
+    psi_T = eng_h.forward(np.array(gp), spec_h.init).cpu().numpy()
+    L0 = configs.liouvillian_dense(spec_h.H0[0])
+    L1 = configs.liouvillian_dense(spec_h.Hc[0][0])
+    from krotov_amd.engine import HipKrotovEngine
+
+    eng_l = HipKrotovEngine([[L0, L1]] * 4, np.diff(spec_h.tlist), is_super=True)
+    rho0 = np.array([np.outer(p, p.conj()).ravel(order='F') for p in spec_h.init])
+    rho_T = eng_l.forward(np.array(gp), rho0).cpu().numpy()
+    want = np.array([np.outer(p, p.conj()).ravel(order='F') for p in psi_T])
+    assert np.abs(rho_T - want).max() < 1e-12
+
+
+def test_full_size_c5_properties():
+    """BASELINE config 5 at full size (K=256, N=64, 4000 intervals): properties
+    that need no oracle run -- norm conservation, and <chi(t_n)|phi(t_n)> constant
+    in n when both sweeps use the same pulses (U^dagger U = 1 step by step)."""
+    import torch
+
+    spec = configs.config_c5()
+    eng = _engine(spec)
+    assert eng.kernel.startswith('tile64')
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    fw_T, states = eng.forward(pulses, spec.init, store=True)
+    nrm = torch.linalg.vector_norm(states, dim=2)
+    assert float((nrm - 1).abs().max()) < 1e-11
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    chi = eng.backward(chi_T, pulses)
+    ov = (chi.conj() * states).sum(dim=2)  # (K, nt)
+    assert float((ov - ov[:, -1:]).abs().max()) < 1e-10
+    # tau from the kernel equals the stored overlap at t = T
+    tau = eng.tau(spec.target, fw_T)
+    assert float((tau - ov[:, -1]).abs().max()) < 1e-13
+    del states, ov
+    # one update sweep: finite, shape-limited, and exactly reproducible
+    norms = np.full(spec.K, 1.0 / (2 * spec.K))
+    a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    b = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    opt = a[0].cpu().numpy()
+    assert np.all(np.isfinite(opt)) and opt[0, 0] == pulses[0, 0] and opt[0, -1] == pulses[0, -1]
+    assert float((torch.linalg.vector_norm(a[1], dim=1) - 1).abs().max()) < 1e-11
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'ref_c5_full.npz')
+    if os.path.exists(path):
+        g = np.load(path)
+        assert np.abs(opt - g['all_pulses'][1]).max() < 1e-10
+        tau1 = eng.tau(spec.target, a[1]).cpu().numpy()
+        assert np.abs(tau1 - g['tau_vals'][1]).max() < 1e-10
+    eng.close()

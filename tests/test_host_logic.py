@@ -1,0 +1,295 @@
+"""Host-side logic on CPU: conversions, shapes, functionals, objectives and the
+plugin path of optimize_pulses (driven by user callables -- here NumPy closures
+built on the oracle's single-step function, the reference's "numpy mode").
+
+KAT sources: reference tests/test_structural_conversions.py, test_shapes.py,
+test_functionals.py, test_mu.py, test_overlap.py, test_krotov.py, and the TLS
+dump of tests/test_result_serialization.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+import krotov_amd
+from krotov_amd import configs, conversions, functionals, shapes
+from oracle import krotov_oracle as ko
+
+from helpers import golden
+
+
+def numpy_plugins(is_super=False):
+    """propagator / mu / overlap callables as in reference notebook 09."""
+
+    def propagator(H, state, dt, c_ops=None, backwards=False, initialize=False):
+        f = (1.0 + 0j) if is_super else -1j
+        if backwards:
+            f = f.conjugate()
+        A = f * H[0]
+        for part in H[1:]:
+            A = A + (f * part[1]) * part[0]
+        return ko.expm_dense(A * dt, use_scipy=False) @ state
+
+    def mu(objs, i_obj, pulses, mapping, i_pulse, n):
+        op = objs[i_obj].H[1 + i_pulse][0]
+        return (lambda s: 1j * (op @ s)) if is_super else (lambda s: op @ s)
+
+    def overlap(a, b):
+        return complex(np.vdot(a, b))
+
+    return propagator, mu, overlap
+
+
+def test_controls_roundtrip_and_boundaries():
+    rng = np.random.default_rng(0)
+    c = rng.standard_normal(50)
+    p = conversions.control_onto_interval(c)
+    assert len(p) == 49 and p[0] == c[0] and p[-1] == c[-1]
+    back = conversions.pulse_onto_tlist(p)
+    assert np.abs(back[:-2] - c[:-2]).max() < 1e-12  # the recurrence inverts the averaging
+    assert np.abs(conversions.control_onto_interval(back) - p).max() < 1e-12  # pulse -> control -> pulse = id
+    assert back[0] == c[0] and back[-1] == p[-1]
+    # matches the oracle's restatement bit for bit
+    assert np.array_equal(p, ko.control_onto_interval(c))
+    assert np.array_equal(back, ko.pulse_onto_tlist(p))
+
+
+def test_discretize_rejects_complex_and_wrong_length():
+    tl = np.linspace(0, 1, 11)
+    with pytest.raises(TypeError):
+        conversions.discretize(lambda t, a: 1j * t, tl)
+    with pytest.raises(ValueError):
+        conversions.discretize(np.zeros(5), tl)
+    with pytest.raises(TypeError):
+        conversions.discretize("nope", tl)
+    vals = conversions.discretize(lambda t, a: t**2, tl, via_midpoints=True)
+    assert len(vals) == 11 and vals[0] == 0.0
+
+
+def test_shapes_match_oracle_bitwise():
+    for t in np.linspace(-0.5, 5.5, 241):
+        for func in ('blackman', 'sinsq'):
+            assert shapes.flattop(t, 0, 5, 0.3, func=func) == ko.flattop(t, 0, 5, 0.3, func=func)
+        assert shapes.blackman(t, 1.0, 4.0) == ko.blackman(t, 1.0, 4.0)
+    assert abs(shapes.flattop(0.0, 0, 5, 0.3)) < 1e-16 and shapes.flattop(2.5, 0, 5, 0.3) == 1.0
+    with pytest.raises(ValueError):
+        shapes.flattop(1.0, 0, 5, 0.3, func='nope')
+    cb = shapes.qutip_callback(shapes.flattop, t_start=0, t_stop=5, t_rise=0.3)
+    assert cb(2.5, None) == 1.0 and cb(2.5, {'func': 'sinsq'}) == 1.0
+
+
+def test_mapping_and_plug_in():
+    X, Y, Z = np.eye(2), 2 * np.eye(2), 3 * np.eye(2)
+    u1, u2 = np.zeros(3), np.ones(3)
+    o1 = krotov_amd.Objective(initial_state=None, target=None, H=[X, [Y, u1], [Z, u1]])
+    o2 = krotov_amd.Objective(initial_state=None, target=None, H=[X, [Y, u2]])
+    controls = conversions.extract_controls([o1, o2])
+    assert len(controls) == 2 and controls[0] is u1 and controls[1] is u2
+    mapping = conversions.extract_controls_mapping([o1, o2], controls)
+    assert mapping == [[[[1, 2], []]], [[[], [1]]]]
+    H = conversions.plug_in_pulse_values(['X', ['X', None], ['Y', None], ['Z', None]],
+                                         [np.array([0, 10, 0]), np.array([0, 20, 0])], [[1, 2], [3]], 1)
+    assert H == ['X', ['X', 10], ['Y', 10], ['Z', 20]]
+    with pytest.raises(ValueError):
+        conversions.pulse_options_dict_to_list({}, controls)
+
+
+def test_functionals_known_answers():
+    """reference tests/test_functionals.py: J_T_ss=0.25? -> values on fixed taus."""
+    class O:
+        def __init__(self, target):
+            self.target = target
+    objs = [O(np.array([1, 0], dtype=complex)), O(np.array([0, 1], dtype=complex))]
+    taus = np.array([0.5, 1.0], dtype=complex)
+    assert abs(functionals.F_ss(None, objs, taus) - (0.25 + 1.0) / 2) < 1e-14
+    assert abs(functionals.F_sm(None, objs, taus) - 0.75**2) < 1e-14
+    assert abs(functionals.F_re(None, objs, taus) - 0.75) < 1e-14
+    assert abs(functionals.J_T_re(None, objs, taus) - 0.25) < 1e-14
+    for name in ('re', 'ss', 'sm', 'hs'):
+        fn = getattr(functionals, 'chis_' + name)
+        fw = [np.array([0.6, 0.8j]), np.array([0.1, 0.9])]
+        listed = np.array(fn(fw, objs, taus))
+        stacked = functionals.chi_stacked(fn, np.array([o.target for o in objs]), None, np.array(fw), taus)
+        assert np.abs(listed - stacked).max() < 1e-15, name
+    objs[0].weight, objs[1].weight = 0.5, 1.5
+    listed = np.array(functionals.chis_sm(None, objs, taus))
+    stacked = functionals.chi_stacked(functionals.chis_sm, np.array([o.target for o in objs]),
+                                      np.array([0.5, 1.5]), None, taus)
+    assert np.abs(listed - stacked).max() < 1e-15
+
+
+def test_overlap_and_mu():
+    from krotov_amd.mu import derivative_wrt_pulse
+    from krotov_amd.second_order import _overlap
+
+    a = np.array([[1, 2j], [0, 1]], dtype=complex)  # non-Hermitian: must use a^dagger
+    b = np.array([[0.5, 1], [1j, 2]], dtype=complex)
+    assert abs(_overlap(a, b) - np.trace(a.conj().T @ b)) < 1e-14
+    assert _overlap('PE', b) is None
+    sp = np.array([[0, 1], [0, 0]], dtype=complex)
+    sm = sp.T.copy()
+    u = np.zeros(3)
+    obj = krotov_amd.Objective(initial_state=None, target=None, H=[np.eye(2), [sp, u], [sm, u]])
+    mapping = conversions.extract_controls_mapping([obj], [u])
+    mu = derivative_wrt_pulse([obj], 0, [u], mapping, 0, 0)
+    v = np.array([0.3, 0.7j])
+    assert np.abs(mu(v) - (sp + sm) @ v).max() < 1e-15  # repeated control: sum of terms
+    other = np.ones(3)
+    mapping2 = conversions.extract_controls_mapping([obj], [u, other])
+    zero = derivative_wrt_pulse([obj], 0, [u, other], mapping2, 1, 0)
+    assert np.all(zero(v) == 0)
+
+
+def test_objective_copy_eq_adjoint_and_constructors():
+    H0 = np.diag([1.0, -1.0]).astype(complex)
+    H1 = np.array([[0, 1j], [-1j, 0]])
+    u = lambda t, args: 1.0  # noqa: E731
+    psi = np.array([1, 0], dtype=complex)
+    obj = krotov_amd.Objective(initial_state=psi, target=psi[::-1].copy(), H=[H0, [H1 * 1j, u]])
+    obj.weight = 0.7
+    c = copy.copy(obj)
+    assert c == obj and c.H is not obj.H and c.H[1] is not obj.H[1] and c.H[1][0] is obj.H[1][0]
+    assert c.weight == 0.7
+    adj = obj.adjoint()
+    assert np.array_equal(adj.H[1][0], (H1 * 1j).conj().T) and adj.H[1][1] is u and adj.weight == 0.7
+    d = copy.deepcopy(obj)
+    assert d == obj
+    d.weight = 0.1
+    assert d != obj
+    # gate objectives: X gate on a qubit reuses the basis objects
+    basis = [np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)]
+    X = np.array([[0, 1], [1, 0]])
+    objs = krotov_amd.gate_objectives(basis, X, [H0, [H1, u]])
+    assert len(objs) == 2 and objs[0].target is basis[1] and objs[1].target is basis[0]
+    o3 = krotov_amd.gate_objectives(basis, X, [H0, [H1, u]], liouville_states_set='3states', weights=[20, 1, 1])
+    assert len(o3) == 3 and abs(sum(o.weight for o in o3) - 3) < 1e-12
+    assert abs(np.trace(o3[0].initial_state) - 1) < 1e-14
+    full = krotov_amd.gate_objectives(basis, X, [H0, [H1, u]], liouville_states_set='full')
+    assert len(full) == 4
+    with pytest.raises(ValueError):
+        krotov_amd.gate_objectives(basis, 'nope', [H0])
+    ens = krotov_amd.ensemble_objectives(objs, [[H0, [0.9 * H1, u]], [H0, [1.1 * H1, u]]])
+    assert len(ens) == 6 and ens[2].initial_state is basis[0]
+    L = krotov_amd.objectives.liouvillian([H0, [H1, u]], c_ops=[np.array([[0, 1], [0, 0]])])
+    assert L[0].shape == (4, 4) and L[1][1] is u
+    assert np.abs(L[1][0] - configs.liouvillian_dense(H1)).max() == 0
+
+
+def _run_plugin(spec, iters, **kw):
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    prop, mu, overlap = numpy_plugins(spec.is_super)
+    return krotov_amd.optimize_pulses(
+        objectives, pulse_options, spec.tlist, propagator=prop,
+        chi_constructor=getattr(krotov_amd.functionals, 'chis_' + spec.chi),
+        mu=mu, overlap=overlap, norm=np.linalg.norm, iter_stop=iters, store_all_pulses=True, **kw)
+
+
+def test_plugin_path_reproduces_tls_dump():
+    """Config 1 (plumbing, no GPU): the host loop with NumPy plugins vs the
+    reference's shipped TLS result, all pulses of the first 6 iterations."""
+    g = golden('dump_tls_ss')
+    res = _run_plugin(configs.config_c1(), 6)
+    got = np.array([np.array(p) for p in res.all_pulses])
+    assert np.abs(got[0] - g['all_pulses'][0]).max() == 0.0
+    assert np.abs(got - g['all_pulses'][:7]).max() < 1e-9
+    assert np.abs(np.array(res.tau_vals)[:, 0] - g['tau_vals'][:7, 0]).max() < 1e-9
+    assert res.iters == list(range(7)) and res.message == "Reached 6 iterations"
+    assert len(res.optimized_controls[0]) == len(g['tlist'])
+    assert np.abs(res.optimized_controls[0] - conversions.pulse_onto_tlist(got[-1][0])).max() == 0
+
+
+@pytest.mark.parametrize('name,builder', [
+    ('ref_c2_liouville', lambda: configs.config_c2_liouville()),
+    ('ref_c5_small_L3', lambda: configs.config_c5(K=5, N=12, nt=151, L=3, distinct=True)),
+])
+def test_plugin_path_matches_reference_loop(name, builder):
+    g = golden(name)
+    res = _run_plugin(builder(), int(g['iter_stop']))
+    got = np.array([np.array(p) for p in res.all_pulses])
+    assert np.abs(got - g['all_pulses']).max() < 1e-11
+    assert np.abs(np.array(res.tau_vals) - g['tau_vals']).max() < 1e-11
+
+
+def test_continue_from_equals_uninterrupted():
+    """reference tests/test_krotov.py:426-432: continuation == one long run (1e-10)."""
+    spec = configs.config_c1(nt=120)
+    full = _run_plugin(spec, 4)
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    prop, mu, overlap = numpy_plugins()
+    kw = dict(propagator=prop, chi_constructor=krotov_amd.functionals.chis_ss, mu=mu, overlap=overlap,
+              norm=np.linalg.norm, store_all_pulses=True)
+    first = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=2, **kw)
+    cont = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=4, continue_from=first, **kw)
+    assert cont.iters == [0, 1, 2, 3, 4]
+    assert np.abs(cont.optimized_controls[0] - full.optimized_controls[0]).max() < 1e-10
+    with pytest.raises(ValueError):
+        krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist[:-1], iter_stop=3, continue_from=first, **kw)
+    with pytest.raises(ValueError):
+        krotov_amd.optimize_pulses(objectives[:0] + objectives + objectives, pulse_options, spec.tlist,
+                                   iter_stop=3, continue_from=first, **kw)
+
+
+def test_validation_errors():
+    """reference tests/test_krotov.py:22-134, test_pulse_options.py."""
+    spec = configs.config_c1(nt=30)
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    prop, mu, overlap = numpy_plugins()
+    kw = dict(propagator=prop, chi_constructor=krotov_amd.functionals.chis_re, mu=mu, overlap=overlap,
+              norm=np.linalg.norm, iter_stop=1)
+    ctrl = spec.controls[0]
+    with pytest.raises(ValueError, match='lambda_a'):
+        krotov_amd.optimize_pulses(objectives, {ctrl: dict(update_shape=1)}, spec.tlist, **kw)
+    with pytest.raises(ValueError, match='update_shape'):
+        krotov_amd.optimize_pulses(objectives, {ctrl: dict(lambda_a=1.0)}, spec.tlist, **kw)
+    with pytest.raises(ValueError, match=r'range \[0, 1\]'):
+        krotov_amd.optimize_pulses(objectives, {ctrl: dict(lambda_a=1.0, update_shape=lambda t: 2.0)}, spec.tlist, **kw)
+    with pytest.raises(ValueError, match='real-valued'):
+        krotov_amd.optimize_pulses(objectives, {ctrl: dict(lambda_a=1.0, update_shape=lambda t: 1j)}, spec.tlist, **kw)
+    with pytest.raises(ValueError, match='pulse options'):
+        krotov_amd.optimize_pulses(objectives, {}, spec.tlist, **kw)
+    # complex control
+    H = [spec.H0[0], [spec.Hc[0][0], lambda t, args: 1j]]
+    objs = [krotov_amd.Objective(initial_state=spec.init[0], target=spec.target[0], H=H)]
+    with pytest.raises(ValueError, match='real-valued'):
+        krotov_amd.optimize_pulses(objs, {H[1][1]: dict(lambda_a=1.0, update_shape=1)}, spec.tlist, **kw)
+    with pytest.raises(NotImplementedError):
+        krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, sigma=object(), **kw)
+
+
+def test_info_hook_and_convergence_contract():
+    spec = configs.config_c1(nt=60)
+    seen = []
+
+    def hook(**kwargs):
+        needed = {'objectives', 'adjoint_objectives', 'backward_states', 'forward_states', 'forward_states0',
+                  'guess_pulses', 'optimized_pulses', 'g_a_integrals', 'lambda_vals', 'shape_arrays',
+                  'fw_states_T', 'tlist', 'tau_vals', 'start_time', 'stop_time', 'iteration', 'info_vals',
+                  'shared_data', 'propagator', 'chi_constructor', 'mu', 'sigma', 'iter_start', 'iter_stop'}
+        assert needed <= set(kwargs)
+        seen.append(kwargs['iteration'])
+        return 1 - abs(kwargs['tau_vals'][0]) ** 2
+
+    def halve(**kwargs):
+        kwargs['lambda_vals'][:] *= 0.5
+
+    def converged(result):
+        return "done" if len(result.iters) > 2 else None
+
+    res = _run_plugin(spec, 10, info_hook=hook, modify_params_after_iter=halve, check_convergence=converged)
+    assert seen == [0, 1, 2] and res.message == "Reached convergence: done"
+    assert len(res.info_vals) == 3 and res.info_vals[2] < res.info_vals[0]
+
+
+def test_device_path_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    spec = configs.config_c1(nt=20)
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist,
+                                   propagator=krotov_amd.propagators.expm,
+                                   chi_constructor=krotov_amd.functionals.chis_ss, iter_stop=1)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        krotov_amd.propagators.expm([spec.H0[0], [spec.Hc[0][0], 0.1]], spec.init[0], 0.01)
