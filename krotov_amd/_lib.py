@@ -63,6 +63,11 @@ def load():
             "krotov_amd: %s is missing. Build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
         )
+    # PyTorch-ROCm owns the device memory the engine works on: import it first so
+    # that the library binds to the HIP runtime torch has loaded (two copies of
+    # libamdhip64 in one process do not see each other's device context).
+    import torch  # noqa: F401
+
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:

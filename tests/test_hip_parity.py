@@ -66,9 +66,12 @@ def test_sweeps_match_oracle(name):
     eng.check()
     ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
     scale = max(1.0, np.abs(np.array(ref_opt)).max())
-    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * scale
-    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
-    assert np.abs(g_a.cpu().numpy() - ref_ga).max() < 1e-12 * max(1.0, np.abs(ref_ga).max())
+    # the stiff N=25 Liouvillian amplifies round-off ~10x (the oracle's own Pade vs
+    # SciPy's differ by 1.2e-12 there, tests/test_oracle_golden.py)
+    tol = 1e-11 if name == 'c4_d5' else 1e-12
+    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < tol * scale
+    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < tol
+    assert np.abs(g_a.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
     # the sweep cut at the cross-objective sum (multi-GPU form) with a 1-rank "all-reduce"
     opt2, psi2, ga2 = eng.forward_update_sharded(chi, norms, spec.init, pulses, np.array(S), np.array(lam),
                                                  lambda x: x)
