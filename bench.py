@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Benchmark of the Krotov hot path on MI355X (the driver's contract).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one Krotov iteration of the BASELINE.json headline configuration
+(robustness ensemble: 256 objectives per GPU, Hilbert dimension 64, 4000 time
+steps, L=1 control, complex128) through ``krotov_amd.optimize_pulses`` with
+``propagator=krotov_amd.propagators.expm``: chi construction -> backward sweep
+storing chi(t_n) -> forward sweep with sequential pulse update -> tau, exactly
+the bracket the reference times per iteration (optimize.py:396 -> 510).  Inputs
+are synthetic (``krotov_amd.configs.config_c5``) and resident in HBM before the
+timed region.  One JSON line is printed by rank 0.
+
+For N > 1 the driver launches this file under ``torch.distributed.run``; the
+objectives are sharded over the ranks (weak scaling: 256 per GPU) and the L
+update sums are all-reduced once per time interval over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector FMA peak == fp64 MFMA peak (256 CU x 128 flop/clk x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0
+TAYLOR_DEGREE = 14       # degree credited by the roofline formula (theta <= 0.5, 2^-53)
+
+
+def algorithmic_flops(K, N, nt, L):
+    """F_prop = 8 N^2 m, F_upd = 8 N^2 + 8 N per (k, l, step)."""
+    f_prop = 8.0 * N * N * TAYLOR_DEGREE
+    f_upd = 8.0 * N * N + 8.0 * N
+    backward = K * (nt - 1) * f_prop
+    update = K * (nt - 1) * (f_prop + L * f_upd)
+    return backward, update
+
+
+def algorithmic_bytes(K, N, nt, L):
+    """HBM bytes per launch: chi written once (backward) / read once (update),
+    operators read once per sweep, pulses and shapes."""
+    chi = 16.0 * K * N * (nt - 1)
+    ops = 16.0 * K * (1 + L) * N * N
+    return chi + ops + 8.0 * L * (nt - 1), chi + ops + 3 * 8.0 * L * (nt - 1)
+
+
+def cpu_baseline(args):
+    """Oracle in reference-structured mode on a bounded sample of the workload."""
+    from krotov_amd import configs
+    from oracle import cpu_baseline as cb
+
+    cores = len(os.sched_getaffinity(0))
+    P = max(1, min(cores, args.cpu_procs))
+    K_s = min(args.K, 2 * P)
+    # calibrate: time of one dense expm @ state at this N on this host
+    calib = configs.config_c5(K=1, N=args.N, nt=41, L=args.L)
+    r = cb.timed_iteration(calib, processes=1)
+    t_prop = r['seconds'] / r['props']
+    per_proc = (K_s + P - 1) // P
+    nt_s = int(min(args.nt - 1, max(20, args.cpu_seconds / (2 * per_proc * t_prop))))
+    spec = configs.config_c5(K=K_s, N=args.N, nt=nt_s + 1, L=args.L, distinct=args.distinct)
+    r = cb.timed_iteration(spec, processes=P)
+    return {
+        'value': r['props'] / r['seconds'],
+        'unit': 'state*timestep props/s',
+        'cores': r['processes'],
+        'kind': 'port',
+        'sample': 'one Krotov iteration of the same ensemble restricted to K=%d objectives x %d intervals '
+                  '(dt unchanged), NumPy oracle in reference-structured mode: dense expm per objective per '
+                  'step (SciPy if present), 1 BLAS thread per process, %d processes; %.1f s' % (
+                      K_s, nt_s, r['processes'], r['seconds']),
+        'seconds_per_prop_single_core': t_prop,
+        'host_cores_visible': cores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--K', type=int, default=256, help='objectives per GPU')
+    ap.add_argument('--N', type=int, default=64)
+    ap.add_argument('--nt', type=int, default=4001)
+    ap.add_argument('--L', type=int, default=1)
+    ap.add_argument('--distinct', action='store_true', help='every objective gets its own random drift')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--cpu-procs', type=int, default=64)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        group = dist.group.WORLD
+
+    os.environ['KH_PROFILE'] = '1'
+    import krotov_amd
+    from krotov_amd import configs, engine as _engine_mod
+
+    K_total = args.K * world if args.scaling == 'weak' else args.K
+    spec = configs.config_c5(K=K_total, N=args.N, nt=args.nt, L=args.L, distinct=args.distinct)
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+
+    n_iter = args.warmup + args.steps
+    marks = {}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def hook(**kw):
+        it = kw['iteration']
+        if it == args.warmup:
+            eng = _engine_mod.LAST_ENGINE()
+            if eng is not None:
+                eng.kernel_times_ms(reset=True)
+            barrier()
+            marks['t0'] = time.perf_counter()
+        elif it == n_iter:
+            barrier()
+            marks['t1'] = time.perf_counter()
+        return None
+
+    res = krotov_amd.optimize_pulses(
+        objectives, pulse_options, spec.tlist,
+        propagator=krotov_amd.propagators.expm,
+        chi_constructor=krotov_amd.functionals.chis_re,
+        info_hook=hook, iter_stop=n_iter, process_group=group,
+    )
+    elapsed = marks['t1'] - marks['t0']
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng = _engine_mod.LAST_ENGINE()
+    times = eng.kernel_times_ms(reset=True)
+    stats = eng.stats()
+
+    if rank == 0:
+        K_loc = eng.K
+        props = K_total * (args.nt - 1) * 2 * args.steps
+        f_bw, f_up = algorithmic_flops(K_loc, args.N, args.nt, args.L)
+        b_bw, b_up = algorithmic_bytes(K_loc, args.N, args.nt, args.L)
+        t_bw = float(np.mean(times['backward'][-args.steps:])) * 1e-3
+        t_up = float(np.mean(times['update'][-args.steps:])) * 1e-3
+        ms_per_step = elapsed / args.steps * 1e3
+        dominant = 'update' if t_up >= t_bw else 'backward'
+        f_dom, t_dom = (f_up, t_up) if dominant == 'update' else (f_bw, t_bw)
+        out = {
+            'metric': 'state*timestep propagations/s (Krotov iterations/s in iterations_per_sec), '
+                      '256-objective N=64 ensemble',
+            'value': props / elapsed,
+            'unit': 'props/s',
+            'iterations_per_sec': args.steps / elapsed,
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True,
+            'scaling': args.scaling,
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE config 5: robustness ensemble, %d objectives%s x N=%d x %d time steps, '
+                            'L=%d control, chis_re, complex128; one step = one Krotov iteration '
+                            '(backward sweep + forward/update sweep)' % (
+                                K_total, ' (%d per GPU)' % args.K if world > 1 else '', args.N, args.nt - 1, args.L),
+                'objectives': K_total, 'N': args.N, 'time_steps': args.nt - 1, 'controls': args.L,
+                'distinct_drifts': bool(args.distinct),
+                'parallelism': 'objectives sharded over %d GPU(s); 1 all-reduce of L doubles per time step' % world,
+                'kernel': eng.kernel,
+            },
+            'roofline': {
+                'bound': 'mfma',
+                'kernel': 'kh_tile_forward_update' if dominant == 'update' else 'kh_tile_sweep_store',
+                'achieved': f_dom / t_dom / 1e12,
+                'peak': FP64_PEAK_TFLOPS,
+                'unit': 'TFLOP/s',
+                'frac': f_dom / t_dom / 1e12 / FP64_PEAK_TFLOPS,
+                'traffic': None,
+                'note': 'fp64 vector-FMA bound (complex matrix-vector products cannot use MFMA tiles); the fp64 '
+                        'vector peak equals the fp64 MFMA peak on MI355X (78.6 TFLOP/s). Algorithmic flops: '
+                        'K*(nt-1)*(8 N^2 * 14 [+ L*(8 N^2 + 8 N) for the update sweep]).',
+                'launch_ms': t_dom * 1e3,
+            },
+            'kernels': {
+                'backward_sweep_ms': t_bw * 1e3,
+                'update_sweep_ms': t_up * 1e3,
+                'backward_tflops': f_bw / t_bw / 1e12,
+                'update_tflops': f_up / t_up / 1e12,
+                'backward_hbm_gbs': b_bw / t_bw / 1e9,
+                'update_hbm_gbs': b_up / t_up / 1e9,
+                'hbm_frac_of_8TBs': max(b_bw / t_bw, b_up / t_up) / 1e9 / HBM_PEAK_GBS,
+                'matvecs_issued_last_update_sweep': stats['matvecs'],
+                'matvecs_credited_per_sweep': K_loc * (args.nt - 1) * (TAYLOR_DEGREE + args.L),
+            },
+            'final_J_T_re': float(1 - np.mean(np.array(res.tau_vals[-1]).real)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+            out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

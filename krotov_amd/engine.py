@@ -8,13 +8,23 @@ The three sweeps map onto the reference's three ``parallel_map`` dispatches
 (reference src/krotov/optimize.py:302-313, 413-425, 444-501).
 """
 import ctypes
+import os
+import weakref
 
 import numpy as np
 import torch
 
 from . import _lib
 
-__all__ = ['HipKrotovEngine']
+__all__ = ['HipKrotovEngine', 'LAST_ENGINE']
+
+_last_engine = None
+
+
+def LAST_ENGINE():
+    """The most recently created engine that is still alive (for benchmarks
+    that need the per-launch timings of an engine built inside optimize_pulses)."""
+    return None if _last_engine is None else _last_engine()
 
 
 def _require_gpu():
@@ -99,6 +109,38 @@ class HipKrotovEngine:
             _lib.check(self._lib.kh_engine_create(ctypes.byref(pr), ctypes.byref(self._handle)))
         self.op_norms = norms.reshape(self.K, 1 + self.L)
         self.kernel = self._lib.kh_engine_kernel(self._handle).decode()
+        # optional per-launch timing with HIP events on the launch stream
+        self.profile = os.environ.get('KH_PROFILE', '0') == '1'
+        self._events = {'forward': [], 'backward': [], 'update': []}
+        global _last_engine
+        _last_engine = weakref.ref(self)
+
+    def _timed(self, name):
+        """Context manager recording HIP events around a launch when profiling."""
+        eng = self
+
+        class _T:
+            def __enter__(self_t):
+                if eng.profile:
+                    self_t.a = torch.cuda.Event(enable_timing=True)
+                    self_t.b = torch.cuda.Event(enable_timing=True)
+                    self_t.a.record(torch.cuda.current_stream(eng.device))
+
+            def __exit__(self_t, *exc):
+                if eng.profile:
+                    self_t.b.record(torch.cuda.current_stream(eng.device))
+                    eng._events[name].append((self_t.a, self_t.b))
+                return False
+
+        return _T()
+
+    def kernel_times_ms(self, reset=True):
+        """Per-launch durations (ms) measured by HIP events since the last reset."""
+        torch.cuda.synchronize(self.device)
+        out = {k: [a.elapsed_time(b) for a, b in v] for k, v in self._events.items()}
+        if reset:
+            self._events = {k: [] for k in self._events}
+        return out
 
     # -- helpers -----------------------------------------------------------
     def close(self):
@@ -143,9 +185,10 @@ class HipKrotovEngine:
         init = self._c(init, (self.K, self.N))
         psi_T = torch.empty_like(init)
         states = torch.empty((self.K, self.nt, self.N), dtype=torch.complex128, device=self.device) if store else None
-        _lib.check(self._lib.kh_forward_store(
-            self._handle, pulses.data_ptr(), init.data_ptr(),
-            states.data_ptr() if store else None, psi_T.data_ptr(), self._stream()))
+        with self._timed('forward'):
+            _lib.check(self._lib.kh_forward_store(
+                self._handle, pulses.data_ptr(), init.data_ptr(),
+                states.data_ptr() if store else None, psi_T.data_ptr(), self._stream()))
         return (psi_T, states) if store else psi_T
 
     def backward(self, chi_T, pulses, out=None):
@@ -154,8 +197,9 @@ class HipKrotovEngine:
         chi_T = self._c(chi_T, (self.K, self.N))
         if out is None:
             out = torch.empty((self.K, self.nt, self.N), dtype=torch.complex128, device=self.device)
-        _lib.check(self._lib.kh_backward_store(
-            self._handle, chi_T.data_ptr(), pulses.data_ptr(), out.data_ptr(), self._stream()))
+        with self._timed('backward'):
+            _lib.check(self._lib.kh_backward_store(
+                self._handle, chi_T.data_ptr(), pulses.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
     def forward_update(self, chi_store, chi_norms, init, guess, shape, lambdas):
@@ -169,10 +213,11 @@ class HipKrotovEngine:
         opt = torch.empty_like(guess)
         psi_T = torch.empty_like(init)
         g_a = torch.empty((self.L,), dtype=torch.float64, device=self.device)
-        _lib.check(self._lib.kh_forward_update(
-            self._handle, chi_store.data_ptr(), chi_norms.data_ptr(), init.data_ptr(), guess.data_ptr(),
-            shape.data_ptr(), lambdas.data_ptr(), opt.data_ptr(), psi_T.data_ptr(), g_a.data_ptr(),
-            self._stream()))
+        with self._timed('update'):
+            _lib.check(self._lib.kh_forward_update(
+                self._handle, chi_store.data_ptr(), chi_norms.data_ptr(), init.data_ptr(), guess.data_ptr(),
+                shape.data_ptr(), lambdas.data_ptr(), opt.data_ptr(), psi_T.data_ptr(), g_a.data_ptr(),
+                self._stream()))
         return opt, psi_T, g_a
 
     def forward_update_sharded(self, chi_store, chi_norms, init, guess, shape, lambdas, all_reduce):
@@ -191,6 +236,8 @@ class HipKrotovEngine:
         g_a = torch.empty((self.L,), dtype=torch.float64, device=self.device)
         partial = torch.zeros((self.L,), dtype=torch.float64, device=self.device)
         lib, h = self._lib, self._handle
+        timer = self._timed('update')
+        timer.__enter__()
         _lib.check(lib.kh_update_begin(
             h, chi_store.data_ptr(), chi_norms.data_ptr(), init.data_ptr(), guess.data_ptr(),
             opt.data_ptr(), g_a.data_ptr(), partial.data_ptr(), self._stream()))
@@ -200,6 +247,7 @@ class HipKrotovEngine:
                 h, n, partial.data_ptr(), chi_store.data_ptr(), chi_norms.data_ptr(), shape.data_ptr(),
                 lambdas.data_ptr(), opt.data_ptr(), g_a.data_ptr(), partial.data_ptr(), self._stream()))
         _lib.check(lib.kh_update_end(h, psi_T.data_ptr(), self._stream()))
+        timer.__exit__()
         return opt, psi_T, g_a
 
     def tau(self, targets, psi_T):

@@ -36,6 +36,11 @@ import math
 
 import numpy as np
 
+try:  # load SciPy's own OpenBLAS copy *before* pinning, so the pin covers it too
+    import scipy.linalg as _scipy_linalg  # noqa: F401
+except Exception:  # pragma: no cover
+    _scipy_linalg = None
+
 try:  # single-threaded BLAS, as the reference pins it (optimize.py:233-238,
     # propagators.py:116); 8 OpenBLAS threads on 64x64 operands are ~40x slower
     import threadpoolctl as _tpc
