@@ -16,6 +16,10 @@ typedef double2 cplx;
 #define KH_MAX_L 8          // controls per problem the kernels are compiled for
 #define KH_MAX_DEGREE 64    // hard cap on the Taylor degree per sub-step
 
+// 1/j for the Taylor coefficients: a scalar load instead of two fp64 divisions
+// (v_rcp_f64 + Newton steps, ~60 cycles each) on the critical path of every term
+__constant__ double kh_inv_table[KH_MAX_DEGREE + 1] = {0.0, 1.0 / 1, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11, 1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18, 1.0 / 19, 1.0 / 20, 1.0 / 21, 1.0 / 22, 1.0 / 23, 1.0 / 24, 1.0 / 25, 1.0 / 26, 1.0 / 27, 1.0 / 28, 1.0 / 29, 1.0 / 30, 1.0 / 31, 1.0 / 32, 1.0 / 33, 1.0 / 34, 1.0 / 35, 1.0 / 36, 1.0 / 37, 1.0 / 38, 1.0 / 39, 1.0 / 40, 1.0 / 41, 1.0 / 42, 1.0 / 43, 1.0 / 44, 1.0 / 45, 1.0 / 46, 1.0 / 47, 1.0 / 48, 1.0 / 49, 1.0 / 50, 1.0 / 51, 1.0 / 52, 1.0 / 53, 1.0 / 54, 1.0 / 55, 1.0 / 56, 1.0 / 57, 1.0 / 58, 1.0 / 59, 1.0 / 60, 1.0 / 61, 1.0 / 62, 1.0 / 63, 1.0 / 64};
+
 // ---------------------------------------------------------------------------
 // complex arithmetic
 // ---------------------------------------------------------------------------
@@ -112,6 +116,40 @@ __host__ __device__ inline void kh_choose_degree(double theta, double tol, doubl
     *m_out = m;
 }
 
+// The same rule without divisions on the device: tab[m] (host-built, see
+// kh_build_degree_table) is the largest theta for which degree m meets tol, so
+// the degree is the smallest m with theta <= tab[m].  `hint` (the previous
+// interval's degree) makes the search O(1) along a smooth pulse.
+__host__ inline void kh_build_degree_table(double tol, double *tab /*[KH_MAX_DEGREE+1]*/) {
+    tab[0] = 0.0;
+    for (int m = 1; m <= KH_MAX_DEGREE; ++m) {
+        // bound(th) = th^(m+1)/(m+1)! / (1 - th/(m+2)), increasing on [0, m+2)
+        double lo = 0.0, hi = (double)(m + 2) * (1.0 - 1e-12);
+        for (int it = 0; it < 200; ++it) {
+            const double th = 0.5 * (lo + hi);
+            double term = 1.0;
+            for (int j = 1; j <= m + 1; ++j) term *= th / j;
+            if (term <= tol * (1.0 - th / (m + 2))) lo = th; else hi = th;
+        }
+        tab[m] = lo;
+    }
+}
+
+__device__ __forceinline__ void kh_degree_lookup(double theta, const double *__restrict__ tab, double theta_max,
+                                                 double inv_theta_max, int hint, int *s_out, int *m_out) {
+    int s = 1;
+    double th = theta;
+    if (theta > theta_max) {  // rare: several Taylor sub-steps
+        s = (int)ceil(theta * inv_theta_max);
+        th = theta / s;
+    }
+    int m = hint < 1 ? 1 : (hint > KH_MAX_DEGREE ? KH_MAX_DEGREE : hint);
+    while (m > 1 && th <= tab[m - 1]) --m;
+    while (m < KH_MAX_DEGREE && th > tab[m]) ++m;
+    *s_out = s;
+    *m_out = m;
+}
+
 // ---------------------------------------------------------------------------
 // cross-workgroup exchange of per-workgroup partial sums
 // ---------------------------------------------------------------------------
@@ -134,58 +172,75 @@ struct KhExchange {
     long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
 };
 
-__device__ __forceinline__ void kh_publish(const KhExchange &ex, int parity, int wg, int L, int l,
-                                           double value, unsigned int epoch) {
-    const kh_u64 bits = (kh_u64)__double_as_longlong(value);
-    kh_u64 *g = ex.slots + (((size_t)parity * ex.G + wg) * L + l) * 2;
-    __hip_atomic_store(g, ((kh_u64)epoch << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g + 1, ((kh_u64)epoch << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+// Called by (at least) the first 2*L lanes of one wave: one 8-byte store each.
+__device__ __forceinline__ void kh_publish(const KhExchange &ex, int parity, int wg, int L, int lane,
+                                           const double *values, unsigned int epoch) {
+    if (lane < 2 * L) {
+        const int l = lane >> 1;
+        const kh_u64 bits = (kh_u64)__double_as_longlong(values[l]);
+        const kh_u64 half = (lane & 1) ? (bits & 0xffffffffull) : (bits >> 32);
+        kh_u64 *g = ex.slots + (((size_t)parity * ex.G + wg) * L + l) * 2 + (lane & 1);
+        __hip_atomic_store(g, ((kh_u64)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-// Called by ONE full wave.  Returns false on timeout/abort.  On success every
-// lane holds in out[l] the sum over all workgroups, accumulated in the fixed
-// order (lane-strided partial sums in workgroup order, then the sum64 tree),
-// identical in every workgroup.
+#define KH_GATHER_CHUNKS 4  // workgroups per lane: the exchange handles up to 256 workgroups
+
+// Called by ONE full wave.  Returns false on timeout/abort.  All granule loads
+// of a polling round are issued back to back (one memory round trip per round,
+// not one per producer).  On success every lane holds in out[l] the sum over
+// all workgroups, accumulated in a fixed order (per lane: workgroups lane,
+// lane+64, ...; then the sum64 tree) that is identical in every workgroup, so
+// every workgroup derives bit-identical pulse values.
 template <int MAXL>
 __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int L, unsigned int epoch, int lane,
                                           double (&out)[MAXL]) {
-    double acc[MAXL];
-#pragma unroll
-    for (int l = 0; l < MAXL; ++l) acc[l] = 0.0;
+    const kh_u64 *base = ex.slots + (size_t)parity * ex.G * L * 2;
+    kh_u64 a[MAXL][KH_GATHER_CHUNKS], b[MAXL][KH_GATHER_CHUNKS];
     const long long t0 = wall_clock64();
-    for (int wg = lane; wg - lane < ex.G; wg += 64) {  // uniform trip count
-        const bool active = wg < ex.G;
+    unsigned int spins = 0;
+    for (;;) {
+        bool ok = true;
 #pragma unroll
         for (int l = 0; l < MAXL; ++l) {
-            if (l >= L) break;
-            const kh_u64 *g = ex.slots + (((size_t)parity * ex.G + (active ? wg : 0)) * L + l) * 2;
-            kh_u64 a = 0, b = 0;
-            unsigned int spins = 0;
-            for (;;) {
-                a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ok = !active || (((unsigned int)(a >> 32) == epoch) && ((unsigned int)(b >> 32) == epoch));
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0) {  // wave-uniform
-                    const bool gave_up =
-                        (wall_clock64() - t0 > ex.timeout_ticks) ||
-                        (__hip_atomic_load(ex.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
-                    if (__any(gave_up)) {
-                        if (lane == 0)
-                            __hip_atomic_store(ex.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        return false;
-                    }
+#pragma unroll
+            for (int c = 0; c < KH_GATHER_CHUNKS; ++c) {
+                const int wg = lane + 64 * c;
+                if (l < L && wg < ex.G) {
+                    const kh_u64 *g = base + ((size_t)wg * L + l) * 2;
+                    a[l][c] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b[l][c] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    a[l][c] = b[l][c] = (kh_u64)epoch << 32;  // neutral: tag ok, value +0.0
                 }
             }
-            if (active) {
-                const kh_u64 bits = ((a & 0xffffffffull) << 32) | (b & 0xffffffffull);
-                acc[l] += __longlong_as_double((long long)bits);
+        }
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l)
+#pragma unroll
+            for (int c = 0; c < KH_GATHER_CHUNKS; ++c)
+                ok = ok && ((unsigned int)(a[l][c] >> 32) == epoch) && ((unsigned int)(b[l][c] >> 32) == epoch);
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0) {  // wave-uniform
+            const bool gave_up =
+                (wall_clock64() - t0 > ex.timeout_ticks) ||
+                (__hip_atomic_load(ex.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+            if (__any(gave_up)) {
+                if (lane == 0) __hip_atomic_store(ex.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
             }
         }
     }
 #pragma unroll
-    for (int l = 0; l < MAXL; ++l) out[l] = (l < L) ? sum64(acc[l]) : 0.0;
+    for (int l = 0; l < MAXL; ++l) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < KH_GATHER_CHUNKS; ++c) {
+            const kh_u64 bits = ((a[l][c] & 0xffffffffull) << 32) | (b[l][c] & 0xffffffffull);
+            acc += __longlong_as_double((long long)bits);
+        }
+        out[l] = (l < L) ? sum64(acc) : 0.0;
+    }
     return true;
 }

@@ -17,7 +17,8 @@ struct KhSweepArgs {
     const double *op_norms;   // [K*(1+L)]
     const double *dt;         // [nt-1]
     double fre, fim;          // equation-of-motion factor f (propagators.py:94-99)
-    double tol, theta_max;
+    double tol, theta_max, inv_theta_max;
+    const double *deg_theta;  // [KH_MAX_DEGREE+1] largest theta per Taylor degree (kh_build_degree_table)
     double *stats;            // [0] += matvecs issued (per objective, summed)
 };
 
@@ -82,14 +83,15 @@ __device__ __forceinline__ int kh_gen_expm_action(const KhSweepArgs &p, const cp
     for (int l = 0; l < L; ++l) theta += fabs(eps[l]) * norms_k[1 + l];
     theta *= dt;
     int nsub, m;
-    kh_choose_degree(theta, p.tol, p.theta_max, &nsub, &m);
+    kh_degree_lookup(theta, p.deg_theta, p.theta_max, p.inv_theta_max, 12, &nsub, &m);
     const double h = dt / nsub;
     for (int sub = 0; sub < nsub; ++sub) {
         for (int i = tid; i < N; i += KH_GEN_THREADS) s.xa[i] = s.acc[i];
         __syncthreads();
         cplx *xin = s.xa, *xout = s.xb;
         for (int j = 1; j <= m; ++j) {
-            const cplx coef = c_make(p.fre * h / j, p.fim * h / j);
+            const double hj = h * kh_inv_table[j];
+            const cplx coef = c_make(p.fre * hj, p.fim * hj);
             for (int row0 = 0; row0 < N; row0 += 16) {
                 const int row = row0 + grp;
                 const cplx d = kh_gen_row_dot(ops_k, eps, L, N, row, c16, xin);
@@ -244,8 +246,7 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         // ---- cross-objective sum D_l (optimize.py:470) ----
         if (u.internal_exchange) {
             if (wave == 0) {
-                if (lane == 0)
-                    for (int l = 0; l < L; ++l) kh_publish(ex, n & 1, blockIdx.x, L, l, part[l], (unsigned)(n + 1));
+                kh_publish(ex, n & 1, blockIdx.x, L, lane, part, (unsigned)(n + 1));
                 double D[KH_MAX_L];
                 const bool ok = kh_gather<KH_MAX_L>(ex, n & 1, L, (unsigned)(n + 1), lane, D);
                 if (lane == 0) {

@@ -61,43 +61,34 @@ __device__ __forceinline__ void kh_tile_matvec(const cplx (&a)[RPT][8], const cp
 }
 
 // state (in registers of every lane of the row group) <- exp(f A dt) state.
-// buf0/buf1: LDS ping-pong vectors of KH_TILE_N entries.  On entry buf0 must
-// hold the state (all rows written, barrier passed).  Returns matvec count.
+// buf: LDS ping-pong vectors.  On entry buf[cur] holds the state (all rows
+// written, barrier passed); on exit buf[cur] (updated) holds the NEW state, so
+// consecutive intervals chain without an extra write + barrier: the last
+// Taylor term is never needed in LDS, its slot receives the state instead.
+// One barrier per matrix-vector product.  Returns the matvec count.
 template <int RPT>
-__device__ __forceinline__ int kh_tile_expm_action(const cplx (&a)[RPT][8], cplx (&state)[RPT], cplx *buf0,
-                                                   cplx *buf1, double fre, double fim, double dt, int nsub,
-                                                   int m, int wave, int lane) {
+__device__ __forceinline__ int kh_tile_expm_action(const cplx (&a)[RPT][8], cplx (&state)[RPT],
+                                                   cplx (*buf)[KH_TILE_N], int &cur, double fre, double fim,
+                                                   double dt, int nsub, int m, int wave, int lane) {
     const int cg = lane & 7;
-    const double h = dt / nsub;
+    const double h = nsub == 1 ? dt : dt / nsub;
     for (int sub = 0; sub < nsub; ++sub) {
-        if (sub > 0) {
-            // restart the series from the current state
-            if (cg == 0) {
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) buf0[KhTile<RPT>::row(wave, lane, r)] = state[r];
-            }
-            __syncthreads();
-        }
-        cplx *xin = buf0, *xout = buf1;
         for (int j = 1; j <= m; ++j) {
-            const cplx coef = c_make(fre * h / j, fim * h / j);
+            const double hj = h * kh_inv_table[j];
+            const cplx coef = c_make(fre * hj, fim * hj);
             cplx y[RPT];
-            kh_tile_matvec<RPT>(a, xin, cg, y);
+            kh_tile_matvec<RPT>(a, buf[cur], cg, y);
+            const bool last = (j == m);
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
                 const cplx t = c_mul(coef, y[r]);
                 state[r].x += t.x;
                 state[r].y += t.y;
-                if (cg == 0) xout[KhTile<RPT>::row(wave, lane, r)] = t;
+                if (cg == 0) buf[cur ^ 1][KhTile<RPT>::row(wave, lane, r)] = last ? state[r] : t;
             }
             __syncthreads();
-            cplx *tmp = xin;
-            xin = xout;
-            xout = tmp;
+            cur ^= 1;
         }
-        // after an odd number of terms the newest term sits in buf1; the next
-        // sub-step (or the caller) rewrites buf0 before reading it, and every
-        // thread has passed the barrier above, so no hazard remains.
     }
     return nsub * m;
 }
@@ -147,6 +138,7 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
             state[r] = row < N ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
         }
         __syncthreads();  // previous objective's readers are done with buf
+        int cur = 0;
         if (cg == 0) {
 #pragma unroll
             for (int r = 0; r < RPT; ++r) buf[0][KhTile<RPT>::row(wave, lane, r)] = state[r];
@@ -155,32 +147,40 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
         if (store != nullptr && wave == 0 && lane < N)
             store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + lane] = buf[0][lane];
 
+        // per-interval scalars are fetched one interval ahead (their load
+        // latency would otherwise sit on the critical path of every interval)
+        const int n0 = direction > 0 ? 0 : nt - 2;
+        double eps_next[LT], dt_next = p.dt[n0];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) eps_next[l] = pulses[(size_t)l * (nt - 1) + n0];
+        int m_hint = 12;
         for (int step = 0; step < nt - 1; ++step) {
             const int n = direction > 0 ? step : nt - 2 - step;
             double eps[LT];
             double theta = nrm[0];
+            const double dt = dt_next;
 #pragma unroll
             for (int l = 0; l < LT; ++l) {
-                eps[l] = pulses[(size_t)l * (nt - 1) + n];
+                eps[l] = eps_next[l];
                 theta += fabs(eps[l]) * nrm[1 + l];
             }
-            const double dt = p.dt[n];
+            if (step + 1 < nt - 1) {
+                const int nn = direction > 0 ? n + 1 : n - 1;
+                dt_next = p.dt[nn];
+#pragma unroll
+                for (int l = 0; l < LT; ++l) eps_next[l] = pulses[(size_t)l * (nt - 1) + nn];
+            }
             int nsub, m;
-            kh_choose_degree(theta * dt, p.tol, p.theta_max, &nsub, &m);
+            kh_degree_lookup(theta * dt, p.deg_theta, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
+            m_hint = m;
             cplx a[RPT][8];
             kh_tile_build_generator<RPT, LT>(h, eps, a);
-            matvecs += kh_tile_expm_action<RPT>(a, state, buf[0], buf[1], p.fre, p.fim, dt, nsub, m, wave, lane);
-            // publish the new state in buf[0] (next interval's first term) and
-            // stream it to HBM with one coalesced store
-            if (cg == 0) {
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) buf[0][KhTile<RPT>::row(wave, lane, r)] = state[r];
-            }
-            __syncthreads();
+            matvecs += kh_tile_expm_action<RPT>(a, state, buf, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
+            // buf[cur] now holds the new state: stream it to HBM, one coalesced 1 KiB store
             if (store != nullptr && wave == 0 && lane < N)
-                store[((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N + lane] = buf[0][lane];
+                store[((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N + lane] = buf[cur][lane];
         }
-        if (state_out != nullptr && wave == 0 && lane < N) state_out[(size_t)k * N + lane] = buf[0][lane];
+        if (state_out != nullptr && wave == 0 && lane < N) state_out[(size_t)k * N + lane] = buf[cur][lane];
     }
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }
@@ -190,13 +190,15 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
 // ---------------------------------------------------------------------------
 // Requires gridDim.x == K (one resident workgroup per objective): operators
 // and the running state never leave the registers / LDS of their workgroup.
+// Barriers per interval: 1 (partial sums) + 1 (broadcast of the reduced sums)
+// + one per Taylor term.
 template <int RPT, int LT>
 __global__ void __launch_bounds__(512 / RPT)
 kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     constexpr int WAVES = KhTile<RPT>::WAVES;
     __shared__ __attribute__((aligned(16))) cplx buf[2][KH_TILE_N];
-    __shared__ __attribute__((aligned(16))) double red[WAVES][LT][2];
-    __shared__ __attribute__((aligned(16))) double D_sh[LT + 1];  // [LT] = ok flag
+    __shared__ __attribute__((aligned(16))) double red[2][WAVES][LT][2];  // double-buffered on interval parity
+    __shared__ __attribute__((aligned(16))) double D_sh[2][LT + 1];       // [LT] = ok flag
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
     const int N = p.N, nt = p.nt;
     const int k = blockIdx.x;
@@ -210,8 +212,7 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     double nrm[1 + LT];
 #pragma unroll
     for (int o = 0; o <= LT; ++o) nrm[o] = norms_k[o];
-    // mu operators are the forward control operators themselves (mu.py:123-134);
-    // the engine passes mu_ops[k*L+l] == ops[k*(1+L)+1+l], so h[1+l] serves both.
+    // dH/d eps_l is the forward control operator itself (mu.py:123-134): h[1+l] serves both
     const double chi_norm = u.chi_norms[k];
 
     cplx state[RPT];
@@ -220,6 +221,7 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         const int row = KhTile<RPT>::row(wave, lane, r);
         state[r] = row < N ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     }
+    int cur = 0;
     if (cg == 0) {
 #pragma unroll
         for (int r = 0; r < RPT; ++r) buf[0][KhTile<RPT>::row(wave, lane, r)] = state[r];
@@ -240,13 +242,12 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         }
     };
 
-    // part[l] = chi_norm * Im(mu <chi(t_n) | H_l phi>) ; phi must be in buf[0]
-    double part[LT];
-    auto partials = [&]() {
+    // wave-level pieces of  chi_norm * Im(mu <chi(t_n) | H_l phi>)  -> red[par][wave]; phi in buf[cur]
+    auto partial_pieces = [&](int par) {
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
             cplx y[RPT];
-            kh_tile_matvec<RPT>(h[1 + l], buf[0], cg, y);
+            kh_tile_matvec<RPT>(h[1 + l], buf[cur], cg, y);
             cplx ov = c_make(0.0, 0.0);
             if (cg == 0) {
 #pragma unroll
@@ -254,72 +255,98 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
             }
             const double re = sum64(ov.x), im = sum64(ov.y);
             if (lane == 0) {
-                red[wave][l][0] = re;
-                red[wave][l][1] = im;
+                red[par][wave][l][0] = re;
+                red[par][wave][l][1] = im;
             }
         }
-        __syncthreads();
+        matvecs += LT;
+    };
+    // after a barrier: the workgroup's partial sums, same value in every thread
+    auto partial_total = [&](int par, double (&part)[LT]) {
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
             double re = 0.0, im = 0.0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) {
-                re += red[w][l][0];
-                im += red[w][l][1];
+                re += red[par][w][l][0];
+                im += red[par][w][l][1];
             }
             part[l] = chi_norm * (u.mu_re * im + u.mu_im * re);
         }
-        __syncthreads();
-        matvecs += LT;
     };
 
     const bool emit_only = (!u.internal_exchange && u.n_begin == u.n_end);
     if ((u.internal_exchange || emit_only) && u.n_begin < nt - 1) {
         load_chi(u.n_begin);
-        partials();
+        partial_pieces(u.n_begin & 1);
     }
+    __syncthreads();
     if (emit_only) {
+        double part[LT];
+        partial_total(u.n_begin & 1, part);
         if (tid == 0)
             for (int l = 0; l < LT; ++l) u.wg_partial[(size_t)k * LT + l] = part[l];
         return;
     }
 
+    // per-interval scalars, fetched one interval ahead
+    double dt_next = p.dt[u.n_begin], guess_next[LT], shape_next[LT], lam[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        guess_next[l] = u.guess[(size_t)l * (nt - 1) + u.n_begin];
+        shape_next[l] = u.shape[(size_t)l * (nt - 1) + u.n_begin];
+        lam[l] = u.lambda[l];
+    }
+    int m_hint = 12;
+
     for (int n = u.n_begin; n < u.n_end; ++n) {
+        const int par = n & 1;
         if (n + 1 < nt - 1) load_chi(n + 1);  // lands while this interval is processed
         // ---- cross-objective sum (optimize.py:470) ----
         if (u.internal_exchange) {
             if (wave == 0) {
-                if (lane == 0) {
-#pragma unroll
-                    for (int l = 0; l < LT; ++l) kh_publish(ex, n & 1, k, LT, l, part[l], (unsigned)(n + 1));
-                }
+                double part[LT];
+                partial_total(par, part);
+                kh_publish(ex, par, k, LT, lane, part, (unsigned)(n + 1));
                 double D[LT];
-                const bool ok = kh_gather<LT>(ex, n & 1, LT, (unsigned)(n + 1), lane, D);
+                const bool ok = kh_gather<LT>(ex, par, LT, (unsigned)(n + 1), lane, D);
                 if (lane == 0) {
 #pragma unroll
-                    for (int l = 0; l < LT; ++l) D_sh[l] = D[l];
-                    D_sh[LT] = ok ? 1.0 : 0.0;
+                    for (int l = 0; l < LT; ++l) D_sh[par][l] = D[l];
+                    D_sh[par][LT] = ok ? 1.0 : 0.0;
                 }
             }
-            __syncthreads();
-            if (D_sh[LT] == 0.0) return;
-        } else {
-            if (tid == 0) {
-                for (int l = 0; l < LT; ++l) D_sh[l] = u.D_in[l];
-            }
-            __syncthreads();
+        } else if (tid == 0) {
+            for (int l = 0; l < LT; ++l) D_sh[par][l] = u.D_in[l];
+            D_sh[par][LT] = 1.0;
         }
+        // scalars of this interval (prefetched) and prefetch of the next
+        const double dt = dt_next;
+        double guess[LT], shape[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            guess[l] = guess_next[l];
+            shape[l] = shape_next[l];
+        }
+        if (n + 1 < nt - 1) {
+            dt_next = p.dt[n + 1];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) {
+                guess_next[l] = u.guess[(size_t)l * (nt - 1) + n + 1];
+                shape_next[l] = u.shape[(size_t)l * (nt - 1) + n + 1];
+            }
+        }
+        __syncthreads();
+        if (D_sh[par][LT] == 0.0) return;
         // ---- pulse update (optimize.py:471-477) ----
-        const double dt = p.dt[n];
         double eps[LT];
         double theta = nrm[0];
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
-            const double S = u.shape[(size_t)l * (nt - 1) + n];
-            const double lam = u.lambda[l];
-            const double d1 = D_sh[l];
-            eps[l] = u.guess[(size_t)l * (nt - 1) + n] + (S / lam) * d1;
-            g_a_loc[l] += (S / lam) * (d1 * d1) * dt;
+            const double d1 = D_sh[par][l];
+            const double step = shape[l] / lam[l];
+            eps[l] = guess[l] + step * d1;
+            g_a_loc[l] += step * (d1 * d1) * dt;
             theta += fabs(eps[l]) * nrm[1 + l];
         }
         if (k == 0 && tid == 0) {
@@ -328,22 +355,25 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         }
         // ---- propagate over interval n with the updated pulse (optimize.py:479-491) ----
         int nsub, m;
-        kh_choose_degree(theta * dt, p.tol, p.theta_max, &nsub, &m);
+        kh_degree_lookup(theta * dt, p.deg_theta, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
+        m_hint = m;
         cplx a[RPT][8];
         kh_tile_build_generator<RPT, LT>(h, eps, a);
-        matvecs += kh_tile_expm_action<RPT>(a, state, buf[0], buf[1], p.fre, p.fim, dt, nsub, m, wave, lane);
-        if (cg == 0) {
-#pragma unroll
-            for (int r = 0; r < RPT; ++r) buf[0][KhTile<RPT>::row(wave, lane, r)] = state[r];
+        matvecs += kh_tile_expm_action<RPT>(a, state, buf, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
+        // ---- partial sums of the next interval (state is in buf[cur], barrier passed) ----
+        if (n + 1 < nt - 1) {
+            partial_pieces((n + 1) & 1);
+            __syncthreads();  // every wave's piece is in red[] before wave 0 totals it
         }
-        __syncthreads();
-        // ---- partial sums of the next interval ----
-        if (n + 1 < nt - 1) partials();
     }
     // running state back to the engine workspace (final states / next launch)
-    if (wave == 0 && lane < N) u.phi[(size_t)k * N + lane] = buf[0][lane];
-    if (!u.internal_exchange && u.n_end < nt - 1 && tid == 0)
-        for (int l = 0; l < LT; ++l) u.wg_partial[(size_t)k * LT + l] = part[l];
+    if (wave == 0 && lane < N) u.phi[(size_t)k * N + lane] = buf[cur][lane];
+    if (!u.internal_exchange && u.n_end < nt - 1) {
+        double part[LT];
+        partial_total(u.n_end & 1, part);
+        if (tid == 0)
+            for (int l = 0; l < LT; ++l) u.wg_partial[(size_t)k * LT + l] = part[l];
+    }
     if (k == 0 && tid == 0)
         for (int l = 0; l < LT; ++l) u.g_a[l] = (u.internal_exchange ? 0.0 : u.g_a[l]) + g_a_loc[l];
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);

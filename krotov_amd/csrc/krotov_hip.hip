@@ -52,6 +52,7 @@ struct kh_engine {
     const cplx **d_ops_bw = nullptr;  // [K*(1+L)] adjoints
     double *d_norms = nullptr;        // [K*(1+L)]
     double *d_dt = nullptr;           // [nt-1]
+    double *d_deg_theta = nullptr;    // [KH_MAX_DEGREE+1] degree thresholds for tol
     std::vector<void *> owned;        // adjoint operator copies
     // workspaces
     cplx *d_phi = nullptr;            // [K][N]
@@ -96,6 +97,8 @@ static KhSweepArgs sweep_args(const kh_engine *e, bool backward) {
     }
     p.tol = e->tol;
     p.theta_max = e->theta_max;
+    p.inv_theta_max = 1.0 / e->theta_max;
+    p.deg_theta = e->d_deg_theta;
     p.stats = e->d_stats;
     return p;
 }
@@ -107,6 +110,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree((void *)e->d_ops_bw);
     (void)hipFree(e->d_norms);
     (void)hipFree(e->d_dt);
+    (void)hipFree(e->d_deg_theta);
     (void)hipFree(e->d_phi);
     (void)hipFree(e->d_slots);
     (void)hipFree(e->d_abort);
@@ -187,16 +191,24 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
         kh_fro_norms<<<(unsigned)nops, 256>>>(e->d_ops_fw, (int)nops, e->N, e->d_norms);
         KH_HIP_E(hipGetLastError());
     }
+    {
+        double tab[KH_MAX_DEGREE + 1];
+        kh_build_degree_table(e->tol, tab);
+        KH_HIP_E(hipMalloc(&e->d_deg_theta, sizeof(tab)));
+        KH_HIP_E(hipMemcpy(e->d_deg_theta, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
     KH_HIP_E(hipMalloc(&e->d_dt, sizeof(double) * (e->nt - 1)));
     KH_HIP_E(hipMemcpy(e->d_dt, pr->dt, sizeof(double) * (e->nt - 1), hipMemcpyHostToDevice));
 
     // ---- kernel family
     e->kind = KIND_GENERIC;
-    e->grid_update = e->K < e->num_cus ? e->K : e->num_cus;
+    const int max_wgs = e->num_cus < 64 * KH_GATHER_CHUNKS ? e->num_cus : 64 * KH_GATHER_CHUNKS;
+    e->grid_update = e->K < max_wgs ? e->K : max_wgs;
     const char *force = getenv("KH_KERNEL");  // "generic" | "tile256" | "tile512" (testing)
-    const bool tile_ok = e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && e->K <= e->num_cus;
+    const bool tile_ok = e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && e->K <= max_wgs;
     if (tile_ok && !(force && strcmp(force, "generic") == 0)) {
-        e->kind = (e->L == 1) ? KIND_TILE_RPT2 : KIND_TILE_RPT1;
+        // two waves per SIMD are needed to keep the fp64 FMA pipe issuing back to back
+        e->kind = KIND_TILE_RPT1;
         if (force && strcmp(force, "tile512") == 0) e->kind = KIND_TILE_RPT1;
         if (force && strcmp(force, "tile256") == 0 && e->L <= 2) e->kind = KIND_TILE_RPT2;
         e->grid_update = e->K;
