@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .sharding import run_update_loop
 
 __all__ = ['HipKrotovEngine', 'LAST_ENGINE']
 
@@ -235,19 +236,28 @@ class HipKrotovEngine:
         psi_T = torch.empty_like(init)
         g_a = torch.empty((self.L,), dtype=torch.float64, device=self.device)
         partial = torch.zeros((self.L,), dtype=torch.float64, device=self.device)
-        lib, h = self._lib, self._handle
-        timer = self._timed('update')
-        timer.__enter__()
-        _lib.check(lib.kh_update_begin(
-            h, chi_store.data_ptr(), chi_norms.data_ptr(), init.data_ptr(), guess.data_ptr(),
-            opt.data_ptr(), g_a.data_ptr(), partial.data_ptr(), self._stream()))
-        for n in range(self.nt - 1):
-            all_reduce(partial)
-            _lib.check(lib.kh_update_step(
-                h, n, partial.data_ptr(), chi_store.data_ptr(), chi_norms.data_ptr(), shape.data_ptr(),
-                lambdas.data_ptr(), opt.data_ptr(), g_a.data_ptr(), partial.data_ptr(), self._stream()))
-        _lib.check(lib.kh_update_end(h, psi_T.data_ptr(), self._stream()))
-        timer.__exit__()
+        lib, h, eng = self._lib, self._handle, self
+
+        class _Stepper:
+            """kh_update_begin / kh_update_step / kh_update_end of the C ABI."""
+
+            def begin(self_s):
+                _lib.check(lib.kh_update_begin(
+                    h, chi_store.data_ptr(), chi_norms.data_ptr(), init.data_ptr(), guess.data_ptr(),
+                    opt.data_ptr(), g_a.data_ptr(), partial.data_ptr(), eng._stream()))
+                return partial
+
+            def step(self_s, n, D):
+                _lib.check(lib.kh_update_step(
+                    h, n, D.data_ptr(), chi_store.data_ptr(), chi_norms.data_ptr(), shape.data_ptr(),
+                    lambdas.data_ptr(), opt.data_ptr(), g_a.data_ptr(), partial.data_ptr(), eng._stream()))
+                return partial
+
+            def end(self_s):
+                _lib.check(lib.kh_update_end(h, psi_T.data_ptr(), eng._stream()))
+
+        with self._timed('update'):
+            run_update_loop(_Stepper(), self.nt - 1, all_reduce)
         return opt, psi_T, g_a
 
     def tau(self, targets, psi_T):

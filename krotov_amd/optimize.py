@@ -50,6 +50,7 @@ from .propagators import HipExpm, Propagator, expm
 from .result import Result
 from .second_order import _overlap
 from .shapes import one_shape, zero_shape
+from .sharding import gather_rows, shard_range
 
 __all__ = ['optimize_pulses']
 
@@ -352,9 +353,7 @@ class _HipBackend:
             self.rank = dist.get_rank(process_group)
             self.world = dist.get_world_size(process_group)
         # contiguous shard of objectives for this rank
-        per = (K_total + self.world - 1) // self.world
-        self.k0 = min(self.rank * per, K_total)
-        self.k1 = min(self.k0 + per, K_total)
+        self.k0, self.k1 = shard_range(K_total, self.world, self.rank)
         if self.k1 <= self.k0:
             raise ValueError("rank %d has no objectives (K=%d, world=%d)" % (self.rank, K_total, self.world))
         self.K_total = K_total
@@ -436,17 +435,7 @@ class _HipBackend:
 
     def _gather_rows(self, local):
         """(K_loc, ...) host array on every rank -> (K_total, ...) on every rank."""
-        if self.world == 1:
-            return local
-        per = (self.K_total + self.world - 1) // self.world
-        t = self.torch
-        pad = np.zeros((per,) + local.shape[1:], dtype=local.dtype)
-        pad[: local.shape[0]] = local
-        send = t.from_numpy(np.ascontiguousarray(pad)).to(self.engine.device)
-        recv = [t.empty_like(send) for _ in range(self.world)]
-        self.dist.all_gather(recv, send, group=self.group)
-        full = np.concatenate([r.cpu().numpy() for r in recv], axis=0)
-        return full[: self.K_total]
+        return gather_rows(local, self.K_total, self.world, self.group, self.engine.device)
 
     def initial_forward(self, pulses):
         self.fw_T_dev = self.engine.forward(self._pulses(pulses), self.init)
