@@ -50,11 +50,14 @@ __device__ __forceinline__ void c_fma_conj(cplx &acc, cplx a, cplx b) {
 // DPP cross-lane moves on doubles (two 32-bit DPP moves each)
 // ---------------------------------------------------------------------------
 
+// every pattern used below reads a valid lane for every lane, so the "old"
+// operand is irrelevant: mov_dpp (undef old, bound_ctrl) compiles to a single
+// v_mov_b32_dpp per dword instead of copy + dpp.
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -169,6 +172,7 @@ struct KhExchange {
     kh_u64 *slots;          // [2][G][L][2]
     unsigned int *abort_flag;  // set by any workgroup that gave up
     int G;                  // workgroups taking part
+    int first_poll_delay;   // s_sleep units (64 cycles) between publishing and the first poll
     long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
 };
 
@@ -199,6 +203,9 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
     kh_u64 a[MAXL][KH_GATHER_CHUNKS], b[MAXL][KH_GATHER_CHUNKS];
     const long long t0 = wall_clock64();
     unsigned int spins = 0;
+    // a poll issued before the slowest producer's store has reached the memory
+    // side costs a whole extra round trip: give the stores a head start
+    for (int d = 0; d < ex.first_poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
     for (;;) {
         bool ok = true;
 #pragma unroll

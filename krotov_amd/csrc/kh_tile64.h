@@ -84,7 +84,8 @@ __device__ __forceinline__ int kh_tile_expm_action(const cplx (&a)[RPT][8], cplx
                 const cplx t = c_mul(coef, y[r]);
                 state[r].x += t.x;
                 state[r].y += t.y;
-                if (cg == 0) buf[cur ^ 1][KhTile<RPT>::row(wave, lane, r)] = last ? state[r] : t;
+                const double wx = last ? state[r].x : t.x, wy = last ? state[r].y : t.y;
+                if (cg == 0) buf[cur ^ 1][KhTile<RPT>::row(wave, lane, r)] = c_make(wx, wy);
             }
             __syncthreads();
             cur ^= 1;

@@ -1,0 +1,337 @@
+// Two-terms-per-phase register-tile kernels: N <= 64, exactly one control (L = 1).
+//
+// The Taylor series of exp(c A) v is a chain of dependent matrix-vector
+// products; on one CU each product costs a fixed LDS-write -> barrier ->
+// LDS-read round trip (~250 cycles) and a cross-lane reduction besides its
+// 256 cycles of fp64 FMAs.  With a single control the generator is
+// A(eps) = H0 + eps H1, so its square is a quadratic polynomial with three
+// FIXED matrices,  A^2 = P0 + eps P1 + eps^2 P2,  P0 = H0 H0,
+// P1 = H0 H1 + H1 H0,  P2 = H1 H1  (staged once by kh_engine_create).  Keeping
+// both A and B = A^2 in registers, every phase produces TWO Taylor terms from
+// one broadcast of the input vector:
+//     t_{2p+1} = c/(2p+1) A t_{2p},   t_{2p+2} = c^2/((2p+1)(2p+2)) B t_{2p},
+// halving the number of barriers/LDS round trips and LDS vector reads per FMA.
+// Flop count is unchanged (one matvec per term).
+//
+// Register budget (512 threads, 2 waves per SIMD, 256 VGPRs): H1, P1, P2, A, B
+// tiles (5 x 32 dwords) + the broadcast vector (32).  H0 and P0 tiles live in
+// LDS (2 x 64 KiB, lane-linear: conflict-free ds_read_b128) and are re-read
+// once per interval when A and B are rebuilt.
+#pragma once
+
+#include "kh_common.h"
+#include "kh_generic.h"
+#include "kh_tile64.h"
+
+#define KH_Q2_THREADS 512
+#define KH_Q2_TILE_ELEMS (8 * KH_Q2_THREADS)  // complex elements of one 64x64 operator, lane-linear
+
+struct KhQ2Lds {
+    cplx *h0;    // [8][512]
+    cplx *p0;    // [8][512]
+    cplx (*buf)[KH_TILE_N];  // [2][64]
+    double *red; // [2][8 waves][2]
+    double *D;   // [2][2]
+};
+
+__host__ __device__ inline size_t kh_q2_lds_bytes() {
+    return (size_t)2 * KH_Q2_TILE_ELEMS * sizeof(cplx) + 2 * KH_TILE_N * sizeof(cplx) + (2 * 8 * 2 + 4) * sizeof(double);
+}
+
+__device__ __forceinline__ KhQ2Lds kh_q2_carve(char *smem) {
+    KhQ2Lds s;
+    s.h0 = (cplx *)smem;
+    s.p0 = s.h0 + KH_Q2_TILE_ELEMS;
+    s.buf = (cplx(*)[KH_TILE_N])(s.p0 + KH_Q2_TILE_ELEMS);
+    s.red = (double *)(s.buf + 2);
+    s.D = s.red + 2 * 8 * 2;
+    return s;
+}
+
+// this lane's 8 elements of an operator (row wave*8 + lane/8, columns cg + 8 j)
+__device__ __forceinline__ void kh_q2_load_tile(const cplx *op, int N, int wave, int lane, cplx (&t)[8]) {
+    const int row = wave * 8 + (lane >> 3), cg = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int col = cg + 8 * j;
+        t[j] = (op != nullptr && row < N && col < N) ? op[(size_t)row * N + col] : c_make(0.0, 0.0);
+    }
+}
+
+__device__ __forceinline__ void kh_q2_stage_tile(const cplx *op, int N, int wave, int lane, int tid, cplx *dst) {
+    cplx t[8];
+    kh_q2_load_tile(op, N, wave, lane, t);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j * KH_Q2_THREADS + tid] = t[j];
+}
+
+// A = H0 + eps H1,  B = P0 + eps P1 + eps^2 P2  (H0, P0 from LDS)
+__device__ __forceinline__ void kh_q2_build(const KhQ2Lds &s, int tid, double eps, const cplx (&h1)[8],
+                                            const cplx (&p1)[8], const cplx (&p2)[8], cplx (&a)[8], cplx (&b)[8]) {
+    const double eps2 = eps * eps;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const cplx h0 = s.h0[j * KH_Q2_THREADS + tid];
+        const cplx q0 = s.p0[j * KH_Q2_THREADS + tid];
+        a[j].x = fma(eps, h1[j].x, h0.x);
+        a[j].y = fma(eps, h1[j].y, h0.y);
+        b[j].x = fma(eps2, p2[j].x, fma(eps, p1[j].x, q0.x));
+        b[j].y = fma(eps2, p2[j].y, fma(eps, p1[j].y, q0.y));
+    }
+}
+
+// state <- exp(f A dt) state with two Taylor terms per phase.  On entry
+// buf[cur] holds the state; on exit buf[cur] holds the new state.  f*f is real
+// (-1 in Hilbert space, +1 for Liouvillians): c2 = f^2 h^2 / (j1 j2).
+//
+// Only the B half (t_{2p+2}, the next phase's input) is reduced across lanes
+// every phase.  The odd terms t_{2p+1} = c1 A t_{2p} only enter the state sum,
+// and the sum over phases commutes with the sum over lanes: each lane keeps
+// its unreduced  sA = sum_p c1_p (A t_2p)|lane  and reduces it ONCE per
+// interval.  Order within a phase: B FMAs -> reduce -> write (what phase p+1
+// waits for), then the A FMAs under the LDS write latency, then the barrier.
+// Returns the number of matrix-vector products issued.
+__device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx (&b)[8], cplx &state,
+                                                 cplx (*buf)[KH_TILE_N], int &cur, double fre, double fim,
+                                                 double dt, int nsub, int m, int wave, int lane) {
+    const int cg = lane & 7, row = wave * 8 + (lane >> 3);
+    const double h = nsub == 1 ? dt : dt / nsub;
+    const double f2 = fre * fre - fim * fim;  // f is purely real or purely imaginary
+    const int phases = (m + 1) >> 1;
+    for (int sub = 0; sub < nsub; ++sub) {
+        cplx sA = c_make(0.0, 0.0);  // this lane's share of the odd-term sum
+        for (int ph = 0; ph < phases; ++ph) {
+            const int j1 = 2 * ph + 1;
+            const double hj1 = h * kh_inv_table[j1];
+            const cplx c1 = c_make(fre * hj1, fim * hj1);
+            const double c2 = f2 * hj1 * (h * kh_inv_table[j1 + 1]);
+            cplx xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = buf[cur][cg + 8 * j];
+            const bool last = (ph + 1 == phases);
+            cplx yb = c_make(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c_fma(yb, b[j], xv[j]);
+            yb.x = sum8(yb.x);
+            yb.y = sum8(yb.y);
+            const double t2x = c2 * yb.x, t2y = c2 * yb.y;
+            state.x += t2x;
+            state.y += t2y;
+            if (!last && cg == 0) buf[cur ^ 1][row] = c_make(t2x, t2y);
+            cplx ya = c_make(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c_fma(ya, a[j], xv[j]);
+            c_fma(sA, c1, ya);
+            if (last) {
+                state.x += sum8(sA.x);
+                state.y += sum8(sA.y);
+                if (cg == 0) buf[cur ^ 1][row] = c_make(state.x, state.y);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    return nsub * phases * 2;
+}
+
+// ---------------------------------------------------------------------------
+// plain propagation with storage (backward sweep / iteration-0 forward sweep)
+// ---------------------------------------------------------------------------
+// sq: [K*3] pointers to P0, P1, P2 of this direction's operators
+__global__ void __launch_bounds__(KH_Q2_THREADS)
+kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const double *__restrict__ pulses,
+                  const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out,
+                  int direction) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KhQ2Lds s = kh_q2_carve(smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    const int row = wave * 8 + (lane >> 3);
+    const int N = p.N, nt = p.nt;
+    double matvecs = 0.0;
+    for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
+        const cplx *const *ops_k = p.ops + (size_t)k * 2;
+        const cplx *const *sq_k = sq + (size_t)k * 3;
+        __syncthreads();  // previous objective's readers are done with LDS
+        kh_q2_stage_tile(ops_k[0], N, wave, lane, tid, s.h0);
+        kh_q2_stage_tile(sq_k[0], N, wave, lane, tid, s.p0);
+        cplx h1[8], p1[8], p2[8];
+        kh_q2_load_tile(ops_k[1], N, wave, lane, h1);
+        kh_q2_load_tile(sq_k[1], N, wave, lane, p1);
+        kh_q2_load_tile(sq_k[2], N, wave, lane, p2);
+        const double nrm0 = p.op_norms[(size_t)k * 2], nrm1 = p.op_norms[(size_t)k * 2 + 1];
+
+        cplx state = row < N ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
+        int cur = 0;
+        if (cg == 0) s.buf[0][row] = state;
+        __syncthreads();
+        if (store != nullptr && wave == 0 && lane < N)
+            store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + lane] = s.buf[0][lane];
+
+        const int n0 = direction > 0 ? 0 : nt - 2;
+        double eps_next = pulses[n0], dt_next = p.dt[n0];
+        int m_hint = 12;
+        for (int step = 0; step < nt - 1; ++step) {
+            const int n = direction > 0 ? step : nt - 2 - step;
+            const double eps = eps_next, dt = dt_next;
+            if (step + 1 < nt - 1) {
+                const int nn = direction > 0 ? n + 1 : n - 1;
+                dt_next = p.dt[nn];
+                eps_next = pulses[nn];
+            }
+            int nsub, m;
+            kh_degree_lookup((nrm0 + fabs(eps) * nrm1) * dt, p.deg_theta, p.theta_max, p.inv_theta_max, m_hint,
+                             &nsub, &m);
+            m_hint = m;
+            cplx a[8], b[8];
+            kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
+            matvecs += kh_q2_expm_action(a, b, state, s.buf, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
+            if (store != nullptr && wave == 0 && lane < N)
+                store[((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N + lane] = s.buf[cur][lane];
+        }
+        if (state_out != nullptr && wave == 0 && lane < N) state_out[(size_t)k * N + lane] = s.buf[cur][lane];
+    }
+    if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
+}
+
+// ---------------------------------------------------------------------------
+// forward sweep with sequential pulse update (optimize.py:444-508), grid == K
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(KH_Q2_THREADS)
+kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdateArgs u, KhExchange ex) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KhQ2Lds s = kh_q2_carve(smem);
+    double(*red)[8][2] = (double(*)[8][2])s.red;  // [parity][wave][re, im]
+    double(*D_sh)[2] = (double(*)[2])s.D;         // [parity][value, ok]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    const int row = wave * 8 + (lane >> 3);
+    const int N = p.N, nt = p.nt;
+    const int k = blockIdx.x;
+    double matvecs = 0.0;
+
+    const cplx *const *ops_k = p.ops + (size_t)k * 2;
+    const cplx *const *sq_k = sq + (size_t)k * 3;
+    kh_q2_stage_tile(ops_k[0], N, wave, lane, tid, s.h0);
+    kh_q2_stage_tile(sq_k[0], N, wave, lane, tid, s.p0);
+    cplx h1[8], p1[8], p2[8];
+    kh_q2_load_tile(ops_k[1], N, wave, lane, h1);  // also dH/d eps (mu.py:123-134)
+    kh_q2_load_tile(sq_k[1], N, wave, lane, p1);
+    kh_q2_load_tile(sq_k[2], N, wave, lane, p2);
+    const double nrm0 = p.op_norms[(size_t)k * 2], nrm1 = p.op_norms[(size_t)k * 2 + 1];
+    const double chi_norm = u.chi_norms[k];
+
+    cplx state = row < N ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
+    int cur = 0;
+    if (cg == 0) s.buf[0][row] = state;
+    __syncthreads();
+
+    double g_a_loc = 0.0;
+    cplx chi = c_make(0.0, 0.0);
+    auto load_chi = [&](int n) { chi = row < N ? u.chi_store[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0); };
+
+    // wave-level pieces of <chi(t_n) | H1 phi> -> red[par][wave]; phi in buf[cur]
+    auto partial_pieces = [&](int par) {
+        cplx xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = s.buf[cur][cg + 8 * j];
+        cplx y = c_make(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c_fma(y, h1[j], xv[j]);
+        y.x = sum8(y.x);
+        y.y = sum8(y.y);
+        cplx ov = c_make(0.0, 0.0);
+        if (cg == 0) c_fma_conj(ov, chi, y);
+        // Im(mu <chi|H1 phi>) needs only one real combination: reduce that, not both parts
+        const double v = sum64(u.mu_re * ov.y + u.mu_im * ov.x);
+        if (lane == 0) red[par][wave][0] = v;
+        matvecs += 1.0;
+    };
+    auto partial_total = [&](int par) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc += red[par][w][0];
+        return chi_norm * acc;
+    };
+
+    const bool emit_only = (!u.internal_exchange && u.n_begin == u.n_end);
+    if ((u.internal_exchange || emit_only) && u.n_begin < nt - 1) {
+        load_chi(u.n_begin);
+        partial_pieces(u.n_begin & 1);
+    }
+    __syncthreads();
+    if (emit_only) {
+        const double part = partial_total(u.n_begin & 1);
+        if (tid == 0) u.wg_partial[k] = part;
+        return;
+    }
+
+    double dt_next = p.dt[u.n_begin], guess_next = u.guess[u.n_begin], shape_next = u.shape[u.n_begin];
+    const double lam = u.lambda[0];
+    int m_hint = 12;
+
+    for (int n = u.n_begin; n < u.n_end; ++n) {
+        const int par = n & 1;
+        if (n + 1 < nt - 1) load_chi(n + 1);
+        // ---- cross-objective sum (optimize.py:470) ----
+        if (u.internal_exchange) {
+            if (wave == 0) {
+                double part[1] = {partial_total(par)};
+                kh_publish(ex, par, k, 1, lane, part, (unsigned)(n + 1));
+                double D[1];
+                const bool ok = kh_gather<1>(ex, par, 1, (unsigned)(n + 1), lane, D);
+                if (lane == 0) {
+                    D_sh[par][0] = D[0];
+                    D_sh[par][1] = ok ? 1.0 : 0.0;
+                }
+            }
+        } else if (tid == 0) {
+            D_sh[par][0] = u.D_in[0];
+            D_sh[par][1] = 1.0;
+        }
+        const double dt = dt_next, guess = guess_next, shape = shape_next;
+        if (n + 1 < nt - 1) {
+            dt_next = p.dt[n + 1];
+            guess_next = u.guess[n + 1];
+            shape_next = u.shape[n + 1];
+        }
+        __syncthreads();
+        if (D_sh[par][1] == 0.0) return;
+        // ---- pulse update (optimize.py:471-477) ----
+        const double d1 = D_sh[par][0];
+        const double stepw = shape / lam;
+        const double eps = guess + stepw * d1;
+        g_a_loc += stepw * (d1 * d1) * dt;
+        if (k == 0 && tid == 0) u.opt[n] = eps;
+        // ---- propagate over interval n with the updated pulse (optimize.py:479-491) ----
+        int nsub, m;
+        kh_degree_lookup((nrm0 + fabs(eps) * nrm1) * dt, p.deg_theta, p.theta_max, p.inv_theta_max, m_hint, &nsub,
+                         &m);
+        m_hint = m;
+        cplx a[8], b[8];
+        kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
+        matvecs += kh_q2_expm_action(a, b, state, s.buf, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
+        if (n + 1 < nt - 1) {
+            partial_pieces((n + 1) & 1);
+            __syncthreads();
+        }
+    }
+    if (wave == 0 && lane < N) u.phi[(size_t)k * N + lane] = s.buf[cur][lane];
+    if (!u.internal_exchange && u.n_end < nt - 1) {
+        const double part = partial_total(u.n_end & 1);
+        if (tid == 0) u.wg_partial[k] = part;
+    }
+    if (k == 0 && tid == 0) u.g_a[0] = (u.internal_exchange ? 0.0 : u.g_a[0]) + g_a_loc;
+    if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
+}
+
+// C = X Y (+ Y X if symmetrize) for N <= 64; one workgroup of 256 threads per product
+__global__ void kh_q2_product(const cplx *__restrict__ X, const cplx *__restrict__ Y, cplx *__restrict__ C, int N,
+                              int symmetrize) {
+    for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
+        const int i = idx / N, j = idx % N;
+        cplx acc = c_make(0.0, 0.0);
+        for (int q = 0; q < N; ++q) c_fma(acc, X[(size_t)i * N + q], Y[(size_t)q * N + j]);
+        if (symmetrize)
+            for (int q = 0; q < N; ++q) c_fma(acc, Y[(size_t)i * N + q], X[(size_t)q * N + j]);
+        C[idx] = acc;
+    }
+}

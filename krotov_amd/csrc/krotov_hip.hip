@@ -12,12 +12,14 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/krotov_hip.h"
 #include "kh_common.h"
 #include "kh_generic.h"
 #include "kh_tile64.h"
+#include "kh_tile64q2.h"
 
 static thread_local std::string g_last_error;
 
@@ -39,7 +41,7 @@ static int kh_fail(int code, const char *fmt, ...) {
                            __FILE__, __LINE__);                                               \
     } while (0)
 
-enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2 };
+enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3 };
 
 struct kh_engine {
     int K, N, L, nt, is_super;
@@ -53,6 +55,8 @@ struct kh_engine {
     double *d_norms = nullptr;        // [K*(1+L)]
     double *d_dt = nullptr;           // [nt-1]
     double *d_deg_theta = nullptr;    // [KH_MAX_DEGREE+1] degree thresholds for tol
+    const cplx **d_sq_fw = nullptr;   // [K*3] P0, P1, P2 of A^2 (q2 kernels), forward operators
+    const cplx **d_sq_bw = nullptr;   // [K*3] the same for the adjoint operators
     std::vector<void *> owned;        // adjoint operator copies
     // workspaces
     cplx *d_phi = nullptr;            // [K][N]
@@ -74,6 +78,7 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     switch (e->kind) {
         case KIND_TILE_RPT2: return "tile64/256";
         case KIND_TILE_RPT1: return "tile64/512";
+        case KIND_TILE_Q2: return "tile64q2/512";
         default: return "generic";
     }
 }
@@ -111,6 +116,8 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_norms);
     (void)hipFree(e->d_dt);
     (void)hipFree(e->d_deg_theta);
+    (void)hipFree((void *)e->d_sq_fw);
+    (void)hipFree((void *)e->d_sq_bw);
     (void)hipFree(e->d_phi);
     (void)hipFree(e->d_slots);
     (void)hipFree(e->d_abort);
@@ -209,9 +216,60 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
     if (tile_ok && !(force && strcmp(force, "generic") == 0)) {
         // two waves per SIMD are needed to keep the fp64 FMA pipe issuing back to back
         e->kind = KIND_TILE_RPT1;
+        if (e->L == 1) e->kind = KIND_TILE_Q2;  // two Taylor terms per phase (kh_tile64q2.h)
         if (force && strcmp(force, "tile512") == 0) e->kind = KIND_TILE_RPT1;
         if (force && strcmp(force, "tile256") == 0 && e->L <= 2) e->kind = KIND_TILE_RPT2;
         e->grid_update = e->K;
+    }
+    if (e->kind == KIND_TILE_Q2) {
+        // stage P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 once per distinct operator (pair)
+        const size_t bytes = sizeof(cplx) * (size_t)e->N * e->N;
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::vector<const cplx *> &tab = dir == 0 ? fw : bw;
+            std::vector<const cplx *> sq((size_t)e->K * 3, nullptr);
+            std::map<const void *, cplx *> p0_of, p2_of;
+            std::map<std::pair<const void *, const void *>, cplx *> p1_of;
+            for (int k = 0; k < e->K; ++k) {
+                const cplx *H0 = tab[(size_t)k * 2], *H1 = tab[(size_t)k * 2 + 1];
+                auto it0 = p0_of.find(H0);
+                if (it0 == p0_of.end()) {
+                    cplx *dst = nullptr;
+                    KH_HIP_E(hipMalloc(&dst, bytes));
+                    e->owned.push_back(dst);
+                    kh_q2_product<<<1, 256>>>(H0, H0, dst, e->N, 0);
+                    it0 = p0_of.emplace(H0, dst).first;
+                }
+                sq[(size_t)k * 3] = it0->second;
+                if (H1 == nullptr) continue;
+                auto it2 = p2_of.find(H1);
+                if (it2 == p2_of.end()) {
+                    cplx *dst = nullptr;
+                    KH_HIP_E(hipMalloc(&dst, bytes));
+                    e->owned.push_back(dst);
+                    kh_q2_product<<<1, 256>>>(H1, H1, dst, e->N, 0);
+                    it2 = p2_of.emplace(H1, dst).first;
+                }
+                sq[(size_t)k * 3 + 2] = it2->second;
+                auto key = std::make_pair((const void *)H0, (const void *)H1);
+                auto it1 = p1_of.find(key);
+                if (it1 == p1_of.end()) {
+                    cplx *dst = nullptr;
+                    KH_HIP_E(hipMalloc(&dst, bytes));
+                    e->owned.push_back(dst);
+                    kh_q2_product<<<1, 256>>>(H0, H1, dst, e->N, 1);
+                    it1 = p1_of.emplace(key, dst).first;
+                }
+                sq[(size_t)k * 3 + 1] = it1->second;
+            }
+            KH_HIP_E(hipGetLastError());
+            const cplx ***slot = dir == 0 ? &e->d_sq_fw : &e->d_sq_bw;
+            KH_HIP_E(hipMalloc((void **)slot, sizeof(cplx *) * sq.size()));
+            KH_HIP_E(hipMemcpy((void *)*slot, sq.data(), sizeof(cplx *) * sq.size(), hipMemcpyHostToDevice));
+        }
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kh_q2_lds_bytes()));
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
     }
 
     // ---- workspaces
@@ -259,7 +317,10 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     const int direction = backward ? -1 : +1;
     KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
     int rc = KH_OK;
-    if (e->kind == KIND_TILE_RPT2) {
+    if (e->kind == KIND_TILE_Q2) {
+        kh_q2_sweep_store<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(
+            p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
+    } else if (e->kind == KIND_TILE_RPT2) {
         rc = dispatch_tile_store<2>(e, p, pulses, in, store, out, direction, st);
     } else if (e->kind == KIND_TILE_RPT1) {
         rc = dispatch_tile_store<1>(e, p, pulses, in, store, out, direction, st);
@@ -306,8 +367,14 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     ex.abort_flag = e->d_abort;
     ex.G = e->grid_update;
     ex.timeout_ticks = 100000000LL;  // 1 s of the 100 MHz wall clock
+    {
+        const char *d = getenv("KH_POLL_DELAY");  // tuning knob, s_sleep units
+        ex.first_poll_delay = d ? atoi(d) : 16;  // ~0.4 us: measured best on MI355X
+    }
     if (u.internal_exchange) KH_HIP(hipMemsetAsync(e->d_slots, 0, e->slots_bytes, st));
-    if (e->kind == KIND_TILE_RPT2 || e->kind == KIND_TILE_RPT1) {
+    if (e->kind == KIND_TILE_Q2) {
+        kh_q2_forward_update<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
+    } else if (e->kind == KIND_TILE_RPT2 || e->kind == KIND_TILE_RPT1) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
         switch (e->L) {
             case 1: rpt2 ? launch_tile_update<2, 1>(e, p, u, ex, st) : launch_tile_update<1, 1>(e, p, u, ex, st); break;
