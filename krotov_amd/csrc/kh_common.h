@@ -138,6 +138,34 @@ __host__ inline void kh_build_degree_table(double tol, double *tab /*[KH_MAX_DEG
     }
 }
 
+// Per-thread cache of the bracket [tab[m-1], tab[m]] of the current degree: along
+// a smooth pulse the degree rarely changes, and the table reads (LDS, ~100
+// cycles each, dependent) would otherwise sit on every interval's critical path.
+struct KhDegreeCache {
+    int m;
+    double lo, hi;
+};
+
+__device__ __forceinline__ void kh_degree_cached(double theta, const double *tab, double theta_max,
+                                                 double inv_theta_max, KhDegreeCache &c, int *s_out, int *m_out) {
+    int s = 1;
+    double th = theta;
+    if (theta > theta_max) {
+        s = (int)ceil(theta * inv_theta_max);
+        th = theta / s;
+    }
+    if (!(th > c.lo && th <= c.hi)) {
+        int m = c.m < 1 ? 1 : c.m;
+        while (m > 1 && th <= tab[m - 1]) --m;
+        while (m < KH_MAX_DEGREE && th > tab[m]) ++m;
+        c.m = m;
+        c.lo = m > 1 ? tab[m - 1] : -1.0;
+        c.hi = m < KH_MAX_DEGREE ? tab[m] : 1e300;
+    }
+    *s_out = s;
+    *m_out = c.m;
+}
+
 __device__ __forceinline__ void kh_degree_lookup(double theta, const double *__restrict__ tab, double theta_max,
                                                  double inv_theta_max, int hint, int *s_out, int *m_out) {
     int s = 1;

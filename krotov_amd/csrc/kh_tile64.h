@@ -68,13 +68,14 @@ __device__ __forceinline__ void kh_tile_matvec(const cplx (&a)[RPT][8], const cp
 // One barrier per matrix-vector product.  Returns the matvec count.
 template <int RPT>
 __device__ __forceinline__ int kh_tile_expm_action(const cplx (&a)[RPT][8], cplx (&state)[RPT],
-                                                   cplx (*buf)[KH_TILE_N], int &cur, double fre, double fim,
+                                                   cplx (*buf)[KH_TILE_N], const double *inv, int &cur, double fre,
+                                                   double fim,
                                                    double dt, int nsub, int m, int wave, int lane) {
     const int cg = lane & 7;
     const double h = nsub == 1 ? dt : dt / nsub;
     for (int sub = 0; sub < nsub; ++sub) {
         for (int j = 1; j <= m; ++j) {
-            const double hj = h * kh_inv_table[j];
+            const double hj = h * inv[j];  // LDS copy: an SMEM load here would drain lgkmcnt every term
             const cplx coef = c_make(fre * hj, fim * hj);
             cplx y[RPT];
             kh_tile_matvec<RPT>(a, buf[cur], cg, y);
@@ -119,7 +120,13 @@ __global__ void __launch_bounds__(512 / RPT)
 kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx *__restrict__ state_in,
                     cplx *__restrict__ store, cplx *__restrict__ state_out, int direction) {
     __shared__ __attribute__((aligned(16))) cplx buf[2][KH_TILE_N];
+    __shared__ __attribute__((aligned(16))) double inv_sh[KH_MAX_DEGREE + 2];
+    __shared__ __attribute__((aligned(16))) double deg_sh[KH_MAX_DEGREE + 2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    if (tid <= KH_MAX_DEGREE) {
+        inv_sh[tid] = tid ? 1.0 / tid : 0.0;
+        deg_sh[tid] = p.deg_theta[tid];
+    }
     const int N = p.N, nt = p.nt;
     double matvecs = 0.0;
     for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
@@ -172,11 +179,11 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
                 for (int l = 0; l < LT; ++l) eps_next[l] = pulses[(size_t)l * (nt - 1) + nn];
             }
             int nsub, m;
-            kh_degree_lookup(theta * dt, p.deg_theta, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
+            kh_degree_lookup(theta * dt, deg_sh, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
             m_hint = m;
             cplx a[RPT][8];
             kh_tile_build_generator<RPT, LT>(h, eps, a);
-            matvecs += kh_tile_expm_action<RPT>(a, state, buf, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
+            matvecs += kh_tile_expm_action<RPT>(a, state, buf, inv_sh, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
             // buf[cur] now holds the new state: stream it to HBM, one coalesced 1 KiB store
             if (store != nullptr && wave == 0 && lane < N)
                 store[((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N + lane] = buf[cur][lane];
@@ -200,7 +207,13 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     __shared__ __attribute__((aligned(16))) cplx buf[2][KH_TILE_N];
     __shared__ __attribute__((aligned(16))) double red[2][WAVES][LT][2];  // double-buffered on interval parity
     __shared__ __attribute__((aligned(16))) double D_sh[2][LT + 1];       // [LT] = ok flag
+    __shared__ __attribute__((aligned(16))) double inv_sh[KH_MAX_DEGREE + 2];
+    __shared__ __attribute__((aligned(16))) double deg_sh[KH_MAX_DEGREE + 2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    if (tid <= KH_MAX_DEGREE) {
+        inv_sh[tid] = tid ? 1.0 / tid : 0.0;
+        deg_sh[tid] = p.deg_theta[tid];
+    }
     const int N = p.N, nt = p.nt;
     const int k = blockIdx.x;
     double matvecs = 0.0;
@@ -356,11 +369,11 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         }
         // ---- propagate over interval n with the updated pulse (optimize.py:479-491) ----
         int nsub, m;
-        kh_degree_lookup(theta * dt, p.deg_theta, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
+        kh_degree_lookup(theta * dt, deg_sh, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         cplx a[RPT][8];
         kh_tile_build_generator<RPT, LT>(h, eps, a);
-        matvecs += kh_tile_expm_action<RPT>(a, state, buf, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
+        matvecs += kh_tile_expm_action<RPT>(a, state, buf, inv_sh, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
         // ---- partial sums of the next interval (state is in buf[cur], barrier passed) ----
         if (n + 1 < nt - 1) {
             partial_pieces((n + 1) & 1);

@@ -32,10 +32,13 @@ struct KhQ2Lds {
     cplx (*buf)[KH_TILE_N];  // [2][64]
     double *red; // [2][8 waves][2]
     double *D;   // [2][2]
+    double2 *inv2;  // [KH_MAX_DEGREE/2] {1/(2p+1), 1/(2p+2)} (LDS copy: no SMEM loads in the phase loop)
+    double *deg;    // [KH_MAX_DEGREE+1] copy of the degree-threshold table
 };
 
 __host__ __device__ inline size_t kh_q2_lds_bytes() {
-    return (size_t)2 * KH_Q2_TILE_ELEMS * sizeof(cplx) + 2 * KH_TILE_N * sizeof(cplx) + (2 * 8 * 2 + 4) * sizeof(double);
+    return (size_t)2 * KH_Q2_TILE_ELEMS * sizeof(cplx) + 2 * KH_TILE_N * sizeof(cplx) + (2 * 8 * 2 + 4) * sizeof(double) +
+           (KH_MAX_DEGREE / 2) * sizeof(double2) + (KH_MAX_DEGREE + 2) * sizeof(double);
 }
 
 __device__ __forceinline__ KhQ2Lds kh_q2_carve(char *smem) {
@@ -45,6 +48,8 @@ __device__ __forceinline__ KhQ2Lds kh_q2_carve(char *smem) {
     s.buf = (cplx(*)[KH_TILE_N])(s.p0 + KH_Q2_TILE_ELEMS);
     s.red = (double *)(s.buf + 2);
     s.D = s.red + 2 * 8 * 2;
+    s.inv2 = (double2 *)(s.D + 4);
+    s.deg = (double *)(s.inv2 + KH_MAX_DEGREE / 2);
     return s;
 }
 
@@ -92,7 +97,8 @@ __device__ __forceinline__ void kh_q2_build(const KhQ2Lds &s, int tid, double ep
 // waits for), then the A FMAs under the LDS write latency, then the barrier.
 // Returns the number of matrix-vector products issued.
 __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx (&b)[8], cplx &state,
-                                                 cplx (*buf)[KH_TILE_N], int &cur, double fre, double fim,
+                                                 cplx (*buf)[KH_TILE_N], const double2 *inv2, int &cur,
+                                                 cplx *store_in, int N, double fre, double fim,
                                                  double dt, int nsub, int m, int wave, int lane) {
     const int cg = lane & 7, row = wave * 8 + (lane >> 3);
     const double h = nsub == 1 ? dt : dt / nsub;
@@ -101,13 +107,18 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
     for (int sub = 0; sub < nsub; ++sub) {
         cplx sA = c_make(0.0, 0.0);  // this lane's share of the odd-term sum
         for (int ph = 0; ph < phases; ++ph) {
-            const int j1 = 2 * ph + 1;
-            const double hj1 = h * kh_inv_table[j1];
+            const double2 iv = inv2[ph];
+            const double hj1 = h * iv.x;
             const cplx c1 = c_make(fre * hj1, fim * hj1);
-            const double c2 = f2 * hj1 * (h * kh_inv_table[j1 + 1]);
+            const double c2 = f2 * hj1 * (h * iv.y);
             cplx xv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[j] = buf[cur][cg + 8 * j];
+            if (store_in != nullptr && sub == 0 && ph == 0 && wave == 0 && lane < N) {
+                // the interval's incoming state goes to HBM from here: one extra LDS read
+                // issued with the vector reads, one fire-and-forget coalesced store
+                store_in[lane] = buf[cur][lane];
+            }
             const bool last = (ph + 1 == phases);
             cplx yb = c_make(0.0, 0.0);
 #pragma unroll
@@ -145,6 +156,8 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KhQ2Lds s = kh_q2_carve(smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / (2 * tid + 2));
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     const int row = wave * 8 + (lane >> 3);
     const int N = p.N, nt = p.nt;
     double matvecs = 0.0;
@@ -164,12 +177,12 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
         int cur = 0;
         if (cg == 0) s.buf[0][row] = state;
         __syncthreads();
-        if (store != nullptr && wave == 0 && lane < N)
-            store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + lane] = s.buf[0][lane];
-
+        // the state entering interval `step` is stored from inside its first phase
+        // (index n for the forward direction, n+1 for the backward one); the last
+        // state is stored after the loop.
         const int n0 = direction > 0 ? 0 : nt - 2;
         double eps_next = pulses[n0], dt_next = p.dt[n0];
-        int m_hint = 12;
+        KhDegreeCache dc = {12, 1.0, 0.0};
         for (int step = 0; step < nt - 1; ++step) {
             const int n = direction > 0 ? step : nt - 2 - step;
             const double eps = eps_next, dt = dt_next;
@@ -179,15 +192,16 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
                 eps_next = pulses[nn];
             }
             int nsub, m;
-            kh_degree_lookup((nrm0 + fabs(eps) * nrm1) * dt, p.deg_theta, p.theta_max, p.inv_theta_max, m_hint,
-                             &nsub, &m);
-            m_hint = m;
+            kh_degree_cached((nrm0 + fabs(eps) * nrm1) * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
             cplx a[8], b[8];
             kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
-            matvecs += kh_q2_expm_action(a, b, state, s.buf, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
-            if (store != nullptr && wave == 0 && lane < N)
-                store[((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N + lane] = s.buf[cur][lane];
+            cplx *store_in =
+                store == nullptr ? nullptr : store + ((size_t)k * nt + (direction > 0 ? n : n + 1)) * N;
+            matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, store_in, N, p.fre, p.fim, dt, nsub, m,
+                                         wave, lane);
         }
+        if (store != nullptr && wave == 0 && lane < N)
+            store[((size_t)k * nt + (direction > 0 ? nt - 1 : 0)) * N + lane] = s.buf[cur][lane];
         if (state_out != nullptr && wave == 0 && lane < N) state_out[(size_t)k * N + lane] = s.buf[cur][lane];
     }
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
@@ -203,6 +217,8 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     double(*red)[8][2] = (double(*)[8][2])s.red;  // [parity][wave][re, im]
     double(*D_sh)[2] = (double(*)[2])s.D;         // [parity][value, ok]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / (2 * tid + 2));
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     const int row = wave * 8 + (lane >> 3);
     const int N = p.N, nt = p.nt;
     const int k = blockIdx.x;
@@ -266,7 +282,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
 
     double dt_next = p.dt[u.n_begin], guess_next = u.guess[u.n_begin], shape_next = u.shape[u.n_begin];
     const double lam = u.lambda[0];
-    int m_hint = 12;
+    KhDegreeCache dc = {12, 1.0, 0.0};
 
     for (int n = u.n_begin; n < u.n_end; ++n) {
         const int par = n & 1;
@@ -303,12 +319,11 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         if (k == 0 && tid == 0) u.opt[n] = eps;
         // ---- propagate over interval n with the updated pulse (optimize.py:479-491) ----
         int nsub, m;
-        kh_degree_lookup((nrm0 + fabs(eps) * nrm1) * dt, p.deg_theta, p.theta_max, p.inv_theta_max, m_hint, &nsub,
-                         &m);
-        m_hint = m;
+        kh_degree_cached((nrm0 + fabs(eps) * nrm1) * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
         cplx a[8], b[8];
         kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
-        matvecs += kh_q2_expm_action(a, b, state, s.buf, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
+        matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, nullptr, N, p.fre, p.fim, dt, nsub, m, wave,
+                                     lane);
         if (n + 1 < nt - 1) {
             partial_pieces((n + 1) & 1);
             __syncthreads();

@@ -20,6 +20,7 @@
 #include "kh_generic.h"
 #include "kh_tile64.h"
 #include "kh_tile64q2.h"
+#include "kh_tile64ws.h"
 
 static thread_local std::string g_last_error;
 
@@ -41,7 +42,7 @@ static int kh_fail(int code, const char *fmt, ...) {
                            __FILE__, __LINE__);                                               \
     } while (0)
 
-enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3 };
+enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3, KIND_TILE_WS = 4 };
 
 struct kh_engine {
     int K, N, L, nt, is_super;
@@ -79,6 +80,7 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
         case KIND_TILE_RPT2: return "tile64/256";
         case KIND_TILE_RPT1: return "tile64/512";
         case KIND_TILE_Q2: return "tile64q2/512";
+        case KIND_TILE_WS: return "tile64ws/512";
         default: return "generic";
     }
 }
@@ -217,11 +219,13 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
         // two waves per SIMD are needed to keep the fp64 FMA pipe issuing back to back
         e->kind = KIND_TILE_RPT1;
         if (e->L == 1) e->kind = KIND_TILE_Q2;  // two Taylor terms per phase (kh_tile64q2.h)
+        // wave-specialised variant (kh_tile64ws.h): same speed today, kept selectable for tuning
+        if (force && strcmp(force, "ws") == 0 && e->L == 1) e->kind = KIND_TILE_WS;
         if (force && strcmp(force, "tile512") == 0) e->kind = KIND_TILE_RPT1;
         if (force && strcmp(force, "tile256") == 0 && e->L <= 2) e->kind = KIND_TILE_RPT2;
         e->grid_update = e->K;
     }
-    if (e->kind == KIND_TILE_Q2) {
+    if (e->kind == KIND_TILE_Q2 || e->kind == KIND_TILE_WS) {
         // stage P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 once per distinct operator (pair)
         const size_t bytes = sizeof(cplx) * (size_t)e->N * e->N;
         for (int dir = 0; dir < 2; ++dir) {
@@ -270,6 +274,10 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
                                      (int)kh_q2_lds_bytes()));
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_ws_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kh_ws_lds_bytes()));
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_ws_forward_update,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_ws_lds_bytes()));
     }
 
     // ---- workspaces
@@ -317,7 +325,10 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     const int direction = backward ? -1 : +1;
     KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
     int rc = KH_OK;
-    if (e->kind == KIND_TILE_Q2) {
+    if (e->kind == KIND_TILE_WS) {
+        kh_ws_sweep_store<<<e->K, KH_WS_THREADS, kh_ws_lds_bytes(), st>>>(
+            p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
+    } else if (e->kind == KIND_TILE_Q2) {
         kh_q2_sweep_store<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(
             p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
     } else if (e->kind == KIND_TILE_RPT2) {
@@ -372,7 +383,9 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         ex.first_poll_delay = d ? atoi(d) : 16;  // ~0.4 us: measured best on MI355X
     }
     if (u.internal_exchange) KH_HIP(hipMemsetAsync(e->d_slots, 0, e->slots_bytes, st));
-    if (e->kind == KIND_TILE_Q2) {
+    if (e->kind == KIND_TILE_WS) {
+        kh_ws_forward_update<<<e->K, KH_WS_THREADS, kh_ws_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
+    } else if (e->kind == KIND_TILE_Q2) {
         kh_q2_forward_update<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_TILE_RPT2 || e->kind == KIND_TILE_RPT1) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
@@ -527,5 +540,10 @@ extern "C" int kh_last_stats(kh_engine *e, double stats[4]) {
     stats[1] = e->last_intervals;
     stats[2] = e->last_wgs;
     stats[3] = 0.0;
+#ifdef KH_TIMING
+    stats[1] = d[1];
+    stats[2] = d[2];
+    stats[3] = d[3];
+#endif
     return KH_OK;
 }
