@@ -311,3 +311,62 @@ def test_full_size_c5_properties():
         tau1 = eng.tau(spec.target, a[1]).cpu().numpy()
         assert np.abs(tau1 - g['tau_vals'][1]).max() < 1e-10
     eng.close()
+
+
+def _two_rank_worker(rank, world, port, queue):
+    """One of two ranks sharing the single GPU (gloo moves the CUDA tensors through
+    the host): the real multi-rank device path -- kh_update_begin/step/end with an
+    all-reduce per interval, tau / state all-gathers -- minus RCCL itself."""
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import krotov_amd as ka
+        from krotov_amd import configs as cfg
+
+        spec = cfg.config_c5(K=6, N=64, nt=61, L=1)
+        spec.chi = 'sm'
+        objectives, pulse_options = cfg.spec_to_objectives(spec, ka)
+        res = ka.optimize_pulses(
+            objectives, pulse_options, spec.tlist, propagator=ka.propagators.expm,
+            chi_constructor=ka.functionals.chis_sm, iter_stop=2, store_all_pulses=True,
+            process_group=dist.group.WORLD)
+        queue.put((rank, np.array(res.all_pulses), np.array(res.tau_vals)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sharded_on_one_gpu():
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([queue.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    spec = configs.config_c5(K=6, N=64, nt=61, L=1)
+    spec.chi = 'sm'
+    ref = oracle_optimize(spec, 2)
+    for _, pulses, tau in out:
+        assert np.abs(pulses - ref['all_pulses']).max() < 1e-12
+        assert np.abs(tau - ref['tau_vals']).max() < 1e-12
+    assert np.array_equal(out[0][1], out[1][1])
