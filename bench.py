@@ -48,6 +48,25 @@ def algorithmic_bytes(K, N, nt, L):
     return chi + ops + 8.0 * L * (nt - 1), chi + ops + 3 * 8.0 * L * (nt - 1)
 
 
+def pmc_traffic(kernel, K_loc, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/pmc_latest.json, written by scripts/collect_profiles.sh: separate
+    FETCH_SIZE and WRITE_SIZE passes, KB units, FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md), or None when no matching record exists."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None
+    cfg = rec.get('config', {})
+    if (cfg.get('K'), cfg.get('N'), cfg.get('nt'), cfg.get('L')) != (K_loc, args.N, args.nt, args.L):
+        return None
+    k = rec.get('kernels', {}).get(kernel)
+    if not k:
+        return None
+    return (2.0 * k['FETCH_SIZE_KB'] + k['WRITE_SIZE_KB']) * 1024.0
+
+
 def cpu_baseline(args):
     """Oracle in reference-structured mode on a bounded sample of the workload."""
     from krotov_amd import configs
@@ -156,6 +175,11 @@ def main():
     eng = _engine_mod.LAST_ENGINE()
     times = eng.kernel_times_ms(reset=True)
     stats = eng.stats()
+    kernel_names = {
+        'tile64q2/512': ('kh_q2_forward_update', 'kh_q2_sweep_store'),
+        'tile64ws/512': ('kh_ws_forward_update', 'kh_ws_sweep_store'),
+        'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
+    }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
 
     if rank == 0:
         K_loc = eng.K
@@ -194,12 +218,12 @@ def main():
             },
             'roofline': {
                 'bound': 'mfma',
-                'kernel': 'kh_tile_forward_update' if dominant == 'update' else 'kh_tile_sweep_store',
+                'kernel': kernel_names[0] if dominant == 'update' else kernel_names[1],
                 'achieved': f_dom / t_dom / 1e12,
                 'peak': FP64_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': f_dom / t_dom / 1e12 / FP64_PEAK_TFLOPS,
-                'traffic': None,
+                'traffic': pmc_traffic(kernel_names[0] if dominant == 'update' else kernel_names[1], K_loc, args),
                 'note': 'fp64 vector-FMA bound (complex matrix-vector products cannot use MFMA tiles); the fp64 '
                         'vector peak equals the fp64 MFMA peak on MI355X (78.6 TFLOP/s). Algorithmic flops: '
                         'K*(nt-1)*(8 N^2 * 14 [+ L*(8 N^2 + 8 N) for the update sweep]).',

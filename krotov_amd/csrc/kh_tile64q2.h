@@ -284,9 +284,16 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     const double lam = u.lambda[0];
     KhDegreeCache dc = {12, 1.0, 0.0};
 
+#ifdef KH_TIMING
+    long long t_ex = 0, t_prop = 0, t_part = 0;
+    const long long t_all0 = clock64();
+#endif
     for (int n = u.n_begin; n < u.n_end; ++n) {
         const int par = n & 1;
         if (n + 1 < nt - 1) load_chi(n + 1);
+#ifdef KH_TIMING
+        const long long tq0 = clock64();
+#endif
         // ---- cross-objective sum (optimize.py:470) ----
         if (u.internal_exchange) {
             if (wave == 0) {
@@ -310,6 +317,10 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
             shape_next = u.shape[n + 1];
         }
         __syncthreads();
+#ifdef KH_TIMING
+        const long long tq1 = clock64();
+        t_ex += tq1 - tq0;
+#endif
         if (D_sh[par][1] == 0.0) return;
         // ---- pulse update (optimize.py:471-477) ----
         const double d1 = D_sh[par][0];
@@ -324,11 +335,25 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
         matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, nullptr, N, p.fre, p.fim, dt, nsub, m, wave,
                                      lane);
+#ifdef KH_TIMING
+        const long long tq2 = clock64();
+        t_prop += tq2 - tq1;
+#endif
         if (n + 1 < nt - 1) {
             partial_pieces((n + 1) & 1);
             __syncthreads();
         }
+#ifdef KH_TIMING
+        t_part += clock64() - tq2;
+#endif
     }
+#ifdef KH_TIMING
+    if (tid == 0 && k == 0 && p.stats != nullptr) {
+        p.stats[1] = (double)t_ex;
+        p.stats[2] = (double)t_prop;
+        p.stats[3] = (double)t_part;
+    }
+#endif
     if (wave == 0 && lane < N) u.phi[(size_t)k * N + lane] = s.buf[cur][lane];
     if (!u.internal_exchange && u.n_end < nt - 1) {
         const double part = partial_total(u.n_end & 1);

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag> (scripts/collect_profiles.sh) into the committed summaries under profiles/<tag>/
+and refresh profiles/pmc_latest.json (read by bench.py for roofline.traffic)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = os.path.join(ROOT, 'gpurun_out', tag)
+dst = os.path.join(ROOT, 'profiles', tag)
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, 'stats', 'b_kernel_stats.csv'), os.path.join(dst, 'kernel_stats.csv'))
+shutil.copy(os.path.join(src, 'bench_n1.json'), os.path.join(dst, 'bench_n1.json'))
+bench = json.loads(open(os.path.join(src, 'bench_n1.json')).read().strip())
+summary = {}
+for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_lds'):
+    path = os.path.join(src, sub, 'b_counter_collection.csv')
+    if not os.path.exists(path):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        agg[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
+    for kern, ctrs in agg.items():
+        if not kern.startswith('kh_'):
+            continue
+        for c, v in ctrs.items():
+            summary.setdefault(kern, {})[c] = {'avg_per_launch': sum(v) / len(v), 'launches': len(v)}
+json.dump(summary, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
+cfg = bench['config']
+latest = {
+    'source': 'profiles/%s/pmc_summary.json' % tag,
+    'config': {'K': cfg['objectives'], 'N': cfg['N'], 'nt': cfg['time_steps'] + 1, 'L': cfg['controls']},
+    'kernels': {},
+}
+for kern, c in summary.items():
+    if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+        latest['kernels'][kern] = {'FETCH_SIZE_KB': c['FETCH_SIZE']['avg_per_launch'],
+                                   'WRITE_SIZE_KB': c['WRITE_SIZE']['avg_per_launch']}
+json.dump(latest, open(os.path.join(ROOT, 'profiles', 'pmc_latest.json'), 'w'), indent=1, sort_keys=True)
+print(json.dumps(latest, indent=1))
+for kern, c in summary.items():
+    if 'SQ_WAVE_CYCLES' in c:
+        wc = c['SQ_WAVE_CYCLES']['avg_per_launch']
+        print(kern, {k: round(100 * v['avg_per_launch'] / wc, 1) for k, v in c.items() if k.startswith('SQ_') and k != 'SQ_WAVE_CYCLES'})
