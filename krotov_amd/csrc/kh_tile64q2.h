@@ -363,10 +363,10 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }
 
-// C = X Y (+ Y X if symmetrize) for N <= 64; one workgroup of 256 threads per product
+// C = X Y (+ Y X if symmetrize) for N <= 64; grid-stride over the N*N outputs (engine set-up only)
 __global__ void kh_q2_product(const cplx *__restrict__ X, const cplx *__restrict__ Y, cplx *__restrict__ C, int N,
                               int symmetrize) {
-    for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N * N; idx += gridDim.x * blockDim.x) {
         const int i = idx / N, j = idx % N;
         cplx acc = c_make(0.0, 0.0);
         for (int q = 0; q < N; ++q) c_fma(acc, X[(size_t)i * N + q], Y[(size_t)q * N + j]);

@@ -240,7 +240,7 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
                     cplx *dst = nullptr;
                     KH_HIP_E(hipMalloc(&dst, bytes));
                     e->owned.push_back(dst);
-                    kh_q2_product<<<1, 256>>>(H0, H0, dst, e->N, 0);
+                    kh_q2_product<<<16, 256>>>(H0, H0, dst, e->N, 0);
                     it0 = p0_of.emplace(H0, dst).first;
                 }
                 sq[(size_t)k * 3] = it0->second;
@@ -250,7 +250,7 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
                     cplx *dst = nullptr;
                     KH_HIP_E(hipMalloc(&dst, bytes));
                     e->owned.push_back(dst);
-                    kh_q2_product<<<1, 256>>>(H1, H1, dst, e->N, 0);
+                    kh_q2_product<<<16, 256>>>(H1, H1, dst, e->N, 0);
                     it2 = p2_of.emplace(H1, dst).first;
                 }
                 sq[(size_t)k * 3 + 2] = it2->second;
@@ -260,7 +260,7 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
                     cplx *dst = nullptr;
                     KH_HIP_E(hipMalloc(&dst, bytes));
                     e->owned.push_back(dst);
-                    kh_q2_product<<<1, 256>>>(H0, H1, dst, e->N, 1);
+                    kh_q2_product<<<16, 256>>>(H0, H1, dst, e->N, 1);
                     it1 = p1_of.emplace(key, dst).first;
                 }
                 sq[(size_t)k * 3 + 1] = it1->second;
