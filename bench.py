@@ -109,6 +109,8 @@ def main():
     ap.add_argument('--distinct', action='store_true', help='every objective gets its own random drift')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='run the multi-GPU code path (stepwise sweep + RCCL all-reduce per interval) even on 1 rank')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--cpu-procs', type=int, default=64)
     args = ap.parse_args()
@@ -124,8 +126,14 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     torch.cuda.set_device(local_rank)
     group = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
 
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -246,7 +254,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out))
-    if world > 1:
+    if group is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

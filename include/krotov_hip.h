@@ -163,6 +163,17 @@ int kh_update_step(kh_engine *engine, int32_t n, const double *D_dev,
                    const double *shape_dev, const double *lambda_dev,
                    double *opt_dev, double *g_a_dev, double *partial_dev,
                    void *stream);
+/* kh_update_step with the interval index kept in device memory (*n_dev is read
+ * by the kernels and incremented after each call): consecutive calls are then
+ * byte-identical launches, so a block of intervals -- including the caller's
+ * RCCL all-reduce between them -- can be captured once in a HIP graph and
+ * replayed, which removes the per-interval host launch cost of the sharded
+ * sweep.  Calls past the last interval are no-ops. */
+int kh_update_step_dev(kh_engine *engine, int32_t *n_dev, const double *D_dev,
+                       const kh_cdouble *chi_store_dev, const double *chi_norms_dev,
+                       const double *shape_dev, const double *lambda_dev,
+                       double *opt_dev, double *g_a_dev, double *partial_dev,
+                       void *stream);
 int kh_update_end(kh_engine *engine, kh_cdouble *psi_T_dev, void *stream);
 
 /* tau_k = <target_k | psi_k(T)> (optimize.py:316-322, 502-508;

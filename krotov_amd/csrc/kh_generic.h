@@ -168,6 +168,8 @@ struct KhUpdateArgs {
     const double *D_in;         // [L] all-reduced sums (stepwise mode)
     int n_begin, n_end;         // intervals [n_begin, n_end) are applied; partials of n_end are emitted
     int internal_exchange;      // 1: gather in-kernel (single launch over the grid)
+    const int *n_dev;           // stepwise mode under graph replay: the interval index lives in device memory
+                                // (read here, incremented by kh_reduce_partials), so every replay is identical
 };
 
 // Im( mu * norm_k * <chi_k(t_n) | H_l phi_k> ) summed over this workgroup's
@@ -220,6 +222,11 @@ __device__ __forceinline__ void kh_gen_partials(const KhSweepArgs &p, const KhUp
 __global__ void __launch_bounds__(KH_GEN_THREADS)
 kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (u.n_dev != nullptr) {
+        u.n_begin = *u.n_dev;
+        u.n_end = u.n_begin + 1;
+        if (u.n_begin >= p.nt - 1) return;  // replay past the last interval: nothing to do
+    }
     const KhGenLds s = kh_gen_carve(smem, p.N);
     double *D_sh = s.D;  // all LDS in the dynamic region (keeps its base 16-byte aligned)
     int *ok_sh_p = s.ok;
@@ -298,13 +305,15 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
 }
 
 // sum of per-workgroup partials in workgroup order -> out[L]  (stepwise mode)
-__global__ void kh_reduce_partials(const double *__restrict__ wg_partial, int G, int L, double *__restrict__ out) {
+__global__ void kh_reduce_partials(const double *__restrict__ wg_partial, int G, int L, double *__restrict__ out,
+                                   int *n_dev) {
     const int l = threadIdx.x;
     if (l < L) {
         double acc = 0.0;
         for (int g = 0; g < G; ++g) acc += wg_partial[(size_t)g * L + l];
         out[l] = acc;
     }
+    if (n_dev != nullptr && threadIdx.x == 0) *n_dev += 1;
 }
 
 // tau_k = <target_k | psi_k>  (second_order.py:69-83); one wave per objective

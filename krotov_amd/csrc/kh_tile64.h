@@ -203,6 +203,11 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
 template <int RPT, int LT>
 __global__ void __launch_bounds__(512 / RPT)
 kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
+    if (u.n_dev != nullptr) {  // graph-replayed stepwise mode: interval index from device memory
+        u.n_begin = *u.n_dev;
+        u.n_end = u.n_begin + 1;
+        if (u.n_begin >= p.nt - 1) return;
+    }
     constexpr int WAVES = KhTile<RPT>::WAVES;
     __shared__ __attribute__((aligned(16))) cplx buf[2][KH_TILE_N];
     __shared__ __attribute__((aligned(16))) double red[2][WAVES][LT][2];  // double-buffered on interval parity

@@ -212,6 +212,11 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(KH_Q2_THREADS)
 kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdateArgs u, KhExchange ex) {
+    if (u.n_dev != nullptr) {  // graph-replayed stepwise mode: interval index from device memory
+        u.n_begin = *u.n_dev;
+        u.n_end = u.n_begin + 1;
+        if (u.n_begin >= p.nt - 1) return;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KhQ2Lds s = kh_q2_carve(smem);
     double(*red)[8][2] = (double(*)[8][2])s.red;  // [parity][wave][re, im]

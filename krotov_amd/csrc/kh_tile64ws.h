@@ -333,6 +333,11 @@ kh_ws_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(KH_WS_THREADS)
 kh_ws_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdateArgs u, KhExchange ex) {
+    if (u.n_dev != nullptr) {  // graph-replayed stepwise mode: interval index from device memory
+        u.n_begin = *u.n_dev;
+        u.n_end = u.n_begin + 1;
+        if (u.n_begin >= p.nt - 1) return;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KhWsLds s = kh_ws_carve(smem);
     double(*red)[4] = (double(*)[4])s.red;  // [parity][A wave]

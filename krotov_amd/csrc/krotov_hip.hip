@@ -423,6 +423,7 @@ static KhUpdateArgs update_args(kh_engine *e, const kh_cdouble *chi_store, const
     u.g_a = g_a;
     u.wg_partial = e->d_wg_partial;
     u.D_in = nullptr;
+    u.n_dev = nullptr;
     u.n_begin = 0;
     u.n_end = e->nt - 1;
     u.internal_exchange = 1;
@@ -471,7 +472,7 @@ extern "C" int kh_update_begin(kh_engine *e, const kh_cdouble *chi_store_dev, co
     u.n_begin = u.n_end = 0;
     int rc = launch_update(e, u, st);
     if (rc != KH_OK) return rc;
-    kh_reduce_partials<<<1, 64, 0, st>>>(e->d_wg_partial, e->grid_update, e->L, partial_dev);
+    kh_reduce_partials<<<1, 64, 0, st>>>(e->d_wg_partial, e->grid_update, e->L, partial_dev, nullptr);
     KH_HIP(hipGetLastError());
     return KH_OK;
 }
@@ -495,9 +496,33 @@ extern "C" int kh_update_step(kh_engine *e, int32_t n, const double *D_dev, cons
     int rc = launch_update(e, u, st);
     if (rc != KH_OK) return rc;
     if (n + 1 < e->nt - 1) {
-        kh_reduce_partials<<<1, 64, 0, st>>>(e->d_wg_partial, e->grid_update, e->L, partial_dev);
+        kh_reduce_partials<<<1, 64, 0, st>>>(e->d_wg_partial, e->grid_update, e->L, partial_dev, nullptr);
         KH_HIP(hipGetLastError());
     }
+    return KH_OK;
+}
+
+extern "C" int kh_update_step_dev(kh_engine *e, int32_t *n_dev, const double *D_dev,
+                                  const kh_cdouble *chi_store_dev, const double *chi_norms_dev,
+                                  const double *shape_dev, const double *lambda_dev, double *opt_dev,
+                                  double *g_a_dev, double *partial_dev, void *stream) {
+    if (e == nullptr || n_dev == nullptr || D_dev == nullptr || chi_store_dev == nullptr ||
+        chi_norms_dev == nullptr || shape_dev == nullptr || lambda_dev == nullptr || opt_dev == nullptr ||
+        g_a_dev == nullptr || partial_dev == nullptr)
+        return kh_fail(KH_ERR_INVALID, "null argument");
+    if (e->guess_dev == nullptr) return kh_fail(KH_ERR_INVALID, "kh_update_begin was not called");
+    hipStream_t st = (hipStream_t)stream;
+    KhUpdateArgs u =
+        update_args(e, chi_store_dev, chi_norms_dev, e->guess_dev, shape_dev, lambda_dev, opt_dev, g_a_dev);
+    u.internal_exchange = 0;
+    u.D_in = D_dev;
+    u.n_dev = n_dev;
+    u.n_begin = 0;  // overridden on the device
+    u.n_end = 1;
+    int rc = launch_update(e, u, st);
+    if (rc != KH_OK) return rc;
+    kh_reduce_partials<<<1, 64, 0, st>>>(e->d_wg_partial, e->grid_update, e->L, partial_dev, n_dev);
+    KH_HIP(hipGetLastError());
     return KH_OK;
 }
 

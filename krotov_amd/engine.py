@@ -221,22 +221,55 @@ class HipKrotovEngine:
                 self._stream()))
         return opt, psi_T, g_a
 
-    def forward_update_sharded(self, chi_store, chi_norms, init, guess, shape, lambdas, all_reduce):
+    def forward_update_sharded(self, chi_store, chi_norms, init, guess, shape, lambdas, all_reduce,
+                               graph_chunk=None):
         """The same sweep cut at the cross-objective sum: after every interval
         ``all_reduce(partial)`` (in place, L doubles on the device) must return
         the sum over all ranks -- ``torch.distributed.all_reduce`` on the
-        ``nccl`` (= RCCL over xGMI) backend."""
-        chi_store = self._c(chi_store, (self.K, self.nt, self.N))
-        chi_norms = self._f(chi_norms, (self.K,))
-        init = self._c(init, (self.K, self.N))
-        guess = self._f(guess, (self.L, self.nt - 1))
-        shape = self._f(shape, (self.L, self.nt - 1))
-        lambdas = self._f(lambdas, (self.L,))
-        opt = torch.empty_like(guess)
-        psi_T = torch.empty_like(init)
-        g_a = torch.empty((self.L,), dtype=torch.float64, device=self.device)
-        partial = torch.zeros((self.L,), dtype=torch.float64, device=self.device)
+        ``nccl`` (= RCCL over xGMI) backend.
+
+        With ``graph_chunk`` > 0 (default: env ``KH_GRAPH_CHUNK``, 64) a block of
+        that many intervals -- all-reduce + ``kh_update_step_dev`` each -- is
+        captured once as a HIP graph and replayed, so the host issues one graph
+        launch per block instead of three launches per interval.  The interval
+        index lives in device memory, which makes every replay identical; replays
+        past the last interval are no-ops.  ``graph_chunk=0`` runs the plain loop.
+        """
+        if graph_chunk is None:
+            graph_chunk = int(os.environ.get('KH_GRAPH_CHUNK', '64'))
+        nt, L, K, N = self.nt, self.L, self.K, self.N
+        # persistent buffers: stable addresses let the captured graph be reused
+        b = getattr(self, '_sh', None)
+        if b is None:
+            c128, f64, dev = torch.complex128, torch.float64, self.device
+            b = self._sh = dict(
+                chi_norms=torch.empty((K,), dtype=f64, device=dev),
+                init=torch.empty((K, N), dtype=c128, device=dev),
+                guess=torch.empty((L, nt - 1), dtype=f64, device=dev),
+                shape=torch.empty((L, nt - 1), dtype=f64, device=dev),
+                lambdas=torch.empty((L,), dtype=f64, device=dev),
+                opt=torch.empty((L, nt - 1), dtype=f64, device=dev),
+                psi_T=torch.empty((K, N), dtype=c128, device=dev),
+                g_a=torch.empty((L,), dtype=f64, device=dev),
+                partial=torch.zeros((L,), dtype=f64, device=dev),
+                n_dev=torch.zeros((1,), dtype=torch.int32, device=dev),
+                graph=None, graph_key=None,
+            )
+        chi_store = self._c(chi_store, (K, nt, N))
+        b['chi_norms'].copy_(self._f(chi_norms, (K,)))
+        b['init'].copy_(self._c(init, (K, N)))
+        b['guess'].copy_(self._f(guess, (L, nt - 1)))
+        b['shape'].copy_(self._f(shape, (L, nt - 1)))
+        b['lambdas'].copy_(self._f(lambdas, (L,)))
+        chi_norms, init, guess, shape, lambdas = b['chi_norms'], b['init'], b['guess'], b['shape'], b['lambdas']
+        opt, psi_T, g_a, partial, n_dev = b['opt'], b['psi_T'], b['g_a'], b['partial'], b['n_dev']
         lib, h, eng = self._lib, self._handle, self
+
+        def step_dev():
+            _lib.check(lib.kh_update_step_dev(
+                h, n_dev.data_ptr(), partial.data_ptr(), chi_store.data_ptr(), chi_norms.data_ptr(),
+                shape.data_ptr(), lambdas.data_ptr(), opt.data_ptr(), g_a.data_ptr(), partial.data_ptr(),
+                eng._stream()))
 
         class _Stepper:
             """kh_update_begin / kh_update_step / kh_update_end of the C ABI."""
@@ -257,8 +290,41 @@ class HipKrotovEngine:
                 _lib.check(lib.kh_update_end(h, psi_T.data_ptr(), eng._stream()))
 
         with self._timed('update'):
-            run_update_loop(_Stepper(), self.nt - 1, all_reduce)
-        return opt, psi_T, g_a
+            done = False
+            if graph_chunk > 0 and nt - 1 > 2 * graph_chunk:
+                try:
+                    stepper = _Stepper()
+                    stepper.begin()
+                    n_dev.zero_()
+                    # first interval eagerly: also warms up the communicator outside the capture
+                    all_reduce(partial)
+                    step_dev()
+                    key = (chi_store.data_ptr(), graph_chunk)
+                    if b['graph'] is None or b['graph_key'] != key:
+                        torch.cuda.synchronize(self.device)
+                        g = torch.cuda.CUDAGraph()
+                        # the capture itself runs the block once, but on a scratch copy of
+                        # nothing: captured work is only recorded, not executed
+                        with torch.cuda.graph(g):
+                            for _ in range(graph_chunk):
+                                all_reduce(partial)
+                                step_dev()
+                        b['graph'], b['graph_key'] = g, key
+                    replays = (nt - 2 + graph_chunk - 1) // graph_chunk
+                    for _ in range(replays):
+                        b['graph'].replay()
+                    stepper.end()
+                    done = True
+                except Exception as exc:  # capture unsupported: plain loop below
+                    import warnings
+
+                    warnings.warn("krotov_amd: graph capture of the sharded sweep failed (%s); "
+                                  "falling back to per-interval launches" % exc)
+                    b['graph'] = None
+                    torch.cuda.synchronize(self.device)
+            if not done:
+                run_update_loop(_Stepper(), nt - 1, all_reduce)
+        return opt.clone(), psi_T.clone(), g_a.clone()
 
     def tau(self, targets, psi_T):
         targets = self._c(targets, (self.K, self.N))

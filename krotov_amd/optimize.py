@@ -461,7 +461,7 @@ class _HipBackend:
         self.chi_store = eng.backward(chi_loc, guess, out=self.chi_store)
         shapes = eng.dev(np.array(shape_arrays, dtype=np.float64).reshape(self.L, self.nt - 1), t.float64)
         lambdas = eng.dev(np.asarray(lambda_vals, dtype=np.float64), t.float64)
-        if self.world == 1:
+        if self.group is None:
             opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
         else:
             def all_reduce(x):
