@@ -307,13 +307,15 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
 // sum of per-workgroup partials in workgroup order -> out[L]  (stepwise mode)
 __global__ void kh_reduce_partials(const double *__restrict__ wg_partial, int G, int L, double *__restrict__ out,
                                    int *n_dev) {
-    const int l = threadIdx.x;
-    if (l < L) {
+    // one wave; fixed order: lane-strided partial sums in workgroup order, then the sum64 tree
+    const int lane = threadIdx.x;
+    for (int l = 0; l < L; ++l) {
         double acc = 0.0;
-        for (int g = 0; g < G; ++g) acc += wg_partial[(size_t)g * L + l];
-        out[l] = acc;
+        for (int g = lane; g < G; g += 64) acc += wg_partial[(size_t)g * L + l];
+        acc = sum64(acc);
+        if (lane == 0) out[l] = acc;
     }
-    if (n_dev != nullptr && threadIdx.x == 0) *n_dev += 1;
+    if (n_dev != nullptr && lane == 0) *n_dev += 1;
 }
 
 // tau_k = <target_k | psi_k>  (second_order.py:69-83); one wave per objective

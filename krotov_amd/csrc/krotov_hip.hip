@@ -383,11 +383,15 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         ex.first_poll_delay = d ? atoi(d) : 16;  // ~0.4 us: measured best on MI355X
     }
     if (u.internal_exchange) KH_HIP(hipMemsetAsync(e->d_slots, 0, e->slots_bytes, st));
-    if (e->kind == KIND_TILE_WS) {
+    // One launch per interval (sharded sweep): every launch re-stages its operator
+    // tiles, so the q2/ws kernels (5 tiles, 320 KiB per objective) lose to the
+    // plain tile kernel (2 tiles) there -- measured 39 vs ~20 us per interval.
+    const bool stepwise = !u.internal_exchange;
+    if (e->kind == KIND_TILE_WS && !stepwise) {
         kh_ws_forward_update<<<e->K, KH_WS_THREADS, kh_ws_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
-    } else if (e->kind == KIND_TILE_Q2) {
+    } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
         kh_q2_forward_update<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
-    } else if (e->kind == KIND_TILE_RPT2 || e->kind == KIND_TILE_RPT1) {
+    } else if (e->kind != KIND_GENERIC) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
         switch (e->L) {
             case 1: rpt2 ? launch_tile_update<2, 1>(e, p, u, ex, st) : launch_tile_update<1, 1>(e, p, u, ex, st); break;

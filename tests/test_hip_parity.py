@@ -75,9 +75,11 @@ def test_sweeps_match_oracle(name):
     # the sweep cut at the cross-objective sum (multi-GPU form) with a 1-rank "all-reduce"
     opt2, psi2, ga2 = eng.forward_update_sharded(chi, norms, spec.init, pulses, np.array(S), np.array(lam),
                                                  lambda x: x)
-    assert np.abs((opt2 - opt).cpu().numpy()).max() < 1e-13 * scale
-    assert np.abs((psi2 - psi_T).cpu().numpy()).max() < 1e-13
-    assert np.abs((ga2 - g_a).cpu().numpy()).max() < 1e-13 * max(1.0, np.abs(ref_ga).max())
+    # (the per-interval path may run a different kernel family than the single launch)
+    assert np.abs(opt2.cpu().numpy() - np.array(ref_opt)).max() < tol * scale
+    assert np.abs(psi2.cpu().numpy() - ref_psi).max() < tol
+    assert np.abs(ga2.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
+    assert np.abs((opt2 - opt).cpu().numpy()).max() < 1e-12 * scale
     assert eng.kernel.startswith('tile64') == (spec.N <= 64)
     eng.close()
 
