@@ -54,7 +54,30 @@ __device__ __forceinline__ cplx kh_gen_row_dot(const cplx *const *ops_k, const d
     cplx sum = c_make(0.0, 0.0);
     if (row < N) {
         const size_t off = (size_t)row * N;
-        for (int c = c16; c < N; c += 16) {
+        // four column chunks per trip, all operator loads issued before the FMAs:
+        // with one load in flight per lane the row stream is latency-bound (~20 GB/s per CU)
+        int c = c16;
+        for (; c + 48 < N; c += 64) {
+            cplx a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = ops_k[0][off + c + 16 * q];
+            for (int l = 0; l < L; ++l) {
+                const cplx *h = ops_k[1 + l];
+                if (h != nullptr) {
+                    cplx v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = h[off + c + 16 * q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a[q].x = fma(eps[l], v[q].x, a[q].x);
+                        a[q].y = fma(eps[l], v[q].y, a[q].y);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c_fma(sum, a[q], x[c + 16 * q]);
+        }
+        for (; c < N; c += 16) {
             cplx a = ops_k[0][off + c];
             for (int l = 0; l < L; ++l) {
                 const cplx *h = ops_k[1 + l];

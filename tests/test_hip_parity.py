@@ -372,3 +372,47 @@ def test_two_ranks_sharded_on_one_gpu():
         assert np.abs(pulses - ref['all_pulses']).max() < 1e-12
         assert np.abs(tau - ref['tau_vals']).max() < 1e-12
     assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_full_size_c4_liouville_properties():
+    """BASELINE config 4 as concretised in SURVEY.md 8d: transmon in Liouville space,
+    400-dim vec(rho), 16 density-matrix objectives sharing one operator list, 1000
+    intervals (generic kernels).  No reference golden exists for Liouville-space expm
+    (SURVEY.md 8c): checked by properties -- trace preservation, <chi|rho> conservation
+    between the adjoint (backward) and forward sweeps -- and against the oracle on a
+    short prefix of the time grid."""
+    import torch
+
+    spec = configs.config_c4()
+    assert spec.N == 400 and spec.K == 16
+    eng = _engine(spec)
+    assert eng.kernel == 'generic'
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    fw_T, states = eng.forward(pulses, spec.init, store=True)
+    d = 20
+    tr = states.reshape(spec.K, len(spec.tlist), d, d).diagonal(dim1=2, dim2=3).sum(-1)  # tr rho_k(t_n)
+    tr0 = torch.as_tensor(np.array([np.trace(v.reshape(d, d, order='F')) for v in spec.init]), device=tr.device)
+    assert float((tr - tr0[:, None]).abs().max()) < 1e-11
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    chi = eng.backward(chi_T, pulses)
+    ov = (chi.conj() * states).sum(dim=2)
+    assert float((ov - ov[:, -1:]).abs().max()) < 1e-10
+    opt, psi_T, g_a = eng.forward_update(chi, np.full(spec.K, 1.0 / (2 * spec.K)), spec.init, pulses,
+                                         np.array(S), np.array(lam))
+    eng.check()
+    assert np.all(np.isfinite(opt.cpu().numpy()))
+    eng.close()
+    # oracle on the first 6 intervals, 2 objectives
+    short = configs.config_c4(nt=1001)
+    short.tlist = short.tlist[:7]
+    sub = configs.ProblemSpec(name='c4_prefix', H0=short.H0[:2], Hc=short.Hc[:2], is_super=True,
+                              init=short.init[[1, 5]], target=short.target[[1, 5]], tlist=short.tlist,
+                              controls=short.controls, update_shape=short.update_shape, lambda_a=1.0, chi='re')
+    prob = spec_to_oracle(sub)
+    eng2 = _engine(sub)
+    p6 = pulses[:, :6]
+    got = eng2.forward(p6, sub.init).cpu().numpy()
+    want = ko.forward_propagation(prob, [p6[0]])
+    assert np.abs(got - want).max() < 1e-11
+    eng2.close()
