@@ -416,3 +416,43 @@ def test_full_size_c4_liouville_properties():
     want = ko.forward_propagation(prob, [p6[0]])
     assert np.abs(got - want).max() < 1e-11
     eng2.close()
+
+
+@pytest.mark.parametrize('kernel', ['q2', 'ws', 'tile512', 'generic'])
+def test_nonuniform_grid_and_large_step_norms(kernel, monkeypatch):
+    """Non-uniform dt and ||H dt|| up to ~4 (several Taylor sub-steps per interval,
+    degrees changing along the grid), non-Hermitian drift: every kernel family."""
+    from krotov_amd.engine import HipKrotovEngine
+
+    monkeypatch.setenv('KH_KERNEL', kernel)
+    rng = np.random.default_rng(11)
+    K, N, nt = 3, 10, 25
+    tl = np.cumsum(np.concatenate([[0.0], rng.uniform(0.02, 0.4, nt - 1)]))
+    ops = []
+    for k in range(K):
+        H0 = configs.herm(rng, N, 9.0) - 0.05j * np.diag(rng.uniform(0, 1, N))  # non-Hermitian (decay)
+        H1 = configs.herm(rng, N, 2.0)
+        ops.append([H0, H1])
+    init = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
+    init /= np.linalg.norm(init, axis=1)[:, None]
+    target = np.roll(init, 1, axis=1)
+    prob = ko.OracleProblem(ops, init, target, tl)
+    gp = [0.8 * np.cos(np.arange(nt - 1) * 0.7)]
+    S = [np.linspace(0.2, 1.0, nt - 1)]
+    eng = HipKrotovEngine(ops, np.diff(tl))
+    fw_T, states = eng.forward(np.array(gp), init, store=True)
+    ref_T, ref_states = ko.forward_propagation(prob, gp, store=True)
+    assert np.abs(states.cpu().numpy() - ref_states).max() < 1e-11
+    chi_T = target / np.linalg.norm(target, axis=1)[:, None]
+    norms = np.array([0.3, 0.5, 0.2])
+    chi = eng.backward(chi_T, np.array(gp))
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-11
+    opt, psi_T, g_a = eng.forward_update(chi, norms, init, np.array(gp), np.array(S), np.array([3.0]))
+    eng.check()
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, [3.0])
+    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-11
+    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-11
+    assert np.abs(g_a.cpu().numpy() - ref_ga).max() < 1e-11
+    assert eng.stats()['matvecs'] > 0
+    eng.close()
