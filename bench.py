@@ -221,7 +221,10 @@ def main():
                                 K_total, ' (%d per GPU)' % args.K if world > 1 else '', args.N, args.nt - 1, args.L),
                 'objectives': K_total, 'N': args.N, 'time_steps': args.nt - 1, 'controls': args.L,
                 'distinct_drifts': bool(args.distinct),
-                'parallelism': 'objectives sharded over %d GPU(s); 1 all-reduce of L doubles per time step' % world,
+                'parallelism': 'objectives sharded over %d GPU(s); per time step the L update sums cross the '
+                               'GPUs %s' % (world, 'inside the persistent kernel (peer-mapped windows over xGMI)'
+                                            if getattr(eng, '_p2p_used', False) else
+                                            ('by one RCCL all-reduce' if world > 1 or args.force_dist else '(single GPU: in-kernel exchange)')),
                 'kernel': eng.kernel,
             },
             'roofline': {

@@ -176,6 +176,31 @@ int kh_update_step_dev(kh_engine *engine, int32_t *n_dev, const double *D_dev,
                        void *stream);
 int kh_update_end(kh_engine *engine, kh_cdouble *psi_T_dev, void *stream);
 
+/* Device-side exchange across the GPUs of one node (objectives sharded over
+ * `world` ranks, one per GPU): with it, kh_forward_update stays ONE persistent
+ * launch per rank -- after the in-GPU stage the per-GPU sums of every interval
+ * are exchanged through peer-mapped windows (xGMI) with system-scope atomics,
+ * summed in rank order (bit-identical on every GPU), instead of one RCCL
+ * all-reduce plus kernel launches per interval.
+ *
+ *   kh_p2p_create_window : allocate this rank's window (fine-grained device
+ *                          memory) and return its 64-byte IPC handle
+ *   kh_p2p_open_peers    : map all ranks' windows from the all-gathered
+ *                          handles ([world][64] bytes, rank order)
+ *   kh_p2p_selftest      : collective; runs `rounds` in-kernel exchanges and
+ *                          verifies the totals.  Only after it succeeded on
+ *                          every rank (the caller checks that) does
+ *                          kh_forward_update use the cross-GPU stage.
+ *   kh_p2p_disable       : fall back to the per-interval path (kh_update_*)
+ * Every rank must call kh_forward_update the same number of times (epochs
+ * advance in lock step) and synchronise with the others between sweeps (the
+ * per-iteration all-gather of tau does). */
+int kh_p2p_create_window(kh_engine *engine, int32_t world, int32_t rank,
+                         unsigned char *ipc_handle_out /* [64] */);
+int kh_p2p_open_peers(kh_engine *engine, const unsigned char *all_handles);
+int kh_p2p_selftest(kh_engine *engine, int32_t rounds, void *stream);
+int kh_p2p_disable(kh_engine *engine);
+
 /* tau_k = <target_k | psi_k(T)> (optimize.py:316-322, 502-508;
  * second_order.py:69-83).  targets_dev, psi_T_dev [K][N]; tau_dev [K]. */
 int kh_tau(kh_engine *engine, const kh_cdouble *targets_dev,

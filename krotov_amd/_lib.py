@@ -46,6 +46,10 @@ SYMBOLS = {
     'kh_update_step': (ctypes.c_int, [_P, ctypes.c_int32] + [_P] * 9),
     'kh_update_step_dev': (ctypes.c_int, [_P] * 11),
     'kh_update_end': (ctypes.c_int, [_P, _P, _P]),
+    'kh_p2p_create_window': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
+    'kh_p2p_open_peers': (ctypes.c_int, [_P, _P]),
+    'kh_p2p_selftest': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'kh_p2p_disable': (ctypes.c_int, [_P]),
     'kh_tau': (ctypes.c_int, [_P, _P, _P, _P, _P]),
     'kh_check': (ctypes.c_int, [_P]),
     'kh_last_stats': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double)]),

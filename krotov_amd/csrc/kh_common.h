@@ -202,6 +202,19 @@ struct KhExchange {
     int G;                  // workgroups taking part
     int first_poll_delay;   // s_sleep units (64 cycles) between publishing and the first poll
     long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
+    // ---- second stage across GPUs (objectives sharded over ranks; world == 1: unused) ----
+    // Every rank owns a window [2][world][L][2] of 8-byte granules in fine-grained
+    // device memory; peer_windows[r] is rank r's window mapped into this process
+    // (xGMI peer access; peer_windows[rank] is the local one).  After the in-GPU
+    // stage the leader workgroup stores its GPU's sum into slot [parity][rank] of
+    // EVERY window (system-scope atomics), and every workgroup polls its own GPU's
+    // window and adds the `world` values in rank order -- all GPUs obtain the
+    // bit-identical total.  Epochs are monotonic across sweeps (epoch_base), so
+    // the windows never need clearing.
+    kh_u64 *const *peer_windows;  // device array [world]
+    kh_u64 *my_window;
+    int world, rank;
+    unsigned int epoch_base;
 };
 
 // Called by (at least) the first 2*L lanes of one wave: one 8-byte store each.
@@ -276,6 +289,77 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
             acc += __longlong_as_double((long long)bits);
         }
         out[l] = (l < L) ? sum64(acc) : 0.0;
+    }
+    return true;
+}
+
+// ---- cross-GPU stage -------------------------------------------------------
+__device__ __forceinline__ void kh_p2p_publish(const KhExchange &ex, int parity, int L, int lane,
+                                               const double *values, unsigned int epoch) {
+    // lane -> (peer, l, half): world * L * 2 <= 64 stores, one per lane
+    const int per_peer = 2 * L;
+    if (lane < ex.world * per_peer) {
+        const int peer = lane / per_peer, rem = lane % per_peer, l = rem >> 1, half_sel = rem & 1;
+        const kh_u64 bits = (kh_u64)__double_as_longlong(values[l]);
+        const kh_u64 half = half_sel ? (bits & 0xffffffffull) : (bits >> 32);
+        kh_u64 *g = ex.peer_windows[peer] + (((size_t)parity * ex.world + ex.rank) * L + l) * 2 + half_sel;
+        __hip_atomic_store(g, ((kh_u64)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// one full wave; lane -> (rank r, control l) for lane < world * L; total in rank order
+template <int MAXL>
+__device__ __forceinline__ bool kh_p2p_gather(const KhExchange &ex, int parity, int L, unsigned int epoch, int lane,
+                                              double (&out)[MAXL]) {
+    const int pairs = ex.world * L;
+    const bool active = lane < pairs;
+    const kh_u64 *g = ex.my_window + ((size_t)parity * ex.world * L + (active ? lane : 0)) * 2;
+    kh_u64 a = 0, b = 0;
+    const long long t0 = wall_clock64();
+    unsigned int spins = 0;
+    for (;;) {
+        if (active) {
+            a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const bool ok = !active || (((unsigned int)(a >> 32) == epoch) && ((unsigned int)(b >> 32) == epoch));
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0) {
+            const bool gave_up =
+                (wall_clock64() - t0 > ex.timeout_ticks) ||
+                (__hip_atomic_load(ex.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+            if (__any(gave_up)) {
+                if (lane == 0) __hip_atomic_store(ex.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    const kh_u64 bits = ((a & 0xffffffffull) << 32) | (b & 0xffffffffull);
+    const double v = active ? __longlong_as_double((long long)bits) : 0.0;
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+        double acc = 0.0;
+        if (l < L)
+            for (int r = 0; r < ex.world; ++r) acc += readlane_f64(v, r * L + l);
+        out[l] = acc;
+    }
+    return true;
+}
+
+// The whole per-interval exchange, called by ONE full wave of every workgroup:
+// publish this workgroup's partial sums, gather the GPU's total, and (sharded
+// runs) exchange the GPU totals across ranks.  `n` = interval index.
+template <int MAXL>
+__device__ __forceinline__ bool kh_exchange(const KhExchange &ex, int n, int wg, int L, int lane,
+                                            const double *part, double (&out)[MAXL]) {
+    const int parity = n & 1;
+    kh_publish(ex, parity, wg, L, lane, part, (unsigned)(n + 1));
+    if (!kh_gather<MAXL>(ex, parity, L, (unsigned)(n + 1), lane, out)) return false;
+    if (ex.world > 1) {
+        const unsigned int epoch = ex.epoch_base + (unsigned)(n + 1);
+        if (wg == 0) kh_p2p_publish(ex, parity, L, lane, out, epoch);
+        if (!kh_p2p_gather<MAXL>(ex, parity, L, epoch, lane, out)) return false;
     }
     return true;
 }

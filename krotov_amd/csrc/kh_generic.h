@@ -276,9 +276,8 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         // ---- cross-objective sum D_l (optimize.py:470) ----
         if (u.internal_exchange) {
             if (wave == 0) {
-                kh_publish(ex, n & 1, blockIdx.x, L, lane, part, (unsigned)(n + 1));
                 double D[KH_MAX_L];
-                const bool ok = kh_gather<KH_MAX_L>(ex, n & 1, L, (unsigned)(n + 1), lane, D);
+                const bool ok = kh_exchange<KH_MAX_L>(ex, n, blockIdx.x, L, lane, part, D);
                 if (lane == 0) {
                     *ok_sh_p = ok ? 1 : 0;
                     for (int l = 0; l < L; ++l) D_sh[l] = D[l];

@@ -326,9 +326,8 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
             if (wave == 0) {
                 double part[LT];
                 partial_total(par, part);
-                kh_publish(ex, par, k, LT, lane, part, (unsigned)(n + 1));
                 double D[LT];
-                const bool ok = kh_gather<LT>(ex, par, LT, (unsigned)(n + 1), lane, D);
+                const bool ok = kh_exchange<LT>(ex, n, k, LT, lane, part, D);
                 if (lane == 0) {
 #pragma unroll
                     for (int l = 0; l < LT; ++l) D_sh[par][l] = D[l];

@@ -303,9 +303,8 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         if (u.internal_exchange) {
             if (wave == 0) {
                 double part[1] = {partial_total(par)};
-                kh_publish(ex, par, k, 1, lane, part, (unsigned)(n + 1));
                 double D[1];
-                const bool ok = kh_gather<1>(ex, par, 1, (unsigned)(n + 1), lane, D);
+                const bool ok = kh_exchange<1>(ex, n, k, 1, lane, part, D);
                 if (lane == 0) {
                     D_sh[par][0] = D[0];
                     D_sh[par][1] = ok ? 1.0 : 0.0;

@@ -66,6 +66,14 @@ struct kh_engine {
     double *d_stats = nullptr;        // [4]
     double *d_wg_partial = nullptr;   // [G][L]
     const double *guess_dev = nullptr;  // remembered by kh_update_begin
+    // cross-GPU exchange (kh_p2p_*): objectives sharded over `p2p_world` ranks
+    int p2p_world = 1, p2p_rank = 0;
+    kh_u64 *p2p_window = nullptr;            // this rank's window (fine-grained device memory)
+    size_t p2p_window_bytes = 0;
+    std::vector<void *> p2p_opened;          // peer windows opened through IPC
+    kh_u64 **d_p2p_peers = nullptr;          // device array [world] of window pointers
+    unsigned int p2p_epoch_base = 0;         // advanced by nt per sweep: epochs never repeat
+    bool p2p_ready = false;
     size_t slots_bytes = 0;
     double last_intervals = 0, last_wgs = 0;
 };
@@ -125,6 +133,9 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_abort);
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_wg_partial);
+    for (void *ptr : e->p2p_opened) (void)hipIpcCloseMemHandle(ptr);
+    (void)hipFree(e->p2p_window);
+    (void)hipFree((void *)e->d_p2p_peers);
     delete e;
 }
 
@@ -378,6 +389,11 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     ex.abort_flag = e->d_abort;
     ex.G = e->grid_update;
     ex.timeout_ticks = 100000000LL;  // 1 s of the 100 MHz wall clock
+    ex.peer_windows = e->d_p2p_peers;
+    ex.my_window = e->p2p_window;
+    ex.world = (e->p2p_ready && u.internal_exchange) ? e->p2p_world : 1;
+    ex.rank = e->p2p_rank;
+    ex.epoch_base = e->p2p_epoch_base;
     {
         const char *d = getenv("KH_POLL_DELAY");  // tuning knob, s_sleep units
         ex.first_poll_delay = d ? atoi(d) : 16;  // ~0.4 us: measured best on MI355X
@@ -451,6 +467,7 @@ extern "C" int kh_forward_update(kh_engine *e, const kh_cdouble *chi_store_dev, 
         update_args(e, chi_store_dev, chi_norms_dev, guess_dev, shape_dev, lambda_dev, opt_dev, g_a_dev);
     int rc = launch_update(e, u, st);
     if (rc != KH_OK) return rc;
+    if (e->p2p_ready) e->p2p_epoch_base += (unsigned int)e->nt;  // every rank advances identically
     KH_HIP(hipMemcpyAsync(psi_T_dev, e->d_phi, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice, st));
     e->last_intervals = e->nt - 1;
     e->last_wgs = e->grid_update;
@@ -535,6 +552,126 @@ extern "C" int kh_update_end(kh_engine *e, kh_cdouble *psi_T_dev, void *stream) 
     KH_HIP(hipMemcpyAsync(psi_T_dev, e->d_phi, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice,
                           (hipStream_t)stream));
     e->guess_dev = nullptr;
+    return KH_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// cross-GPU exchange windows (sharded objectives, one rank per GPU)
+// ---------------------------------------------------------------------------
+
+// in-kernel ping-pong over the windows: every rank publishes (rank + round) and
+// must read the same total from its own window
+__global__ void kh_p2p_selftest_kernel(KhExchange ex, int L, int rounds, unsigned int epoch0, int *result) {
+    const int lane = threadIdx.x;
+    int ok_all = 1;
+    for (int r = 0; r < rounds; ++r) {
+        double vals[KH_MAX_L], out[KH_MAX_L];
+        for (int l = 0; l < KH_MAX_L; ++l) vals[l] = (double)(ex.rank + 1) * (l + 1) + 0.25 * r;
+        const unsigned int epoch = epoch0 + (unsigned)r + 1u;
+        kh_p2p_publish(ex, r & 1, L, lane, vals, epoch);
+        if (!kh_p2p_gather<KH_MAX_L>(ex, r & 1, L, epoch, lane, out)) {
+            ok_all = 0;
+            break;
+        }
+        for (int l = 0; l < L; ++l) {
+            const double want = (double)(ex.world * (ex.world + 1) / 2) * (l + 1) + 0.25 * r * ex.world;
+            if (out[l] != want) ok_all = 0;
+        }
+    }
+    if (lane == 0) *result = ok_all;
+}
+
+extern "C" int kh_p2p_create_window(kh_engine *e, int32_t world, int32_t rank, unsigned char *ipc_handle_out) {
+    if (e == nullptr || ipc_handle_out == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return kh_fail(KH_ERR_INVALID, "bad world/rank %d/%d", rank, world);
+    const int Lx = e->L > 0 ? e->L : 1;
+    if (world * Lx * 2 > 64) return kh_fail(KH_ERR_UNSUPPORTED, "world * L = %d exceeds the 32 exchange lanes", world * Lx);
+    if (e->p2p_window != nullptr) return kh_fail(KH_ERR_INVALID, "window already created");
+    e->p2p_world = world;
+    e->p2p_rank = rank;
+    e->p2p_window_bytes = sizeof(kh_u64) * 2 * (size_t)world * Lx * 2;
+    if (e->p2p_window_bytes < 4096) e->p2p_window_bytes = 4096;
+    void *ptr = nullptr;
+    // fine-grained (uncached, system-coherent) device memory for cross-GPU visibility
+    hipError_t err = hipExtMallocWithFlags(&ptr, e->p2p_window_bytes, hipDeviceMallocFinegrained);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        KH_HIP(hipMalloc(&ptr, e->p2p_window_bytes));
+    }
+    e->p2p_window = (kh_u64 *)ptr;
+    KH_HIP(hipMemset(ptr, 0, e->p2p_window_bytes));
+    hipIpcMemHandle_t h;
+    KH_HIP(hipIpcGetMemHandle(&h, ptr));
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the ABI's 64 bytes");
+    memset(ipc_handle_out, 0, 64);
+    memcpy(ipc_handle_out, &h, sizeof(h));
+    KH_HIP(hipDeviceSynchronize());
+    return KH_OK;
+}
+
+extern "C" int kh_p2p_open_peers(kh_engine *e, const unsigned char *all_handles) {
+    if (e == nullptr || all_handles == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
+    if (e->p2p_window == nullptr) return kh_fail(KH_ERR_INVALID, "kh_p2p_create_window was not called");
+    std::vector<kh_u64 *> peers(e->p2p_world, nullptr);
+    for (int r = 0; r < e->p2p_world; ++r) {
+        if (r == e->p2p_rank) {
+            peers[r] = e->p2p_window;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, all_handles + (size_t)r * 64, sizeof(h));
+        void *ptr = nullptr;
+        KH_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        e->p2p_opened.push_back(ptr);
+        peers[r] = (kh_u64 *)ptr;
+    }
+    KH_HIP(hipMalloc((void **)&e->d_p2p_peers, sizeof(kh_u64 *) * e->p2p_world));
+    KH_HIP(hipMemcpy((void *)e->d_p2p_peers, peers.data(), sizeof(kh_u64 *) * e->p2p_world, hipMemcpyHostToDevice));
+    return KH_OK;
+}
+
+// Collective over all ranks (each calls it at the same point): returns KH_OK when
+// `rounds` in-kernel exchanges over the windows produced the expected totals on
+// THIS rank; the caller combines the verdicts of all ranks.  Marks the engine
+// ready for the cross-GPU update sweep on success.
+extern "C" int kh_p2p_selftest(kh_engine *e, int32_t rounds, void *stream) {
+    if (e == nullptr) return kh_fail(KH_ERR_INVALID, "null engine");
+    if (e->d_p2p_peers == nullptr) return kh_fail(KH_ERR_INVALID, "kh_p2p_open_peers was not called");
+    hipStream_t st = (hipStream_t)stream;
+    KhExchange ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.abort_flag = e->d_abort;
+    ex.timeout_ticks = 20000000LL;  // 0.2 s
+    ex.peer_windows = e->d_p2p_peers;
+    ex.my_window = e->p2p_window;
+    ex.world = e->p2p_world;
+    ex.rank = e->p2p_rank;
+    int *d_res = nullptr;
+    KH_HIP(hipMalloc(&d_res, sizeof(int)));
+    KH_HIP(hipMemsetAsync(d_res, 0, sizeof(int), st));
+    const int Lx = e->L > 0 ? e->L : 1;
+    kh_p2p_selftest_kernel<<<1, 64, 0, st>>>(ex, Lx, rounds, e->p2p_epoch_base, d_res);
+    KH_HIP(hipGetLastError());
+    e->p2p_epoch_base += (unsigned int)rounds + 1u;
+    int res = 0;
+    KH_HIP(hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, st));
+    KH_HIP(hipStreamSynchronize(st));
+    (void)hipFree(d_res);
+    unsigned int flag = 0;
+    KH_HIP(hipMemcpy(&flag, e->d_abort, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag != 0) KH_HIP(hipMemset(e->d_abort, 0, sizeof(flag)));
+    if (res != 1 || flag != 0) {
+        e->p2p_ready = false;
+        return kh_fail(KH_ERR_TIMEOUT, "cross-GPU exchange self-test failed on rank %d", e->p2p_rank);
+    }
+    e->p2p_ready = true;
+    return KH_OK;
+}
+
+extern "C" int kh_p2p_disable(kh_engine *e) {
+    if (e == nullptr) return kh_fail(KH_ERR_INVALID, "null engine");
+    e->p2p_ready = false;
     return KH_OK;
 }
 

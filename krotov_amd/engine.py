@@ -326,6 +326,47 @@ class HipKrotovEngine:
                 run_update_loop(_Stepper(), nt - 1, all_reduce)
         return opt.clone(), psi_T.clone(), g_a.clone()
 
+    def enable_p2p(self, group, rounds=8):
+        """Set up the device-side exchange across the ranks of ``group`` (one per
+        GPU of a node): allocate this rank's window, trade IPC handles, map the
+        peers' windows and run the in-kernel self-test.  Collective.  Returns True
+        when EVERY rank passed -- only then does :meth:`forward_update` include the
+        cross-GPU stage; otherwise the engine stays on the per-interval RCCL path."""
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        lib, h = self._lib, self._handle
+
+        def all_ok(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return bool(flag.item())
+
+        handle = (ctypes.c_ubyte * 64)()
+        ok = lib.kh_p2p_create_window(h, world, rank, handle) == 0
+        mine = torch.tensor(list(bytes(handle)), dtype=torch.uint8, device=self.device)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)
+        if not all_ok(ok):
+            lib.kh_p2p_disable(h)
+            return False
+        blob = b''.join(bytes(g.cpu().numpy().tobytes()) for g in gathered)
+        buf = (ctypes.c_ubyte * len(blob)).from_buffer_copy(blob)
+        ok = lib.kh_p2p_open_peers(h, buf) == 0
+        if not all_ok(ok):
+            lib.kh_p2p_disable(h)
+            return False
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=group)  # every window exists and is mapped before anyone writes
+        ok = lib.kh_p2p_selftest(h, int(rounds), self._stream()) == 0
+        if not all_ok(ok):
+            lib.kh_p2p_disable(h)
+            return False
+        return True
+
+    def disable_p2p(self):
+        self._lib.kh_p2p_disable(self._handle)
+
     def tau(self, targets, psi_T):
         targets = self._c(targets, (self.K, self.N))
         psi_T = self._c(psi_T, (self.K, self.N))

@@ -27,6 +27,7 @@ built library, requesting it raises.
 import copy
 import inspect
 import logging
+import os
 import time
 from functools import partial
 
@@ -428,6 +429,13 @@ class _HipBackend:
         self.weights = None if all(x is None for x in w) else np.array([1.0 if x is None else x for x in w])
         self.chi_store = None
         self.fw_T_dev = None
+        # device-side exchange over peer-mapped windows (xGMI) when every rank can set it up;
+        # otherwise (or after a failed sweep) one RCCL all-reduce per interval
+        self.p2p = False
+        if self.world > 1 and os.environ.get('KH_P2P', '1') != '0':
+            self.p2p = self.engine.enable_p2p(self.group)
+            logging.getLogger('krotov').info(
+                "cross-GPU exchange: %s", "peer windows" if self.p2p else "RCCL all-reduce per interval")
 
     # -- helpers -----------------------------------------------------------
     def _pulses(self, pulses):
@@ -461,9 +469,28 @@ class _HipBackend:
         self.chi_store = eng.backward(chi_loc, guess, out=self.chi_store)
         shapes = eng.dev(np.array(shape_arrays, dtype=np.float64).reshape(self.L, self.nt - 1), t.float64)
         lambdas = eng.dev(np.asarray(lambda_vals, dtype=np.float64), t.float64)
+        done = False
         if self.group is None:
             opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
-        else:
+            done = True
+        elif self.p2p:
+            # one persistent launch per rank; the per-GPU sums cross the node inside the kernel
+            failed = 0
+            try:
+                opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
+                eng.check()
+            except Exception as exc:  # exchange timeout: every rank falls back together
+                logging.getLogger('krotov').warning("cross-GPU exchange failed (%s)", exc)
+                failed = 1
+            flag = t.tensor([failed], dtype=t.int32, device=eng.device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, group=self.group)
+            if int(flag.item()) == 0:
+                done = True
+                eng._p2p_used = True
+            else:
+                self.p2p = False
+                eng.disable_p2p()
+        if not done:
             def all_reduce(x):
                 self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM, group=self.group)
 

@@ -98,5 +98,8 @@ class OracleEngineDouble:
     def check(self):
         pass
 
+    def enable_p2p(self, group, rounds=8):
+        return False  # no peer windows on the CPU: the per-interval all-reduce path is exercised
+
     def close(self):
         pass

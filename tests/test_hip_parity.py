@@ -342,7 +342,10 @@ def _two_rank_worker(rank, world, port, queue):
             objectives, pulse_options, spec.tlist, propagator=ka.propagators.expm,
             chi_constructor=ka.functionals.chis_sm, iter_stop=2, store_all_pulses=True,
             process_group=dist.group.WORLD)
-        queue.put((rank, np.array(res.all_pulses), np.array(res.tau_vals)))
+        import krotov_amd.engine as engine_mod
+
+        used_p2p = bool(getattr(engine_mod.LAST_ENGINE(), '_p2p_used', False))
+        queue.put((rank, np.array(res.all_pulses), np.array(res.tau_vals), used_p2p))
     finally:
         dist.destroy_process_group()
 
@@ -368,10 +371,11 @@ def test_two_ranks_sharded_on_one_gpu():
     spec = configs.config_c5(K=6, N=64, nt=61, L=1)
     spec.chi = 'sm'
     ref = oracle_optimize(spec, 2)
-    for _, pulses, tau in out:
+    for _, pulses, tau, used_p2p in out:
         assert np.abs(pulses - ref['all_pulses']).max() < 1e-12
         assert np.abs(tau - ref['tau_vals']).max() < 1e-12
     assert np.array_equal(out[0][1], out[1][1])
+    print("cross-GPU exchange through peer windows used:", [o[3] for o in out])
 
 
 def test_full_size_c4_liouville_properties():
