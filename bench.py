@@ -124,6 +124,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    local_rank = local_rank % max(1, torch.cuda.device_count())  # (testing: several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1 or args.force_dist:
@@ -136,7 +137,11 @@ def main():
             os.environ.setdefault('WORLD_SIZE', '1')
 
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('KH_DIST_BACKEND', 'nccl')  # 'gloo' only for single-GPU testing
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     os.environ['KH_PROFILE'] = '1'
@@ -188,6 +193,9 @@ def main():
         'tile64ws/512': ('kh_ws_forward_update', 'kh_ws_sweep_store'),
         'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
     }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
+    if group is not None and not getattr(eng, '_p2p_used', False) and eng.kernel != 'generic':
+        # per-interval launches (RCCL path) run the two-tile kernel, see krotov_hip.hip:launch_update
+        kernel_names = ('kh_tile_forward_update', kernel_names[1])
 
     if rank == 0:
         K_loc = eng.K

@@ -494,8 +494,10 @@ class _HipBackend:
             def all_reduce(x):
                 self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM, group=self.group)
 
+            # HIP-graph replay of the interval loop needs a capturable collective (RCCL)
+            chunk = None if self.dist.get_backend(self.group) == 'nccl' else 0
             opt, psi_T, g_a = eng.forward_update_sharded(
-                self.chi_store, norms_loc, self.init, guess, shapes, lambdas, all_reduce)
+                self.chi_store, norms_loc, self.init, guess, shapes, lambdas, all_reduce, graph_chunk=chunk)
         self.fw_T_dev = psi_T
         eng.check()
         fw_T = self._gather_rows(psi_T.cpu().numpy())

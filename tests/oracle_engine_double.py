@@ -46,7 +46,7 @@ class OracleEngineDouble:
     def forward_update(self, chi_store, chi_norms, init, guess, shape, lambdas):
         return self.forward_update_sharded(chi_store, chi_norms, init, guess, shape, lambdas, lambda t: t)
 
-    def forward_update_sharded(self, chi_store, chi_norms, init, guess, shape, lambdas, all_reduce):
+    def forward_update_sharded(self, chi_store, chi_norms, init, guess, shape, lambdas, all_reduce, graph_chunk=None):
         chi = self.dev(chi_store, torch.complex128).numpy()
         norms = self.dev(chi_norms, torch.float64).numpy()
         guess = self.dev(guess, torch.float64).numpy()
