@@ -190,7 +190,6 @@ def main():
     stats = eng.stats()
     kernel_names = {
         'tile64q2/512': ('kh_q2_forward_update', 'kh_q2_sweep_store'),
-        'tile64ws/512': ('kh_ws_forward_update', 'kh_ws_sweep_store'),
         'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
     }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
     if group is not None and not getattr(eng, '_p2p_used', False) and eng.kernel != 'generic':

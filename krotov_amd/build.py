@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, 'csrc', 'krotov_hip.hip')
-DEPS = [os.path.join(HERE, 'csrc', f) for f in ('kh_common.h', 'kh_generic.h', 'kh_tile64.h', 'kh_tile64q2.h', 'kh_tile64ws.h')] + [
+DEPS = [os.path.join(HERE, 'csrc', f) for f in ('kh_common.h', 'kh_generic.h', 'kh_tile64.h', 'kh_tile64q2.h')] + [
     os.path.join(ROOT, 'include', 'krotov_hip.h')
 ]
 OUT = os.path.join(HERE, 'libkrotov_hip.so')

@@ -103,23 +103,8 @@ __device__ __forceinline__ double sum64(double v) {
 // <= theta_max and truncate each at the smallest degree m whose remainder
 // bound th^(m+1)/(m+1)! / (1 - th/(m+2)) is <= tol.  theta=0.5, tol=2^-53
 // gives m=14; theta=1.0 gives m=18.
-__host__ __device__ inline void kh_choose_degree(double theta, double tol, double theta_max, int *s_out,
-                                                 int *m_out) {
-    int s = 1;
-    if (theta > theta_max) s = (int)ceil(theta / theta_max);
-    const double th = theta / s;
-    double term = 1.0;
-    int m = 1;
-    for (; m < KH_MAX_DEGREE; ++m) {
-        term *= th / m;  // th^m / m!
-        const double next = term * th / (m + 1);
-        if (next <= tol * (1.0 - th / (m + 2))) break;
-    }
-    *s_out = s;
-    *m_out = m;
-}
-
-// The same rule without divisions on the device: tab[m] (host-built, see
+//
+// Evaluated without divisions on the device: tab[m] (host-built, see
 // kh_build_degree_table) is the largest theta for which degree m meets tol, so
 // the degree is the smallest m with theta <= tab[m].  `hint` (the previous
 // interval's degree) makes the search O(1) along a smooth pulse.

@@ -20,7 +20,6 @@
 #include "kh_generic.h"
 #include "kh_tile64.h"
 #include "kh_tile64q2.h"
-#include "kh_tile64ws.h"
 
 static thread_local std::string g_last_error;
 
@@ -42,7 +41,7 @@ static int kh_fail(int code, const char *fmt, ...) {
                            __FILE__, __LINE__);                                               \
     } while (0)
 
-enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3, KIND_TILE_WS = 4 };
+enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3 };
 
 struct kh_engine {
     int K, N, L, nt, is_super;
@@ -88,7 +87,6 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
         case KIND_TILE_RPT2: return "tile64/256";
         case KIND_TILE_RPT1: return "tile64/512";
         case KIND_TILE_Q2: return "tile64q2/512";
-        case KIND_TILE_WS: return "tile64ws/512";
         default: return "generic";
     }
 }
@@ -230,13 +228,11 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
         // two waves per SIMD are needed to keep the fp64 FMA pipe issuing back to back
         e->kind = KIND_TILE_RPT1;
         if (e->L == 1) e->kind = KIND_TILE_Q2;  // two Taylor terms per phase (kh_tile64q2.h)
-        // wave-specialised variant (kh_tile64ws.h): same speed today, kept selectable for tuning
-        if (force && strcmp(force, "ws") == 0 && e->L == 1) e->kind = KIND_TILE_WS;
         if (force && strcmp(force, "tile512") == 0) e->kind = KIND_TILE_RPT1;
         if (force && strcmp(force, "tile256") == 0 && e->L <= 2) e->kind = KIND_TILE_RPT2;
         e->grid_update = e->K;
     }
-    if (e->kind == KIND_TILE_Q2 || e->kind == KIND_TILE_WS) {
+    if (e->kind == KIND_TILE_Q2) {
         // stage P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 once per distinct operator (pair)
         const size_t bytes = sizeof(cplx) * (size_t)e->N * e->N;
         for (int dir = 0; dir < 2; ++dir) {
@@ -285,10 +281,7 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
                                      (int)kh_q2_lds_bytes()));
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
-        KH_HIP_E(hipFuncSetAttribute((const void *)kh_ws_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kh_ws_lds_bytes()));
-        KH_HIP_E(hipFuncSetAttribute((const void *)kh_ws_forward_update,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_ws_lds_bytes()));
+
     }
 
     // ---- workspaces
@@ -336,10 +329,7 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     const int direction = backward ? -1 : +1;
     KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
     int rc = KH_OK;
-    if (e->kind == KIND_TILE_WS) {
-        kh_ws_sweep_store<<<e->K, KH_WS_THREADS, kh_ws_lds_bytes(), st>>>(
-            p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
-    } else if (e->kind == KIND_TILE_Q2) {
+    if (e->kind == KIND_TILE_Q2) {
         kh_q2_sweep_store<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(
             p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
     } else if (e->kind == KIND_TILE_RPT2) {
@@ -400,12 +390,10 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     }
     if (u.internal_exchange) KH_HIP(hipMemsetAsync(e->d_slots, 0, e->slots_bytes, st));
     // One launch per interval (sharded sweep): every launch re-stages its operator
-    // tiles, so the q2/ws kernels (5 tiles, 320 KiB per objective) lose to the
+    // tiles, so the q2 kernels (5 tiles, 320 KiB per objective) lose to the
     // plain tile kernel (2 tiles) there -- measured 39 vs ~20 us per interval.
     const bool stepwise = !u.internal_exchange;
-    if (e->kind == KIND_TILE_WS && !stepwise) {
-        kh_ws_forward_update<<<e->K, KH_WS_THREADS, kh_ws_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
-    } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
+    if (e->kind == KIND_TILE_Q2 && !stepwise) {
         kh_q2_forward_update<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
     } else if (e->kind != KIND_GENERIC) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;

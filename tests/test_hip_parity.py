@@ -422,7 +422,7 @@ def test_full_size_c4_liouville_properties():
     eng2.close()
 
 
-@pytest.mark.parametrize('kernel', ['q2', 'ws', 'tile512', 'generic'])
+@pytest.mark.parametrize('kernel', ['q2', 'tile512', 'generic'])
 def test_nonuniform_grid_and_large_step_norms(kernel, monkeypatch):
     """Non-uniform dt and ||H dt|| up to ~4 (several Taylor sub-steps per interval,
     degrees changing along the grid), non-Hermitian drift: every kernel family."""
