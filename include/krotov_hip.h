@@ -141,6 +141,18 @@ int kh_forward_update(kh_engine *engine, const kh_cdouble *chi_store_dev,
                       const double *lambda_dev, double *opt_dev,
                       kh_cdouble *psi_T_dev, double *g_a_dev, void *stream);
 
+/* Second-order Krotov update (optimize.py:434-443, 468-469, 492-500): the
+ * following update sweeps add 0.5 sigma_n <phi_k(t_n) - fw_prev[k][n] | mu |
+ * phi_k(t_n)> to every summand of the pulse update and store the propagated
+ * states.
+ *   fw_prev_dev  [K][nt][N] states propagated under the guess pulses
+ *                (forward_states0; iteration 0: kh_forward_store's states)
+ *   fw_store_dev [K][nt][N] OUT states under the optimized pulses
+ *   sigma_dev    [nt-1] sigma(t) at the interval mid-points (optimize.py:452)
+ * Pass three NULLs to return to the first-order update. */
+int kh_set_second_order(kh_engine *engine, const kh_cdouble *fw_prev_dev,
+                        kh_cdouble *fw_store_dev, const double *sigma_dev);
+
 /* The same sweep cut at the cross-objective sum, for objectives sharded over
  * several GPUs: the caller all-reduces `partial` (L doubles, Im parts) across
  * ranks between two calls (RCCL over xGMI).

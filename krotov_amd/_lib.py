@@ -42,6 +42,7 @@ SYMBOLS = {
     'kh_forward_store': (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     'kh_backward_store': (ctypes.c_int, [_P, _P, _P, _P, _P]),
     'kh_forward_update': (ctypes.c_int, [_P] * 11),
+    'kh_set_second_order': (ctypes.c_int, [_P, _P, _P, _P]),
     'kh_update_begin': (ctypes.c_int, [_P] * 9),
     'kh_update_step': (ctypes.c_int, [_P, ctypes.c_int32] + [_P] * 9),
     'kh_update_step_dev': (ctypes.c_int, [_P] * 11),

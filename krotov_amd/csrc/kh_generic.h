@@ -191,6 +191,10 @@ struct KhUpdateArgs {
     const double *D_in;         // [L] all-reduced sums (stepwise mode)
     int n_begin, n_end;         // intervals [n_begin, n_end) are applied; partials of n_end are emitted
     int internal_exchange;      // 1: gather in-kernel (single launch over the grid)
+    // second-order update (optimize.py:434-443, 468-469, 492-500); all three NULL for first order
+    const cplx *fw_prev;        // [K][nt][N] states propagated under the guess pulses (forward_states0)
+    cplx *fw_store;             // [K][nt][N] OUT states propagated under the optimized pulses
+    const double *sigma;        // [nt-1] sigma at the interval mid-points
     const int *n_dev;           // stepwise mode under graph replay: the interval index lives in device memory
                                 // (read here, incremented by kh_reduce_partials), so every replay is identical
 };
@@ -210,15 +214,24 @@ __device__ __forceinline__ void kh_gen_partials(const KhSweepArgs &p, const KhUp
         }
         __syncthreads();
         const double nrm = u.chi_norms[k];
+        const double hs = u.sigma != nullptr ? 0.5 * u.sigma[n] / nrm : 0.0;  // folded into the chi term below
         for (int l = 0; l < L; ++l) {
             const cplx *h = p.ops[(size_t)k * (1 + L) + 1 + l];
-            cplx ov = c_make(0.0, 0.0);  // <chi | H_l phi>, partial over this thread's rows
+            cplx ov = c_make(0.0, 0.0);  // <chi + hs * dphi | H_l phi>, partial over this thread's rows
             if (h != nullptr) {
                 const cplx *one_op[1] = {h};
                 for (int row0 = 0; row0 < N; row0 += 16) {
                     const int row = row0 + grp;
                     const cplx d = kh_gen_row_dot(one_op, zero_eps, 0, N, row, c16, s.xa);
-                    if (c16 == 0 && row < N) c_fma_conj(ov, s.chi[row], d);
+                    if (c16 == 0 && row < N) {
+                        cplx bra = s.chi[row];
+                        if (u.sigma != nullptr) {  // second order: + 0.5 sigma <phi - phi_prev | (optimize.py:469)
+                            const cplx prev = u.fw_prev[((size_t)k * nt + n) * N + row];
+                            bra.x = fma(hs, s.xa[row].x - prev.x, bra.x);
+                            bra.y = fma(hs, s.xa[row].y - prev.y, bra.y);
+                        }
+                        c_fma_conj(ov, bra, d);
+                    }
                 }
             }
             // workgroup reduction in a fixed order: lanes (sum64) then waves
@@ -308,8 +321,12 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
             const double *norms_k = p.op_norms + (size_t)k * (1 + L);
             for (int i = tid; i < N; i += KH_GEN_THREADS) s.acc[i] = u.phi[(size_t)k * N + i];
             __syncthreads();
+            if (u.fw_store != nullptr && n == 0)
+                for (int i = tid; i < N; i += KH_GEN_THREADS) u.fw_store[((size_t)k * nt) * N + i] = s.acc[i];
             matvecs += kh_gen_expm_action(p, ops_k, norms_k, eps, dt, s);
             for (int i = tid; i < N; i += KH_GEN_THREADS) u.phi[(size_t)k * N + i] = s.acc[i];
+            if (u.fw_store != nullptr)
+                for (int i = tid; i < N; i += KH_GEN_THREADS) u.fw_store[((size_t)k * nt + n + 1) * N + i] = s.acc[i];
             __syncthreads();
         }
         // ---- partial sums of the next interval ----

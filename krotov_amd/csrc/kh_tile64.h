@@ -200,7 +200,7 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
 // and the running state never leave the registers / LDS of their workgroup.
 // Barriers per interval: 1 (partial sums) + 1 (broadcast of the reduced sums)
 // + one per Taylor term.
-template <int RPT, int LT>
+template <int RPT, int LT, bool SO>  // SO: second-order update, compiled separately
 __global__ void __launch_bounds__(512 / RPT)
 kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     if (u.n_dev != nullptr) {  // graph-replayed stepwise mode: interval index from device memory
@@ -251,14 +251,20 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
 #pragma unroll
     for (int l = 0; l < LT; ++l) g_a_loc[l] = 0.0;
 
-    // chi_k(t_n) rows for this lane, fetched one interval ahead
-    cplx chi[RPT];
+    // chi_k(t_n) rows for this lane, fetched one interval ahead; second order: also the rows of the
+    // state propagated under the guess pulses and 0.5 sigma_n / ||chi|| (optimize.py:468-469)
+    cplx chi[RPT], prev[RPT];
+    double hs = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) prev[r] = c_make(0.0, 0.0);
     auto load_chi = [&](int n) {
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int row = KhTile<RPT>::row(wave, lane, r);
             chi[r] = row < N ? u.chi_store[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0);
+            if constexpr (SO) prev[r] = row < N ? u.fw_prev[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0);
         }
+        if constexpr (SO) hs = 0.5 * u.sigma[n] / chi_norm;
     };
 
     // wave-level pieces of  chi_norm * Im(mu <chi(t_n) | H_l phi>)  -> red[par][wave]; phi in buf[cur]
@@ -270,7 +276,14 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
             cplx ov = c_make(0.0, 0.0);
             if (cg == 0) {
 #pragma unroll
-                for (int r = 0; r < RPT; ++r) c_fma_conj(ov, chi[r], y[r]);
+                for (int r = 0; r < RPT; ++r) {
+                    // second order: the bra is chi + hs (phi - phi_prev)
+                    cplx bra = chi[r];
+                    if constexpr (SO)
+                        bra = c_make(fma(hs, state[r].x - prev[r].x, chi[r].x),
+                                     fma(hs, state[r].y - prev[r].y, chi[r].y));
+                    c_fma_conj(ov, bra, y[r]);
+                }
             }
             const double re = sum64(ov.x), im = sum64(ov.y);
             if (lane == 0) {
@@ -377,6 +390,9 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         m_hint = m;
         cplx a[RPT][8];
         kh_tile_build_generator<RPT, LT>(h, eps, a);
+        if constexpr (SO) {
+            if (wave == 0 && lane < N) u.fw_store[((size_t)k * nt + n) * N + lane] = buf[cur][lane];
+        }
         matvecs += kh_tile_expm_action<RPT>(a, state, buf, inv_sh, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
         // ---- partial sums of the next interval (state is in buf[cur], barrier passed) ----
         if (n + 1 < nt - 1) {
@@ -385,7 +401,10 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         }
     }
     // running state back to the engine workspace (final states / next launch)
-    if (wave == 0 && lane < N) u.phi[(size_t)k * N + lane] = buf[cur][lane];
+    if (wave == 0 && lane < N) {
+        u.phi[(size_t)k * N + lane] = buf[cur][lane];
+        if constexpr (SO) u.fw_store[((size_t)k * nt + u.n_end) * N + lane] = buf[cur][lane];
+    }
     if (!u.internal_exchange && u.n_end < nt - 1) {
         double part[LT];
         partial_total(u.n_end & 1, part);

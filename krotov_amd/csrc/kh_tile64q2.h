@@ -210,6 +210,7 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
 // ---------------------------------------------------------------------------
 // forward sweep with sequential pulse update (optimize.py:444-508), grid == K
 // ---------------------------------------------------------------------------
+template <bool SO>  // SO: second-order update (compiled separately so first order keeps its register budget)
 __global__ void __launch_bounds__(KH_Q2_THREADS)
 kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdateArgs u, KhExchange ex) {
     if (u.n_dev != nullptr) {  // graph-replayed stepwise mode: interval index from device memory
@@ -246,8 +247,17 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     __syncthreads();
 
     double g_a_loc = 0.0;
-    cplx chi = c_make(0.0, 0.0);
-    auto load_chi = [&](int n) { chi = row < N ? u.chi_store[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0); };
+    // chi_k(t_n) row of this lane, fetched one interval ahead; second order: also the row of the
+    // state propagated under the guess pulses and 0.5 sigma_n / ||chi|| (optimize.py:468-469)
+    cplx chi = c_make(0.0, 0.0), prev = c_make(0.0, 0.0);
+    double hs = 0.0;
+    auto load_chi = [&](int n) {
+        chi = row < N ? u.chi_store[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0);
+        if constexpr (SO) {
+            prev = row < N ? u.fw_prev[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0);
+            hs = 0.5 * u.sigma[n] / chi_norm;
+        }
+    };
 
     // wave-level pieces of <chi(t_n) | H1 phi> -> red[par][wave]; phi in buf[cur]
     auto partial_pieces = [&](int par) {
@@ -260,7 +270,10 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         y.x = sum8(y.x);
         y.y = sum8(y.y);
         cplx ov = c_make(0.0, 0.0);
-        if (cg == 0) c_fma_conj(ov, chi, y);
+        // <chi + hs (phi - phi_prev) | H1 phi>: the second-order bra folded into the co-state
+        cplx bra = chi;
+        if constexpr (SO) bra = c_make(fma(hs, state.x - prev.x, chi.x), fma(hs, state.y - prev.y, chi.y));
+        if (cg == 0) c_fma_conj(ov, bra, y);
         // Im(mu <chi|H1 phi>) needs only one real combination: reduce that, not both parts
         const double v = sum64(u.mu_re * ov.y + u.mu_im * ov.x);
         if (lane == 0) red[par][wave][0] = v;
@@ -337,7 +350,9 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         kh_degree_cached((nrm0 + fabs(eps) * nrm1) * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
         cplx a[8], b[8];
         kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
-        matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, nullptr, N, p.fre, p.fim, dt, nsub, m, wave,
+        cplx *fw_out = nullptr;
+        if constexpr (SO) fw_out = u.fw_store + ((size_t)k * nt + n) * N;
+        matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
                                      lane);
 #ifdef KH_TIMING
         const long long tq2 = clock64();
@@ -358,7 +373,10 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         p.stats[3] = (double)t_part;
     }
 #endif
-    if (wave == 0 && lane < N) u.phi[(size_t)k * N + lane] = s.buf[cur][lane];
+    if (wave == 0 && lane < N) {
+        u.phi[(size_t)k * N + lane] = s.buf[cur][lane];
+        if constexpr (SO) u.fw_store[((size_t)k * nt + u.n_end) * N + lane] = s.buf[cur][lane];
+    }
     if (!u.internal_exchange && u.n_end < nt - 1) {
         const double part = partial_total(u.n_end & 1);
         if (tid == 0) u.wg_partial[k] = part;

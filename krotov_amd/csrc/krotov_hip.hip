@@ -65,6 +65,10 @@ struct kh_engine {
     double *d_stats = nullptr;        // [4]
     double *d_wg_partial = nullptr;   // [G][L]
     const double *guess_dev = nullptr;  // remembered by kh_update_begin
+    // second-order update (kh_set_second_order); all NULL = first order
+    const cplx *so_fw_prev = nullptr;
+    cplx *so_fw_store = nullptr;
+    const double *so_sigma = nullptr;
     // cross-GPU exchange (kh_p2p_*): objectives sharded over `p2p_world` ranks
     int p2p_world = 1, p2p_rank = 0;
     kh_u64 *p2p_window = nullptr;            // this rank's window (fine-grained device memory)
@@ -279,7 +283,9 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
         }
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kh_q2_lds_bytes()));
-        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update,
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
 
     }
@@ -369,7 +375,10 @@ extern "C" int kh_backward_store(kh_engine *e, const kh_cdouble *chi_T_dev, cons
 template <int RPT, int LT>
 static void launch_tile_update(const kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u, const KhExchange &ex,
                                hipStream_t st) {
-    kh_tile_forward_update<RPT, LT><<<e->K, 512 / RPT, 0, st>>>(p, u, ex);
+    if (u.sigma != nullptr)
+        kh_tile_forward_update<RPT, LT, true><<<e->K, 512 / RPT, 0, st>>>(p, u, ex);
+    else
+        kh_tile_forward_update<RPT, LT, false><<<e->K, 512 / RPT, 0, st>>>(p, u, ex);
 }
 
 static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
@@ -394,7 +403,10 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     // plain tile kernel (2 tiles) there -- measured 39 vs ~20 us per interval.
     const bool stepwise = !u.internal_exchange;
     if (e->kind == KIND_TILE_Q2 && !stepwise) {
-        kh_q2_forward_update<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
+        if (u.sigma != nullptr)
+            kh_q2_forward_update<true><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
+        else
+            kh_q2_forward_update<false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
     } else if (e->kind != KIND_GENERIC) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
         switch (e->L) {
@@ -432,6 +444,9 @@ static KhUpdateArgs update_args(kh_engine *e, const kh_cdouble *chi_store, const
     u.wg_partial = e->d_wg_partial;
     u.D_in = nullptr;
     u.n_dev = nullptr;
+    u.fw_prev = e->so_fw_prev;
+    u.fw_store = e->so_fw_store;
+    u.sigma = e->so_sigma;
     u.n_begin = 0;
     u.n_end = e->nt - 1;
     u.internal_exchange = 1;
@@ -459,6 +474,20 @@ extern "C" int kh_forward_update(kh_engine *e, const kh_cdouble *chi_store_dev, 
     KH_HIP(hipMemcpyAsync(psi_T_dev, e->d_phi, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice, st));
     e->last_intervals = e->nt - 1;
     e->last_wgs = e->grid_update;
+    return KH_OK;
+}
+
+extern "C" int kh_set_second_order(kh_engine *e, const kh_cdouble *fw_prev_dev, kh_cdouble *fw_store_dev,
+                                   const double *sigma_dev) {
+    if (e == nullptr) return kh_fail(KH_ERR_INVALID, "null engine");
+    const int given = (fw_prev_dev != nullptr) + (fw_store_dev != nullptr) + (sigma_dev != nullptr);
+    if (given != 0 && given != 3)
+        return kh_fail(KH_ERR_INVALID, "fw_prev, fw_store and sigma must be given together (or all NULL)");
+    if (fw_prev_dev != nullptr && (const void *)fw_prev_dev == (const void *)fw_store_dev)
+        return kh_fail(KH_ERR_INVALID, "fw_store must not alias fw_prev");
+    e->so_fw_prev = (const cplx *)fw_prev_dev;
+    e->so_fw_store = (cplx *)fw_store_dev;
+    e->so_sigma = sigma_dev;
     return KH_OK;
 }
 

@@ -203,6 +203,23 @@ class HipKrotovEngine:
                 self._handle, chi_T.data_ptr(), pulses.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
+    def set_second_order(self, fw_prev=None, fw_store=None, sigma_vals=None):
+        """Switch the following update sweeps to the second-order update
+        (``fw_prev``, ``fw_store``: (K, nt, N) device tensors; ``sigma_vals``:
+        sigma at the nt-1 interval mid-points), or back to first order (no
+        arguments)."""
+        if fw_prev is None:
+            self._so = None
+            _lib.check(self._lib.kh_set_second_order(self._handle, None, None, None))
+            return
+        fw_prev = self._c(fw_prev, (self.K, self.nt, self.N))
+        if tuple(fw_store.shape) != (self.K, self.nt, self.N) or fw_store.dtype != torch.complex128:
+            raise ValueError("fw_store must be a (K, nt, N) complex128 device tensor")
+        sig = self._f(sigma_vals, (self.nt - 1,))
+        self._so = (fw_prev, fw_store, sig)  # keep the tensors alive while the engine points at them
+        _lib.check(self._lib.kh_set_second_order(
+            self._handle, fw_prev.data_ptr(), fw_store.data_ptr(), sig.data_ptr()))
+
     def forward_update(self, chi_store, chi_norms, init, guess, shape, lambdas):
         """Forward sweep with sequential update; returns ``(opt, psi_T, g_a)``."""
         chi_store = self._c(chi_store, (self.K, self.nt, self.N))

@@ -6,7 +6,8 @@ execution paths share all bookkeeping:
 
 * **device path** -- taken when ``propagator`` is this package's
   :func:`krotov_amd.propagators.expm` / :class:`~krotov_amd.propagators.HipExpm`
-  and ``mu``, ``overlap``, ``sigma``, ``storage`` are the defaults.  Per
+  and ``mu``, ``overlap``, ``storage`` are the defaults (first- or second-order
+  update).  Per
   iteration the three objective-parallel dispatches of the reference
   (optimize.py:302-313, 413-425, 449-501) become three calls into
   ``libkrotov_hip.so``: all objectives are batched in one launch per sweep,
@@ -247,7 +248,8 @@ class _PluginBackend:
     def tau_vals(self, fw_states_T):
         return np.array([self.overlap(obj.target, s) for s, obj in zip(fw_states_T, self.objectives)])
 
-    def iterate(self, chi_states, chi_norms, guess_pulses, lambda_vals, shape_arrays):
+    def iterate(self, chi_states, chi_norms, guess_pulses, lambda_vals, shape_arrays, sigma=None,
+                forward_states0=None):
         objectives, tlist = self.objectives, self.tlist
         K, nt = len(objectives), len(tlist)
         backward_states = self.pmap[1](
@@ -257,14 +259,25 @@ class _PluginBackend:
         g_a = np.zeros(len(guess_pulses))
         optimized = copy.deepcopy(guess_pulses)
         fw_states = [obj.initial_state for obj in objectives]
+        forward_states = moved = None
+        if sigma is not None:  # second order: keep phi(t_n) and phi(t_n) - phi_prev(t_n) (optimize.py:429-442)
+            forward_states = [self.storage(nt) for _ in range(K)]
+            for k in range(K):
+                forward_states[k][0] = objectives[k].initial_state
+            moved = [fw_states[k] - forward_states0[k][0] for k in range(K)]  # zero at t=0
         for n in range(nt - 1):
             dt = tlist[n + 1] - tlist[n]
+            if sigma is not None:
+                half_sigma = 0.5 * sigma(tlist[n] + 0.5 * dt)
             for l in range(len(guess_pulses)):
                 total = 0j
                 for k in range(K):  # optimize.py:455-470
                     mu_op = self.mu(objectives, k, guess_pulses, self.mapping, l, n)
-                    update = self.overlap(backward_states[k][n], mu_op(fw_states[k]))
+                    mu_phi = mu_op(fw_states[k])
+                    update = self.overlap(backward_states[k][n], mu_phi)
                     update *= chi_norms[k]
+                    if sigma is not None:
+                        update += half_sigma * self.overlap(moved[k], mu_phi)
                     total += update
                 step = shape_arrays[l][n] / lambda_vals[l]
                 d1 = total.imag
@@ -274,7 +287,11 @@ class _PluginBackend:
                 _forward_propagation_step, list(range(K)),
                 (fw_states, objectives, optimized, self.mapping, tlist, n, self.propagators),
             )
-        return backward_states, optimized, fw_states, g_a
+            if sigma is not None:
+                moved = [fw_states[k] - forward_states0[k][n + 1] for k in range(K)]
+                for k in range(K):
+                    forward_states[k][n + 1] = fw_states[k]
+        return backward_states, optimized, fw_states, g_a, forward_states
 
 
 # ---------------------------------------------------------------------------
@@ -302,19 +319,54 @@ class _LazyStates:
         return (self[k] for k in range(len(self)))
 
 
-class _DeviceTrajectories:
-    """``backward_states[k][n]`` for ``info_hook``: fetched from HBM on access."""
+class _DeviceTrajectory:
+    """States of one objective on the time grid, one device row per access."""
 
-    def __init__(self, tensor, likes, k0=0):
-        self._t, self._likes, self._k0 = tensor, likes, k0
+    def __init__(self, owner, k):
+        self._o, self._k = owner, k
 
     def __len__(self):
-        return self._t.shape[0]
+        return self._o._t.shape[1]
+
+    def __getitem__(self, n):
+        o, k = self._o, self._k
+        nt = len(self)
+        if isinstance(n, slice):
+            return [self[i] for i in range(*n.indices(nt))]
+        if not -nt <= n < nt:
+            raise IndexError("time index %d out of range" % n)
+        n %= nt
+        like = o._likes[k]
+        if n == nt - 1 and o._final is not None:
+            return vector_to_state(o._final[k], like)
+        if not o._k0 <= k < o._k0 + o._t.shape[0]:
+            raise IndexError("objective %d lives on another rank; only its final state is available here" % k)
+        return vector_to_state(o._t[k - o._k0, n].cpu().numpy(), like)
+
+    def __iter__(self):
+        return (self[n] for n in range(len(self)))
+
+
+class _DeviceTrajectories:
+    """``backward_states[k][n]`` / ``forward_states[k][n]`` for ``info_hook`` and
+    ``sigma.refresh``: (K_loc, nt, N) in HBM, fetched on access.  ``final``: the
+    states at T of all objectives of all ranks on the host, if known."""
+
+    def __init__(self, tensor, likes, k0=0, final=None):
+        self._t, self._likes, self._k0, self._final = tensor, likes, k0, final
+
+    def __len__(self):
+        return len(self._likes) if self._final is not None else self._t.shape[0]
 
     def __getitem__(self, k):
-        traj = self._t[k].cpu().numpy()
-        like = self._likes[self._k0 + k]
-        return [vector_to_state(traj[n], like) for n in range(traj.shape[0])]
+        if self._final is None:
+            k += self._k0  # local numbering (backward states of this rank)
+        if not 0 <= k < len(self._likes):
+            raise IndexError("objective index out of range")
+        return _DeviceTrajectory(self, k)
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
 
 
 def _use_device_path(propagator, mu, overlap, sigma, storage, objectives):
@@ -327,7 +379,7 @@ def _use_device_path(propagator, mu, overlap, sigma, storage, objectives):
         return False
     if overlap is not None and overlap is not _overlap:
         return False
-    if sigma is not None or storage != 'array':
+    if storage != 'array':
         return False
     return all(len(obj.c_ops) == 0 for obj in objectives)
 
@@ -413,6 +465,7 @@ class _HipBackend:
         tlist = np.asarray(tlist, dtype=np.float64)
         self.engine = HipKrotovEngine(ops, np.diff(tlist), is_super=self.is_super)
         self.nt = len(tlist)
+        self.tlist_host = tlist
         self.likes = [obj.initial_state for obj in objectives]
         init = [state_to_vector(obj.initial_state, N, self.is_super) for obj in objectives[self.k0:self.k1]]
         if any(v is None for v in init):
@@ -429,6 +482,8 @@ class _HipBackend:
         self.weights = None if all(x is None for x in w) else np.array([1.0 if x is None else x for x in w])
         self.chi_store = None
         self.fw_T_dev = None
+        self.fw_prev = self.fw_next = None  # second order: phi(t_n) of the last / the running iteration
+        self.fw_prev_T = None
         # device-side exchange over peer-mapped windows (xGMI) when every rank can set it up;
         # otherwise (or after a failed sweep) one RCCL all-reduce per interval
         self.p2p = False
@@ -445,10 +500,17 @@ class _HipBackend:
         """(K_loc, ...) host array on every rank -> (K_total, ...) on every rank."""
         return gather_rows(local, self.K_total, self.world, self.group, self.engine.device)
 
-    def initial_forward(self, pulses):
-        self.fw_T_dev = self.engine.forward(self._pulses(pulses), self.init)
+    def initial_forward(self, pulses, store=False):
+        forward_states = None
+        if store:
+            self.fw_T_dev, self.fw_prev = self.engine.forward(self._pulses(pulses), self.init, store=True)
+        else:
+            self.fw_T_dev = self.engine.forward(self._pulses(pulses), self.init)
         fw_T = self._gather_rows(self.fw_T_dev.cpu().numpy())
-        return _LazyStates(fw_T, self.likes), None
+        if store:
+            self.fw_prev_T = fw_T
+            forward_states = _DeviceTrajectories(self.fw_prev, self.likes, self.k0, final=fw_T)
+        return _LazyStates(fw_T, self.likes), forward_states
 
     def fw_T_host(self, fw_states_T):
         return fw_states_T._array if isinstance(fw_states_T, _LazyStates) else None
@@ -459,11 +521,19 @@ class _HipBackend:
         tau = self.engine.tau(self.targets, self.fw_T_dev).cpu().numpy()
         return self._gather_rows(tau)
 
-    def iterate(self, chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays):
+    def iterate(self, chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays, sigma=None):
         """chi_T: (K_total, N) normalised co-states (host); chi_norms (K_total,)."""
         t = self.torch
         eng = self.engine
         guess = self._pulses(guess_pulses)
+        if sigma is not None:
+            # sigma at the interval mid-points (optimize.py:451-452); phi under the guess pulses is
+            # the trajectory the previous sweep stored, the running one goes to the other buffer
+            tl = np.asarray(self.tlist_host)
+            sig = np.array([sigma(tl[n] + 0.5 * (tl[n + 1] - tl[n])) for n in range(self.nt - 1)], dtype=np.float64)
+            if self.fw_next is None:
+                self.fw_next = t.empty_like(self.fw_prev)
+            eng.set_second_order(self.fw_prev, self.fw_next, sig)
         chi_loc = eng.dev(chi_T[self.k0:self.k1], t.complex128)
         norms_loc = eng.dev(np.asarray(chi_norms, dtype=np.float64)[self.k0:self.k1], t.float64)
         self.chi_store = eng.backward(chi_loc, guess, out=self.chi_store)
@@ -504,7 +574,15 @@ class _HipBackend:
         opt_host = opt.cpu().numpy()
         optimized = [opt_host[l].copy() for l in range(self.L)]
         backward_states = _DeviceTrajectories(self.chi_store, self.likes, self.k0)
-        return backward_states, optimized, _LazyStates(fw_T, self.likes), g_a.cpu().numpy()
+        forward_states = None
+        if sigma is not None:
+            forward_states = _DeviceTrajectories(self.fw_next, self.likes, self.k0, final=fw_T)
+        return backward_states, optimized, _LazyStates(fw_T, self.likes), g_a.cpu().numpy(), forward_states
+
+    def advance_second_order(self):
+        """The stored trajectory of the finished iteration becomes ``forward_states0``
+        of the next one (optimize.py:577)."""
+        self.fw_prev, self.fw_next = self.fw_next, self.fw_prev
 
 
 # ---------------------------------------------------------------------------
@@ -548,13 +626,20 @@ def optimize_pulses(
     * ``process_group`` (extension): a ``torch.distributed`` group with one
       rank per GPU; every rank passes the full objective list and gets the
       full result, objectives are sharded contiguously over the ranks.
-    * ``sigma`` (second order) is not supported (NotImplementedError).
+    * ``sigma`` (second order): on the device path the trajectories phi(t_n) of
+      the last two iterations stay in HBM; ``forward_states`` / ``forward_states0``
+      handed to ``info_hook`` and ``sigma.refresh`` fetch single states on
+      access (with ``process_group``: all time points of this rank's
+      objectives, the final time of every objective).
     * ``limit_thread_pool`` is accepted and ignored (no BLAS on the hot path).
     """
     logger = logging.getLogger('krotov')
     logger.info("Initializing optimization with Krotov's method")
-    if sigma is not None:
-        raise NotImplementedError("second-order Krotov (sigma) is outside the accelerated path")
+    second_order = sigma is not None
+    if second_order and skip_initial_forward_propagation:
+        raise ValueError(
+            "skip_initial_forward_propagation is incompatible with second order Krotov (sigma is not None)"
+        )
     device_path = _use_device_path(propagator, mu, overlap, sigma, storage, objectives)
     if process_group is not None and not device_path:
         raise ValueError("process_group requires the device path (propagator=krotov_amd.propagators.expm)")
@@ -619,9 +704,15 @@ def optimize_pulses(
             backend.fw_T_dev = None
         tau_vals = np.array([overlap(obj.target, s) for s, obj in zip(fw_states_T, objectives)])
     else:
-        fw_states_T, _ = backend.initial_forward(guess_pulses)
+        if device_path:
+            fw_states_T, forward_states = backend.initial_forward(guess_pulses, store=second_order)
+        else:
+            fw_states_T, forward_states = backend.initial_forward(guess_pulses)
         tau_vals = backend.tau_vals(fw_states_T)
     toc = time.time()
+    # the stored trajectories are only needed by the second-order update (optimize.py:324-329);
+    # in iteration 0 the states under "optimized" and guess pulses coincide
+    forward_states0 = forward_states = forward_states if second_order else None
 
     info = None
     optimized_pulses = copy.deepcopy(guess_pulses)
@@ -632,7 +723,8 @@ def optimize_pulses(
     )
     if info_hook is not None:
         info = info_hook(
-            backward_states=None, forward_states=None, forward_states0=None, guess_pulses=guess_pulses,
+            backward_states=None, forward_states=forward_states, forward_states0=forward_states0,
+            guess_pulses=guess_pulses,
             optimized_pulses=optimized_pulses, g_a_integrals=g_a_integrals, fw_states_T=fw_states_T,
             tau_vals=tau_vals, start_time=tic, stop_time=toc, iteration=0, info_vals=[], shared_data={},
             **static_args,
@@ -691,12 +783,13 @@ def optimize_pulses(
 
         g_a_integrals[:] = 0.0
         if device_path:
-            backward_states, optimized_pulses, fw_states_T, g_a = backend.iterate(
-                chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays
+            backward_states, optimized_pulses, fw_states_T, g_a, forward_states = backend.iterate(
+                chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays, sigma=sigma
             )
         else:
-            backward_states, optimized_pulses, fw_states_T, g_a = backend.iterate(
-                chi_states, chi_norms, guess_pulses, lambda_vals, shape_arrays
+            backward_states, optimized_pulses, fw_states_T, g_a, forward_states = backend.iterate(
+                chi_states, chi_norms, guess_pulses, lambda_vals, shape_arrays, sigma=sigma,
+                forward_states0=forward_states0,
             )
         g_a_integrals[:] = g_a
         tau_vals = backend.tau_vals(fw_states_T)
@@ -704,7 +797,7 @@ def optimize_pulses(
 
         if info_hook is not None:
             info = info_hook(
-                backward_states=backward_states, forward_states=None, forward_states0=None,
+                backward_states=backward_states, forward_states=forward_states, forward_states0=forward_states0,
                 fw_states_T=fw_states_T, guess_pulses=guess_pulses, optimized_pulses=optimized_pulses,
                 g_a_integrals=g_a_integrals, tau_vals=tau_vals, start_time=tic, stop_time=toc,
                 info_vals=result.info_vals, shared_data={}, iteration=krotov_iteration, **static_args,
@@ -734,6 +827,17 @@ def optimize_pulses(
                 result.message += ": " + msg
             break
         guess_pulses = optimized_pulses
+        if second_order:
+            if chi_states is None:  # stacked co-states of the device path, in the caller's state type
+                chi_states = _LazyStates(chi_T, backend.likes)
+            sigma.refresh(
+                forward_states=forward_states, forward_states0=forward_states0, chi_states=chi_states,
+                chi_norms=chi_norms, optimized_pulses=optimized_pulses, guess_pulses=guess_pulses,
+                objectives=objectives, result=result,
+            )
+            forward_states0 = forward_states
+            if device_path:
+                backend.advance_second_order()
     else:
         result.message = "Reached %d iterations" % max(iter_start, iter_stop)
 

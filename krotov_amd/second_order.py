@@ -1,24 +1,60 @@
-"""Inner product used by the optimisation (first-order method).
+"""Second-order update support and the inner product used by the optimisation.
 
-Mirrors ``krotov.second_order._overlap`` (reference src/krotov/second_order.py:
-69-83).  The second-order ``Sigma`` machinery of the reference is outside the
-hot path this package accelerates.
+Mirrors ``krotov.second_order`` (reference src/krotov/second_order.py):
+:class:`Sigma` (9-66), ``_overlap`` (69-83), :func:`numerical_estimate_A`
+(86-164).  In the kernels the second-order term is folded into the co-state:
+``Im <chi + sigma/(2 ||chi||) (phi - phi_prev) | mu | phi>`` (krotov_hip.h,
+``kh_set_second_order``).
 """
+from abc import ABC, abstractmethod
+
 import numpy as np
 
-__all__ = ['_overlap', 'Sigma']
+__all__ = ['Sigma', 'numerical_estimate_A']
 
 
-class Sigma:
-    """Placeholder base class of second-order update functions (reference
-    second_order.py:9-66).  ``optimize_pulses(sigma=...)`` is not supported by
-    this package yet and raises NotImplementedError."""
+class Sigma(ABC):
+    """sigma(t) of the second-order update equation.
 
-    def __call__(self, t):
+    Subclass it for the problem at hand: ``__call__(t)`` evaluates sigma at
+    time ``t`` (it is sampled at the mid-point of every time interval), and
+    ``refresh(...)`` -- called after every iteration but the last -- updates
+    whatever sigma depends on parametrically (typically the constant A, see
+    :func:`numerical_estimate_A`).  Pass an instance as ``sigma=`` to
+    :func:`krotov_amd.optimize_pulses`.
+    """
+
+    @abstractmethod
+    def __call__(self, t):  # pragma: nocover
         raise NotImplementedError()
 
-    def refresh(self, **kwargs):
+    @abstractmethod
+    def refresh(self, forward_states, forward_states0, chi_states, chi_norms, optimized_pulses, guess_pulses,
+                objectives, result):  # pragma: nocover
+        """Arguments as in the reference (second_order.py:31-66):
+        ``forward_states[k][n]`` / ``forward_states0[k][n]`` are the states of
+        objective k at ``tlist[n]`` under the optimized / guess pulses of the
+        finished iteration, ``chi_states`` the normalised boundary co-states
+        and ``chi_norms`` their original norms."""
         raise NotImplementedError()
+
+
+def numerical_estimate_A(forward_states, forward_states0, chi_states, chi_norms, Delta_J_T):
+    """New value of the second-order constant A:
+
+        A = (sum_k 2 Re <chi_k(T)|dphi_k(T)> + Delta_J_T) / sum_k <dphi_k(T)|dphi_k(T)>
+
+    with ``dphi_k(T) = forward_states[k][-1] - forward_states0[k][-1]`` and the
+    un-normalised ``chi_k(T) = chi_norms[k] * chi_states[k]``; 0 when the states
+    did not move (reference second_order.py:86-164).
+    """
+    K = len(forward_states0)
+    moved = [forward_states[k][-1] - forward_states0[k][-1] for k in range(K)]
+    denom = sum(_overlap(d, d).real for d in moved)
+    if not denom > 1.0e-30:
+        return 0
+    numer = sum((2 * chi_norms[k] * _overlap(chi_states[k], moved[k])).real for k in range(K)) + Delta_J_T
+    return numer / denom
 
 
 def _overlap(a, b):

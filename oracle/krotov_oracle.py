@@ -475,13 +475,22 @@ def _mu_apply(problem, k, l, state):
     return op @ state
 
 
-def forward_update_sweep(problem, chi_store, chi_norms, guess_pulses, shapes, lambdas, use_scipy=False):
+def forward_update_sweep(problem, chi_store, chi_norms, guess_pulses, shapes, lambdas, use_scipy=False,
+                         sigma_vals=None, fw_prev=None, store=False):
     """Forward sweep with sequential pulse update (optimize.py:444-508).
 
     At interval n: ``D_l = sum_k ||chi_k|| <chi_k(t_n)| mu_lk |phi_k(t_n)>``,
     ``eps_l[n] += S_l[n]/lambda_l * Im D_l``, then every phi_k is propagated
     over interval n with the *updated* pulses.
-    Returns ``(optimized_pulses, fw_T, g_a_integrals)``.
+
+    Second order (optimize.py:434-443, 468-469, 492-500): with ``sigma_vals``
+    (sigma at the interval mid-points) and ``fw_prev`` (K, nt, N), the states
+    propagated under the guess pulses, every summand gets the extra term
+    ``0.5 sigma_n <Delta phi_k(t_n)| mu |phi_k(t_n)>`` with ``Delta phi =
+    phi_k(t_n) - fw_prev[k, n]`` (zero at n = 0).
+
+    Returns ``(optimized_pulses, fw_T, g_a_integrals)`` and, with ``store``, the
+    (K, nt, N) forward states as a fourth element.
     """
     tl = problem.tlist
     nt = len(tl)
@@ -489,13 +498,21 @@ def forward_update_sweep(problem, chi_store, chi_norms, guess_pulses, shapes, la
     opt = [np.array(p, dtype=np.float64, copy=True) for p in guess_pulses]
     g_a = np.zeros(L)
     fw = [problem.init[k].copy() for k in range(K)]
+    second_order = sigma_vals is not None
+    out = np.empty((K, nt, problem.N), dtype=np.complex128) if store else None
+    if store:
+        out[:, 0] = problem.init
+    delta = [np.zeros(problem.N, dtype=np.complex128) for _ in range(K)]  # optimize.py:437-440
     for n in range(nt - 1):
         dt = tl[n + 1] - tl[n]
         for l in range(L):
             d = 0j
             for k in range(K):  # optimize.py:455-470, k-order summation
-                update = np.vdot(chi_store[k, n], _mu_apply(problem, k, l, fw[k]))
+                mu_psi = _mu_apply(problem, k, l, fw[k])
+                update = np.vdot(chi_store[k, n], mu_psi)
                 update *= chi_norms[k]
+                if second_order:
+                    update += 0.5 * sigma_vals[n] * np.vdot(delta[k], mu_psi)
                 d += update
             S_t = shapes[l][n]
             d1 = d.imag
@@ -504,7 +521,24 @@ def forward_update_sweep(problem, chi_store, chi_norms, guess_pulses, shapes, la
         eps = [p[n] for p in opt]
         for k in range(K):
             fw[k] = step(problem.ops[k], eps, dt, fw[k], problem.is_super, False, use_scipy)
+            if second_order:
+                delta[k] = fw[k] - fw_prev[k, n + 1]  # optimize.py:494-497
+            if store:
+                out[k, n + 1] = fw[k]
+    if store:
+        return opt, np.array(fw), g_a, out
     return opt, np.array(fw), g_a
+
+
+def numerical_estimate_A(fw_T, fw_T0, chi_T, chi_norms, Delta_J_T):
+    """Second-order parameter A (second_order.py:86-141), from the final states
+    of the current (fw_T) and previous (fw_T0) iteration."""
+    dphi = fw_T - fw_T0
+    denom = float(np.sum(np.abs(dphi) ** 2))
+    if denom > 1.0e-30:
+        numer = sum((2 * chi_norms[k] * np.vdot(chi_T[k], dphi[k])).real for k in range(len(dphi))) + Delta_J_T
+        return numer / denom
+    return 0
 
 
 def default_norm(problem, chi):
@@ -533,25 +567,51 @@ def krotov_iteration(problem, guess_pulses, shapes, lambdas, fw_T, tau, chi_cons
     return opt, fw_T, tau, g_a
 
 
-def optimize(problem, guess_pulses, shapes, lambdas, chi_constructor, iter_stop, use_scipy=False, norm=None):
+def optimize(problem, guess_pulses, shapes, lambdas, chi_constructor, iter_stop, use_scipy=False, norm=None,
+             sigma=None):
     """Iteration 0 + ``iter_stop`` iterations; returns per-iteration records.
+
+    ``sigma``: object with ``__call__(t)`` and ``refresh(fw_T, fw_T0, chi_T,
+    chi_norms, tau_history)`` for the second-order update (the oracle's array
+    form of ``krotov.second_order.Sigma``; optimize.py:566-577).
 
     Returns dict with ``all_pulses`` (iter_stop+1, L, nt-1), ``tau_vals``
     (iter_stop+1, K), ``g_a`` (iter_stop+1, L), ``fw_T`` (K, N).
     """
     pulses = [np.array(p, dtype=np.float64, copy=True) for p in guess_pulses]
-    fw_T = forward_propagation(problem, pulses, use_scipy=use_scipy)
+    tl = problem.tlist
+    if sigma is None:
+        fw_T = forward_propagation(problem, pulses, use_scipy=use_scipy)
+        fw_prev = None
+    else:
+        fw_T, fw_prev = forward_propagation(problem, pulses, store=True, use_scipy=use_scipy)
     tau = tau_vals(problem, fw_T)
     all_pulses = [np.array(pulses)]
     taus = [tau]
     gas = [np.zeros(len(pulses))]
+    nrm = default_norm if norm is None else norm
     for _ in range(iter_stop):
-        pulses, fw_T, tau, g_a = krotov_iteration(
-            problem, pulses, shapes, lambdas, fw_T, tau, chi_constructor, use_scipy, norm
-        )
+        if sigma is None:
+            pulses, fw_T, tau, g_a = krotov_iteration(
+                problem, pulses, shapes, lambdas, fw_T, tau, chi_constructor, use_scipy, norm
+            )
+        else:
+            chi_T = chi_constructor(problem, fw_T, tau)
+            chi_norms = np.array([nrm(problem, chi_T[k]) for k in range(problem.K)])
+            chi_T = chi_T / chi_norms[:, None]
+            chi_store = backward_sweep(problem, chi_T, pulses, use_scipy)
+            sig = [sigma(tl[n] + 0.5 * (tl[n + 1] - tl[n])) for n in range(len(tl) - 1)]  # optimize.py:452
+            fw_T0 = fw_T
+            pulses, fw_T, g_a, fw_new = forward_update_sweep(
+                problem, chi_store, chi_norms, pulses, shapes, lambdas, use_scipy,
+                sigma_vals=sig, fw_prev=fw_prev, store=True)
+            tau = tau_vals(problem, fw_T)
         all_pulses.append(np.array(pulses))
         taus.append(tau)
         gas.append(g_a)
+        if sigma is not None:
+            sigma.refresh(fw_T, fw_T0, chi_T, chi_norms, taus)
+            fw_prev = fw_new
     return dict(
         all_pulses=np.array(all_pulses),
         tau_vals=np.array(taus),

@@ -20,7 +20,7 @@ B. ``ref``     -- the reference's real ``krotov.optimize_pulses`` loop executed
    replaced by empty stub modules (they are not installed), on the seeded
    synthetic inputs of ``krotov_amd.configs``.  Outputs: all pulses, tau_vals.
 
-Usage:  python tests/golden/make_reference_goldens.py [dumps] [ref] [c5full]
+Usage:  python tests/golden/make_reference_goldens.py [dumps] [ref] [c5full] [second_order]
 
 The reference is BSD-3-Clause (c) 2018-2024 Michael Goerz et al.; the fixtures
 derived from its shipped data keep that attribution (tests/golden/README.md).
@@ -199,7 +199,11 @@ def import_reference_krotov():
 
         start = update = finished = lambda self, *a, **k: None
 
-    mod('qutip', Qobj=type('Qobj', (), {}), expect=lambda *a: None)
+    class _Qobj:  # numpy mode: "Qobj(array)" (optimize.py:437-440) is just the array
+        def __new__(cls, inpt=None, **kw):
+            return np.asarray(inpt)
+
+    mod('qutip', Qobj=_Qobj, expect=lambda *a: None)
     mod(
         'qutip.parallel',
         serial_map=lambda task, values, task_args=(), task_kwargs={}, **k: [
@@ -222,7 +226,7 @@ def import_reference_krotov():
     return krotov
 
 
-def run_reference(spec, iter_stop, krotov=None):
+def run_reference(spec, iter_stop, krotov=None, sigma=None):
     """Run the reference loop on a ProblemSpec; returns dict of outputs."""
     import scipy.linalg as la
 
@@ -257,7 +261,7 @@ def run_reference(spec, iter_stop, krotov=None):
     res = krotov.optimize_pulses(
         objectives, pulse_options, spec.tlist,
         propagator=expm, chi_constructor=chi, mu=mu, overlap=overlap,
-        norm=np.linalg.norm, iter_stop=iter_stop, store_all_pulses=True,
+        norm=np.linalg.norm, iter_stop=iter_stop, store_all_pulses=True, sigma=sigma,
     )
     secs = time.time() - t0
     return dict(
@@ -296,6 +300,42 @@ def make_ref_fixtures(names=None):
             name, spec.K, spec.N, len(spec.tlist), spec.L, out['seconds'], out['tau_vals'][-1][:2]))
 
 
+def make_second_order():
+    """Second-order update (sigma(t) term; reference optimize.py:434-443, 468-469,
+    492-500, 566-577) on the two-qubit iSWAP system with chis_sm; sigma as in the
+    reference's notebook 07 (cell 30), A re-estimated every iteration from
+    Delta J_T and the final states (numerical_estimate_A's formula, evaluated
+    with NumPy because the reference's own helper needs Qobj states)."""
+    from krotov_amd import configs
+
+    krotov = import_reference_krotov()
+    spec = configs.config_c3(nt=201)
+    spec.lambda_a = 20.0
+
+    class Sigma(krotov.second_order.Sigma):
+        def __init__(self, A, epsA):
+            self.A, self.epsA, self.history = A, epsA, []
+
+        def __call__(self, t):
+            return -max(self.epsA, 2 * self.A + self.epsA)
+
+        def refresh(self, forward_states, forward_states0, chi_states, chi_norms, optimized_pulses,
+                    guess_pulses, objectives, result):
+            J = lambda tau: 1 - abs(np.sum(tau) / len(tau)) ** 2  # noqa: E731  (J_T_sm)
+            dJ = J(result.tau_vals[-1]) - J(result.tau_vals[-2])
+            n = len(objectives)
+            dphi = [np.asarray(forward_states[k][-1]) - np.asarray(forward_states0[k][-1]) for k in range(n)]
+            denom = sum(np.vdot(d, d).real for d in dphi)
+            numer = sum((2 * chi_norms[k] * np.vdot(chi_states[k], dphi[k])).real for k in range(n)) + dJ
+            self.A = numer / denom if denom > 1e-30 else 0
+            self.history.append(self.A)
+
+    sig = Sigma(0.0, 2.0)
+    out = run_reference(spec, 3, krotov, sigma=sig)
+    np.savez_compressed(os.path.join(HERE, 'ref_so_c3.npz'), iter_stop=3, A_history=np.array(sig.history), **out)
+    print('ref_so_c3: A history', sig.history, ' tau[-1][:2]', out['tau_vals'][-1][:2])
+
+
 def make_c5_full():
     """Headline configuration through the real reference loop: 1 iteration
     (~2.5 sweeps * 256 * 4000 props at ~0.8 ms each => ~35 min, one core)."""
@@ -315,6 +355,8 @@ if __name__ == '__main__':
         make_ref_fixtures()
     if 'c5full' in what:
         make_c5_full()
+    if 'second_order' in what:
+        make_second_order()
     for w in what:
         if w in REF_CASES:
             make_ref_fixtures([w])

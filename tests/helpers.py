@@ -30,3 +30,46 @@ def oracle_optimize(spec, iter_stop, **kw):
     # numpy-mode reference runs pass norm=np.linalg.norm (notebook 09, cell 35)
     kw.setdefault('norm', lambda prob, chi: float(np.linalg.norm(chi)))
     return ko.optimize(spec_to_oracle(spec), gp, S, lam, CHI[spec.chi], iter_stop, **kw)
+
+
+class SigmaA:
+    """sigma(t) = -max(epsA, 2A + epsA) with A re-estimated every iteration (the
+    reference's notebook 07, cell 30); oracle-side array form of the Sigma used
+    for tests/golden/ref_so_c3.npz."""
+
+    def __init__(self, A=0.0, epsA=2.0):
+        self.A, self.epsA, self.history = A, epsA, []
+
+    def __call__(self, t):
+        return -max(self.epsA, 2 * self.A + self.epsA)
+
+    def refresh(self, fw_T, fw_T0, chi_T, chi_norms, taus):
+        J = lambda tau: 1 - abs(np.sum(tau) / len(tau)) ** 2  # noqa: E731  (J_T_sm)
+        self.A = ko.numerical_estimate_A(fw_T, fw_T0, chi_T, chi_norms, J(taus[-1]) - J(taus[-2]))
+        self.history.append(self.A)
+
+
+def product_sigma(A=0.0, epsA=2.0):
+    """The same sigma through the product's plugin surface: a
+    ``krotov_amd.second_order.Sigma`` subclass whose ``refresh`` calls
+    ``krotov_amd.second_order.numerical_estimate_A`` with Delta J_T (J_T_sm) taken
+    from ``result.tau_vals``."""
+    import krotov_amd
+    from krotov_amd.second_order import Sigma, numerical_estimate_A
+
+    class _Sigma(Sigma):
+        def __init__(self):
+            self.A, self.epsA, self.history, self.calls = A, epsA, [], []
+
+        def __call__(self, t):
+            return -max(self.epsA, 2 * self.A + self.epsA)
+
+        def refresh(self, forward_states, forward_states0, chi_states, chi_norms, optimized_pulses, guess_pulses,
+                    objectives, result):
+            J = krotov_amd.functionals.J_T_sm
+            dJ = J(None, objectives, tau_vals=result.tau_vals[-1]) - J(None, objectives, tau_vals=result.tau_vals[-2])
+            self.A = numerical_estimate_A(forward_states, forward_states0, chi_states, chi_norms, dJ)
+            self.history.append(self.A)
+            self.calls.append((len(forward_states), len(forward_states[0]), guess_pulses is optimized_pulses))
+
+    return _Sigma()

@@ -109,6 +109,101 @@ def test_kernel_families_agree(name, kernel, monkeypatch):
     eng.close()
 
 
+SECOND_ORDER_CASES = [
+    ('c3', None), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
+    ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c2l', None),
+]
+
+
+@pytest.mark.parametrize('name,kernel', SECOND_ORDER_CASES)
+def test_second_order_update_sweep(name, kernel, monkeypatch):
+    """kh_set_second_order + the update sweep (reference optimize.py:434-443, 451-452,
+    468-469, 492-500) in every kernel family vs the oracle: pulses, g_a, final and
+    stored states, with phi_prev from a different pulse so that Delta phi != 0."""
+    import torch
+
+    spec = SMALL[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    if kernel is not None:
+        monkeypatch.setenv('KH_KERNEL', kernel)
+    eng = _engine(spec)
+    pulses = np.array(gp)
+    rng = np.random.default_rng(5)
+    older = [p * (1.0 + 0.2 * rng.standard_normal(p.shape)) for p in gp]  # the "previous iteration"
+    _, prev = ko.forward_propagation(prob, older, store=True)
+    sigma_vals = -(1.0 + rng.random(len(spec.tlist) - 1))
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = 0.2 + rng.random(spec.K)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    chi = eng.backward(chi_T, pulses)
+    ref_opt, ref_psi, ref_ga, ref_store = ko.forward_update_sweep(
+        prob, ref_chi, norms, gp, S, lam, sigma_vals=sigma_vals, fw_prev=prev, store=True)
+    first_opt = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)[0]
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    assert np.abs(np.array(first_opt) - np.array(ref_opt)).max() > 1e-6 * scale  # the sigma term matters here
+    store = torch.full((spec.K, len(spec.tlist), spec.N), float('nan'), dtype=torch.complex128, device=eng.device)
+    eng.set_second_order(prev, store, sigma_vals)
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    tol = 1e-12
+    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < tol * scale
+    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < tol
+    assert np.abs(g_a.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
+    assert np.abs(store.cpu().numpy() - ref_store).max() < tol
+    # per-interval (multi-GPU) form
+    store.fill_(float('nan'))
+    opt2, psi2, _ = eng.forward_update_sharded(chi, norms, spec.init, pulses, np.array(S), np.array(lam),
+                                               lambda x: x)
+    assert np.abs(opt2.cpu().numpy() - np.array(ref_opt)).max() < tol * scale
+    assert np.abs(psi2.cpu().numpy() - ref_psi).max() < tol
+    assert np.abs(store.cpu().numpy() - ref_store).max() < tol
+    # and back to first order
+    eng.set_second_order()
+    opt1 = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))[0]
+    assert np.abs(opt1.cpu().numpy() - np.array(first_opt)).max() < tol * scale
+    from krotov_amd._lib import KrotovHipError
+
+    with pytest.raises(KrotovHipError):
+        eng.set_second_order(store, store, sigma_vals)
+    eng.close()
+
+
+def test_second_order_optimize_pulses_vs_reference_loop():
+    """optimize_pulses(sigma=...) on the GPU vs the reference's second-order loop
+    (tests/golden/ref_so_c3.npz) and the oracle; sigma.refresh sees the trajectories."""
+    from helpers import SigmaA, product_sigma
+
+    g = golden('ref_so_c3')
+    spec = configs.config_c3(nt=201)
+    spec.lambda_a = 20.0
+    sig = product_sigma(0.0, 2.0)
+    probe = {}
+
+    def hook(**kw):
+        if kw['iteration'] == 2:
+            probe['fw'] = np.array(kw['forward_states'][1][57])
+            probe['fw0'] = np.array(kw['forward_states0'][1][57])
+            probe['len'] = (len(kw['forward_states']), len(kw['forward_states'][0]))
+
+    res = _optimize_on_device(spec, int(g['iter_stop']), sigma=sig, info_hook=hook)
+    got = np.array([np.array(p) for p in res.all_pulses])
+    assert np.abs(got - g['all_pulses']).max() < 1e-9
+    assert np.abs(np.array(res.tau_vals) - g['tau_vals']).max() < 1e-9
+    assert np.abs(np.array(sig.history) - g['A_history']).max() < 1e-8
+    assert sig.calls == [(spec.K, len(spec.tlist), True)] * 2
+    osig = SigmaA(0.0, 2.0)
+    ref = oracle_optimize(spec, int(g['iter_stop']), sigma=osig)
+    assert np.abs(got - ref['all_pulses']).max() < 1e-12 * max(1.0, np.abs(ref['all_pulses']).max())
+    assert np.abs(np.array(res.tau_vals) - ref['tau_vals']).max() < 1e-12
+    # the trajectories handed to the hooks are those of iterations 2 and 1
+    prob = spec_to_oracle(spec)
+    assert probe['len'] == (spec.K, len(spec.tlist))
+    for key, pulses in (('fw', got[2]), ('fw0', got[1])):
+        want = ko.forward_propagation(prob, [pulses[0]], store=True)[1][1, 57]
+        assert np.abs(probe[key].reshape(-1) - want).max() < 1e-12
+
+
 GOLDEN_CASES = {
     'ref_c1_tls': lambda: configs.config_c1(),
     'ref_c2_hilbert': lambda: configs.config_c2_hilbert(),

@@ -206,3 +206,20 @@ def test_kat_oct_log_J_T_re():
         assert abs(got - want) < 0.006 * max(want, 1e-3) + 5e-3, (got, want)
     for got, want in zip(out['g_a'][1:, 0], [1.18e-01, 1.04e-01, 8.37e-02]):
         assert abs(got - want) < 0.006 * want
+
+
+def test_second_order_against_real_reference_loop():
+    """Second-order update (sigma term) vs the reference's loop: tests/golden/ref_so_c3.npz."""
+    from helpers import SigmaA
+
+    g = golden('ref_so_c3')
+    spec = configs.config_c3(nt=201)
+    spec.lambda_a = 20.0
+    sig = SigmaA(0.0, 2.0)
+    out = oracle_optimize(spec, int(g['iter_stop']), sigma=sig, use_scipy=False)
+    assert np.abs(out['all_pulses'] - g['all_pulses']).max() < 1e-12
+    assert np.abs(out['tau_vals'] - g['tau_vals']).max() < 1e-12
+    assert np.abs(np.array(sig.history[:2]) - g['A_history']).max() < 1e-11
+    # and it is not the first-order result
+    first = oracle_optimize(spec, 1)
+    assert np.abs(first['all_pulses'][1] - g['all_pulses'][1]).max() > 1e-3
