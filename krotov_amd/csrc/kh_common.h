@@ -90,6 +90,14 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// a wave-uniform double moved to scalar registers (frees its VGPR pair; VALU ops take it as an
+// SGPR operand)
+__device__ __forceinline__ double kh_uniform(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // full 64-lane sum, same value (and same summation order) in every lane
 __device__ __forceinline__ double sum64(double v) {
     v = sum16(v);

@@ -95,22 +95,80 @@ __device__ __forceinline__ int kh_tile_expm_action(const cplx (&a)[RPT][8], cplx
     return nsub * m;
 }
 
-template <int RPT, int LT>
-__device__ __forceinline__ void kh_tile_build_generator(const cplx (&h)[1 + LT][RPT][8], const double *eps,
-                                                         cplx (&a)[RPT][8]) {
+// The 1+LT operator tiles of one objective.  With more than three operators they do not all fit
+// in the register file next to the generator tile (32 VGPRs each at RPT = 1): the first NL of them
+// are parked in LDS instead, each lane's 8 elements at stride THREADS so a wave reads 64
+// consecutive 16-byte slots (no bank conflicts), and only the lane itself ever reads its slots
+// (no barrier needed after the fill).
+template <int RPT, int LT, int NL>
+struct KhTileOps {
+    static constexpr int THREADS = 512 / RPT;
+    cplx reg[1 + LT - NL][RPT][8];
+    cplx *lds;  // this lane's column of the LDS-resident tiles
+
+    __device__ __forceinline__ cplx at(int o, int r, int j) const {
+        if (o < NL) return lds[(size_t)((o * RPT + r) * 8 + j) * THREADS];
+        return reg[o < NL ? 0 : o - NL][r][j];
+    }
+    __device__ __forceinline__ void load(const cplx *const *ops_k, int N, int wave, int lane, cplx *lds_base,
+                                         int tid) {
+        lds = lds_base + tid;
 #pragma unroll
-    for (int r = 0; r < RPT; ++r)
+        for (int o = 0; o <= LT; ++o) {
+            if (o < NL) {
+                cplx t[RPT][8];
+                kh_tile_load_op<RPT>(ops_k[o], N, wave, lane, t);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            cplx v = h[0][r][j];
+                for (int r = 0; r < RPT; ++r)
 #pragma unroll
-            for (int l = 0; l < LT; ++l) {
-                v.x = fma(eps[l], h[1 + l][r][j].x, v.x);
-                v.y = fma(eps[l], h[1 + l][r][j].y, v.y);
+                    for (int j = 0; j < 8; ++j) lds[(size_t)((o * RPT + r) * 8 + j) * THREADS] = t[r][j];
+            } else {
+                kh_tile_load_op<RPT>(ops_k[o], N, wave, lane, reg[o < NL ? 0 : o - NL]);
             }
-            a[r][j] = v;
         }
-}
+    }
+    // a = op[0] + sum_l eps_l op[1+l]
+    __device__ __forceinline__ void build(const double *eps, cplx (&a)[RPT][8]) const {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                cplx v = at(0, r, j);
+#pragma unroll
+                for (int l = 0; l < LT; ++l) {
+                    const cplx hl = at(1 + l, r, j);
+                    v.x = fma(eps[l], hl.x, v.x);
+                    v.y = fma(eps[l], hl.y, v.y);
+                }
+                a[r][j] = v;
+            }
+    }
+    // y = op[o] x, reduced over the row's 8 lanes
+    __device__ __forceinline__ void matvec(int o, const cplx *x, int cg, cplx (&y)[RPT]) const {
+        cplx xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = x[cg + 8 * j];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            cplx acc = c_make(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c_fma(acc, at(o, r, j), xv[j]);
+            y[r].x = sum8(acc.x);
+            y[r].y = sum8(acc.y);
+        }
+    }
+};
+
+// operators parked in LDS: none up to three operators; for L = 3, 4 the update sweep parks L - 2
+// (it also keeps chi, the partial sums and, second order, phi_prev), the plain sweep one for L = 4
+template <int RPT, int LT>
+struct KhTileLds {
+    static constexpr int UPDATE = (RPT == 1 && LT >= 3) ? LT - 2 : 0;
+    static constexpr int STORE = (RPT == 1 && LT >= 4) ? 1 : 0;
+    static constexpr size_t bytes(int nl) { return (size_t)nl * KH_TILE_N * KH_TILE_N * sizeof(cplx); }
+};
+
+extern __shared__ __attribute__((aligned(16))) cplx kh_tile_dyn_lds[];
 
 // ---------------------------------------------------------------------------
 // plain propagation with storage (backward sweep / iteration-0 forward sweep)
@@ -132,9 +190,8 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
     for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
         const cplx *const *ops_k = p.ops + (size_t)k * (1 + LT);
         const double *norms_k = p.op_norms + (size_t)k * (1 + LT);
-        cplx h[1 + LT][RPT][8];
-#pragma unroll
-        for (int o = 0; o <= LT; ++o) kh_tile_load_op<RPT>(ops_k[o], N, wave, lane, h[o]);
+        KhTileOps<RPT, LT, KhTileLds<RPT, LT>::STORE> h;
+        h.load(ops_k, N, wave, lane, kh_tile_dyn_lds, tid);
         double nrm[1 + LT];
 #pragma unroll
         for (int o = 0; o <= LT; ++o) nrm[o] = norms_k[o];
@@ -182,7 +239,7 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
             kh_degree_lookup(theta * dt, deg_sh, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
             m_hint = m;
             cplx a[RPT][8];
-            kh_tile_build_generator<RPT, LT>(h, eps, a);
+            h.build(eps, a);
             matvecs += kh_tile_expm_action<RPT>(a, state, buf, inv_sh, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
             // buf[cur] now holds the new state: stream it to HBM, one coalesced 1 KiB store
             if (store != nullptr && wave == 0 && lane < N)
@@ -225,14 +282,13 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
 
     const cplx *const *ops_k = p.ops + (size_t)k * (1 + LT);
     const double *norms_k = p.op_norms + (size_t)k * (1 + LT);
-    cplx h[1 + LT][RPT][8];
-#pragma unroll
-    for (int o = 0; o <= LT; ++o) kh_tile_load_op<RPT>(ops_k[o], N, wave, lane, h[o]);
+    KhTileOps<RPT, LT, KhTileLds<RPT, LT>::UPDATE> h;
+    h.load(ops_k, N, wave, lane, kh_tile_dyn_lds, tid);
     double nrm[1 + LT];
 #pragma unroll
-    for (int o = 0; o <= LT; ++o) nrm[o] = norms_k[o];
+    for (int o = 0; o <= LT; ++o) nrm[o] = kh_uniform(norms_k[o]);
     // dH/d eps_l is the forward control operator itself (mu.py:123-134): h[1+l] serves both
-    const double chi_norm = u.chi_norms[k];
+    const double chi_norm = kh_uniform(u.chi_norms[k]);
 
     cplx state[RPT];
 #pragma unroll
@@ -272,7 +328,7 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
             cplx y[RPT];
-            kh_tile_matvec<RPT>(h[1 + l], buf[cur], cg, y);
+            h.matvec(1 + l, buf[cur], cg, y);
             cplx ov = c_make(0.0, 0.0);
             if (cg == 0) {
 #pragma unroll
@@ -322,12 +378,14 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     }
 
     // per-interval scalars, fetched one interval ahead
-    double dt_next = p.dt[u.n_begin], guess_next[LT], shape_next[LT], lam[LT];
+    // (wave-uniform values are kept in scalar registers: with L = 3, 4 the per-control scalars
+    // would otherwise cost ~60 VGPRs next to the operator tiles)
+    double dt_next = kh_uniform(p.dt[u.n_begin]), guess_next[LT], shape_next[LT], lam[LT];
 #pragma unroll
     for (int l = 0; l < LT; ++l) {
-        guess_next[l] = u.guess[(size_t)l * (nt - 1) + u.n_begin];
-        shape_next[l] = u.shape[(size_t)l * (nt - 1) + u.n_begin];
-        lam[l] = u.lambda[l];
+        guess_next[l] = kh_uniform(u.guess[(size_t)l * (nt - 1) + u.n_begin]);
+        shape_next[l] = kh_uniform(u.shape[(size_t)l * (nt - 1) + u.n_begin]);
+        lam[l] = kh_uniform(u.lambda[l]);
     }
     int m_hint = 12;
 
@@ -359,12 +417,13 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
             guess[l] = guess_next[l];
             shape[l] = shape_next[l];
         }
+        double dt_ld = 0.0, guess_ld[LT], shape_ld[LT];  // in flight across the barrier
         if (n + 1 < nt - 1) {
-            dt_next = p.dt[n + 1];
+            dt_ld = p.dt[n + 1];
 #pragma unroll
             for (int l = 0; l < LT; ++l) {
-                guess_next[l] = u.guess[(size_t)l * (nt - 1) + n + 1];
-                shape_next[l] = u.shape[(size_t)l * (nt - 1) + n + 1];
+                guess_ld[l] = u.guess[(size_t)l * (nt - 1) + n + 1];
+                shape_ld[l] = u.shape[(size_t)l * (nt - 1) + n + 1];
             }
         }
         __syncthreads();
@@ -376,8 +435,8 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         for (int l = 0; l < LT; ++l) {
             const double d1 = D_sh[par][l];
             const double step = shape[l] / lam[l];
-            eps[l] = guess[l] + step * d1;
-            g_a_loc[l] += step * (d1 * d1) * dt;
+            eps[l] = kh_uniform(guess[l] + step * d1);
+            g_a_loc[l] = kh_uniform(g_a_loc[l] + step * (d1 * d1) * dt);
             theta += fabs(eps[l]) * nrm[1 + l];
         }
         if (k == 0 && tid == 0) {
@@ -389,11 +448,19 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         kh_degree_lookup(theta * dt, deg_sh, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         cplx a[RPT][8];
-        kh_tile_build_generator<RPT, LT>(h, eps, a);
+        h.build(eps, a);
         if constexpr (SO) {
             if (wave == 0 && lane < N) u.fw_store[((size_t)k * nt + n) * N + lane] = buf[cur][lane];
         }
         matvecs += kh_tile_expm_action<RPT>(a, state, buf, inv_sh, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
+        if (n + 1 < nt - 1) {
+            dt_next = kh_uniform(dt_ld);
+#pragma unroll
+            for (int l = 0; l < LT; ++l) {
+                guess_next[l] = kh_uniform(guess_ld[l]);
+                shape_next[l] = kh_uniform(shape_ld[l]);
+            }
+        }
         // ---- partial sums of the next interval (state is in buf[cur], barrier passed) ----
         if (n + 1 < nt - 1) {
             partial_pieces((n + 1) & 1);

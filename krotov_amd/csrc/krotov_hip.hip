@@ -313,7 +313,13 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
 template <int RPT, int LT>
 static void launch_tile_store(const kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in,
                               cplx *store, cplx *out, int direction, hipStream_t st) {
-    kh_tile_sweep_store<RPT, LT><<<e->K, 512 / RPT, 0, st>>>(p, pulses, in, store, out, direction);
+    constexpr size_t lds = KhTileLds<RPT, LT>::bytes(KhTileLds<RPT, LT>::STORE);
+    if constexpr (lds != 0) {  // operator tiles parked in LDS: more than the default dynamic limit
+        static const hipError_t attr = hipFuncSetAttribute(
+            (const void *)kh_tile_sweep_store<RPT, LT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr;
+    }
+    kh_tile_sweep_store<RPT, LT><<<e->K, 512 / RPT, lds, st>>>(p, pulses, in, store, out, direction);
 }
 
 template <int RPT>
@@ -375,10 +381,19 @@ extern "C" int kh_backward_store(kh_engine *e, const kh_cdouble *chi_T_dev, cons
 template <int RPT, int LT>
 static void launch_tile_update(const kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u, const KhExchange &ex,
                                hipStream_t st) {
+    constexpr size_t lds = KhTileLds<RPT, LT>::bytes(KhTileLds<RPT, LT>::UPDATE);
+    if constexpr (lds != 0) {
+        static const hipError_t attr1 = hipFuncSetAttribute(
+            (const void *)kh_tile_forward_update<RPT, LT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static const hipError_t attr0 = hipFuncSetAttribute(
+            (const void *)kh_tile_forward_update<RPT, LT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr1;
+        (void)attr0;
+    }
     if (u.sigma != nullptr)
-        kh_tile_forward_update<RPT, LT, true><<<e->K, 512 / RPT, 0, st>>>(p, u, ex);
+        kh_tile_forward_update<RPT, LT, true><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
     else
-        kh_tile_forward_update<RPT, LT, false><<<e->K, 512 / RPT, 0, st>>>(p, u, ex);
+        kh_tile_forward_update<RPT, LT, false><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
 }
 
 static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
