@@ -32,7 +32,7 @@ struct KhQ2Lds {
     cplx (*buf)[KH_TILE_N];  // [2][64]
     double *red; // [2][8 waves][2]
     double *D;   // [2][2]
-    double2 *inv2;  // [KH_MAX_DEGREE/2] {1/(2p+1), 1/(2p+2)} (LDS copy: no SMEM loads in the phase loop)
+    double2 *inv2;  // [KH_MAX_DEGREE/2] {1/(2p+1), 1/((2p+1)(2p+2))} (LDS: no SMEM loads in the phase loop)
     double *deg;    // [KH_MAX_DEGREE+1] copy of the degree-threshold table
 };
 
@@ -102,15 +102,15 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
                                                  double dt, int nsub, int m, int wave, int lane) {
     const int cg = lane & 7, row = wave * 8 + (lane >> 3);
     const double h = nsub == 1 ? dt : dt / nsub;
-    const double f2 = fre * fre - fim * fim;  // f is purely real or purely imaginary
+    const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
     const int phases = (m + 1) >> 1;
     for (int sub = 0; sub < nsub; ++sub) {
-        cplx sA = c_make(0.0, 0.0);  // this lane's share of the odd-term sum
+        // this lane's share of sum_p h/(2p+1) A t_2p: the odd-term sum without its factor f
+        cplx sA = c_make(0.0, 0.0);
         for (int ph = 0; ph < phases; ++ph) {
-            const double2 iv = inv2[ph];
+            const double2 iv = inv2[ph];  // {1/(2p+1), 1/((2p+1)(2p+2))}
             const double hj1 = h * iv.x;
-            const cplx c1 = c_make(fre * hj1, fim * hj1);
-            const double c2 = f2 * hj1 * (h * iv.y);
+            const double c2 = f2h2 * iv.y;
             cplx xv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[j] = buf[cur][cg + 8 * j];
@@ -132,10 +132,12 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
             cplx ya = c_make(0.0, 0.0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) c_fma(ya, a[j], xv[j]);
-            c_fma(sA, c1, ya);
+            sA.x = fma(hj1, ya.x, sA.x);
+            sA.y = fma(hj1, ya.y, sA.y);
             if (last) {
-                state.x += sum8(sA.x);
-                state.y += sum8(sA.y);
+                const cplx odd = c_mul(c_make(fre, fim), c_make(sum8(sA.x), sum8(sA.y)));
+                state.x += odd.x;
+                state.y += odd.y;
                 if (cg == 0) buf[cur ^ 1][row] = c_make(state.x, state.y);
             }
             __syncthreads();
@@ -156,7 +158,7 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KhQ2Lds s = kh_q2_carve(smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
-    if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / (2 * tid + 2));
+    if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / ((2.0 * tid + 1) * (2 * tid + 2)));
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     const int row = wave * 8 + (lane >> 3);
     const int N = p.N, nt = p.nt;
@@ -223,7 +225,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     double(*red)[8][2] = (double(*)[8][2])s.red;  // [parity][wave][re, im]
     double(*D_sh)[2] = (double(*)[2])s.D;         // [parity][value, ok]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
-    if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / (2 * tid + 2));
+    if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / ((2.0 * tid + 1) * (2 * tid + 2)));
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     const int row = wave * 8 + (lane >> 3);
     const int N = p.N, nt = p.nt;
