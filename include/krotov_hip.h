@@ -218,6 +218,20 @@ int kh_p2p_disable(kh_engine *engine);
 int kh_tau(kh_engine *engine, const kh_cdouble *targets_dev,
            const kh_cdouble *psi_T_dev, kh_cdouble *tau_dev, void *stream);
 
+/* Boundary co-states of the built-in functionals, normalised for the backward
+ * sweep: v_k = c_k target_k + d_k psi_k(T), chi_T[k] = v_k / ||v_k||_2,
+ * chi_norms[k] = ||v_k||_2.  Replaces the chi_constructor call and the
+ * normalisation of optimize.py:396-410 for krotov.functionals.chis_re /
+ * chis_ss / chis_sm / chis_hs (functionals.py:177-197, 225-253, 293-317,
+ * 389-437), whose per-objective scalars (c_k, d_k) the host derives from
+ * tau and the objective weights: re (w/2K, 0), ss (tau_k w/K, 0),
+ * sm (w/K^2 sum_j w_j tau_j, 0), hs (w/2K, -w/2K).  All arrays on the device:
+ * targets, psi_T, chi_T [K][N]; c, d [K] complex; chi_norms [K]. */
+int kh_chi_boundary(kh_engine *engine, const kh_cdouble *targets_dev,
+                    const kh_cdouble *psi_T_dev, const kh_cdouble *c_dev,
+                    const kh_cdouble *d_dev, kh_cdouble *chi_T_dev,
+                    double *chi_norms_dev, void *stream);
+
 /* After synchronising the stream: returns KH_ERR_TIMEOUT if an in-kernel
  * exchange gave up since the last call (outputs are then invalid), else 0. */
 int kh_check(kh_engine *engine);

@@ -52,6 +52,7 @@ SYMBOLS = {
     'kh_p2p_selftest': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'kh_p2p_disable': (ctypes.c_int, [_P]),
     'kh_tau': (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    'kh_chi_boundary': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     'kh_check': (ctypes.c_int, [_P]),
     'kh_last_stats': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double)]),
 }

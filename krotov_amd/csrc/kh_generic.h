@@ -369,6 +369,33 @@ __global__ void kh_tau_kernel(const cplx *__restrict__ targets, const cplx *__re
     if (lane == 0) tau[k] = c_make(re, im);
 }
 
+// chi_k(T) of the built-in functionals (functionals.py:177-197, 225-253, 293-317, 389-437) is a
+// linear combination of the target and the propagated state with per-objective scalars:
+//   v_k = c_k target_k + d_k psi_k(T);   out_k = v_k / ||v_k||_2,  norms[k] = ||v_k||_2
+// (optimize.py:407-410; a zero v_k gives NaN like the reference's unguarded division).
+// One wave per objective, fixed summation order.
+__global__ void kh_chi_kernel(const cplx *__restrict__ targets, const cplx *__restrict__ psi,
+                              const cplx *__restrict__ c, const cplx *__restrict__ d, cplx *__restrict__ out,
+                              double *__restrict__ norms, int K, int N) {
+    const int k = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    const cplx ck = c[k], dk = d[k];
+    double acc = 0.0;
+    for (int i = lane; i < N; i += 64) {
+        cplx v = c_mul(ck, targets[(size_t)k * N + i]);
+        c_fma(v, dk, psi[(size_t)k * N + i]);
+        acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+    }
+    const double nrm = sqrt(sum64(acc));
+    for (int i = lane; i < N; i += 64) {
+        cplx v = c_mul(ck, targets[(size_t)k * N + i]);
+        c_fma(v, dk, psi[(size_t)k * N + i]);
+        out[(size_t)k * N + i] = c_make(v.x / nrm, v.y / nrm);
+    }
+    if (lane == 0) norms[k] = nrm;
+}
+
 // Frobenius norms of the operators (fallback when the caller gives no bounds)
 __global__ void kh_fro_norms(const cplx *const *ops, int count, int N, double *norms) {
     const int idx = blockIdx.x;

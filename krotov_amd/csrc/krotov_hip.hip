@@ -719,6 +719,21 @@ extern "C" int kh_tau(kh_engine *e, const kh_cdouble *targets_dev, const kh_cdou
     return KH_OK;
 }
 
+extern "C" int kh_chi_boundary(kh_engine *e, const kh_cdouble *targets_dev, const kh_cdouble *psi_T_dev,
+                               const kh_cdouble *c_dev, const kh_cdouble *d_dev, kh_cdouble *chi_T_dev,
+                               double *chi_norms_dev, void *stream) {
+    if (e == nullptr || targets_dev == nullptr || psi_T_dev == nullptr || c_dev == nullptr || d_dev == nullptr ||
+        chi_T_dev == nullptr || chi_norms_dev == nullptr)
+        return kh_fail(KH_ERR_INVALID, "null argument");
+    const int waves_per_block = 4;
+    const int blocks = (e->K + waves_per_block - 1) / waves_per_block;
+    kh_chi_kernel<<<blocks, 64 * waves_per_block, 0, (hipStream_t)stream>>>(
+        (const cplx *)targets_dev, (const cplx *)psi_T_dev, (const cplx *)c_dev, (const cplx *)d_dev,
+        (cplx *)chi_T_dev, chi_norms_dev, e->K, e->N);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
 extern "C" int kh_check(kh_engine *e) {
     if (e == nullptr) return kh_fail(KH_ERR_INVALID, "null engine");
     unsigned int flag = 0;

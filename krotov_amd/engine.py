@@ -391,6 +391,20 @@ class HipKrotovEngine:
         _lib.check(self._lib.kh_tau(self._handle, targets.data_ptr(), psi_T.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
+    def chi_boundary(self, targets, psi_T, c, d):
+        """Normalised boundary co-states ``(c_k target_k + d_k psi_k(T)) / ||.||`` and
+        their norms, ``(K, N)`` and ``(K,)`` device tensors (kh_chi_boundary)."""
+        targets = self._c(targets, (self.K, self.N))
+        psi_T = self._c(psi_T, (self.K, self.N))
+        c = self._c(c, (self.K,))
+        d = self._c(d, (self.K,))
+        chi = torch.empty((self.K, self.N), dtype=torch.complex128, device=self.device)
+        norms = torch.empty((self.K,), dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.kh_chi_boundary(
+            self._handle, targets.data_ptr(), psi_T.data_ptr(), c.data_ptr(), d.data_ptr(), chi.data_ptr(),
+            norms.data_ptr(), self._stream()))
+        return chi, norms
+
     def check(self):
         """Synchronise and raise if an in-kernel exchange timed out."""
         torch.cuda.synchronize(self.device)

@@ -5,9 +5,11 @@ src/krotov/functionals.py:82-437): a ``chi_constructor`` receives
 ``fw_states_T``, ``objectives``, ``tau_vals`` and returns one co-state per
 objective.  They run once per iteration on K states (O(K N) work).
 
-When every objective's states are plain vectors the optimiser evaluates the
-four constructors below in stacked (K, N) array form (:func:`chi_stacked`),
-avoiding a K-long Python loop; the list forms are what user code calls.
+On the device path the optimiser does not call the four constructors below: each
+is ``chi_k = c_k target_k + d_k phi_k(T)`` with per-objective scalars
+(:func:`chi_coefficients`) and is formed and normalised in HBM by
+``kh_chi_boundary``.  :func:`chi_stacked` is the same thing as a (K, N) array
+expression on the host; the list forms are what user code calls.
 """
 import numpy as np
 
@@ -150,4 +152,29 @@ def chi_stacked(chi_constructor, targets, weights, fw_T, tau):
         return ((1.0 / K**2) * w)[:, None] * targets * s
     if chi_constructor is chis_hs:
         return ((1.0 / (2 * K)) * w)[:, None] * (targets - fw_T)
+    return None
+
+
+def chi_coefficients(chi_constructor, weights, tau, K):
+    """Per-objective scalars ``(c, d)`` with ``chi_k = c_k target_k + d_k phi_k(T)``
+    for the four constructors above (None for any other ``chi_constructor``):
+    what the device-side co-state construction (``kh_chi_boundary``) needs from
+    the host.  ``weights``: (K,) or None; ``tau``: (K,) complex or None."""
+    w = np.ones(K) if weights is None else np.asarray(weights, dtype=np.float64)
+    zero = np.zeros(K, dtype=np.complex128)
+    if chi_constructor is chis_re:
+        return ((1.0 / (2 * K)) * w).astype(np.complex128), zero
+    if chi_constructor is chis_hs:
+        c = ((1.0 / (2 * K)) * w).astype(np.complex128)
+        return c, -c
+    if tau is None or any(t is None for t in tau):
+        return None
+    tau = np.asarray(tau, dtype=np.complex128)
+    if chi_constructor is chis_ss:
+        return (tau / K) * w, zero
+    if chi_constructor is chis_sm:
+        s = 0
+        for wk, t in zip(w, tau):
+            s += wk * t
+        return ((1.0 / K**2) * w) * s, zero
     return None

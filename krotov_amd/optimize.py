@@ -300,12 +300,21 @@ class _PluginBackend:
 
 
 class _LazyStates:
-    """List-like view of per-objective states held as one (K, N) host array;
+    """List-like view of per-objective states held as one (K, N) array -- on the
+    host, or still on the device and fetched on first access (``fetch``);
     elements are converted to the caller's state type on access."""
 
-    def __init__(self, array, likes):
-        self._array = array
+    def __init__(self, array, likes, fetch=None):
+        self._host = array
+        self._fetch = fetch
         self._likes = likes
+
+    @property
+    def _array(self):
+        if self._host is None:
+            self._host = self._fetch()
+            self._fetch = None
+        return self._host
 
     def __len__(self):
         return len(self._likes)
@@ -483,7 +492,7 @@ class _HipBackend:
         self.chi_store = None
         self.fw_T_dev = None
         self.fw_prev = self.fw_next = None  # second order: phi(t_n) of the last / the running iteration
-        self.fw_prev_T = None
+        self.last_chi = None
         # device-side exchange over peer-mapped windows (xGMI) when every rank can set it up;
         # otherwise (or after a failed sweep) one RCCL all-reduce per interval
         self.p2p = False
@@ -506,14 +515,10 @@ class _HipBackend:
             self.fw_T_dev, self.fw_prev = self.engine.forward(self._pulses(pulses), self.init, store=True)
         else:
             self.fw_T_dev = self.engine.forward(self._pulses(pulses), self.init)
-        fw_T = self._gather_rows(self.fw_T_dev.cpu().numpy())
+        fw_states_T = self._final_states(self.fw_T_dev)
         if store:
-            self.fw_prev_T = fw_T
-            forward_states = _DeviceTrajectories(self.fw_prev, self.likes, self.k0, final=fw_T)
-        return _LazyStates(fw_T, self.likes), forward_states
-
-    def fw_T_host(self, fw_states_T):
-        return fw_states_T._array if isinstance(fw_states_T, _LazyStates) else None
+            forward_states = _DeviceTrajectories(self.fw_prev, self.likes, self.k0, final=fw_states_T._array)
+        return fw_states_T, forward_states
 
     def tau_vals(self, fw_states_T):
         if self.targets is None:
@@ -521,8 +526,23 @@ class _HipBackend:
         tau = self.engine.tau(self.targets, self.fw_T_dev).cpu().numpy()
         return self._gather_rows(tau)
 
-    def iterate(self, chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays, sigma=None):
-        """chi_T: (K_total, N) normalised co-states (host); chi_norms (K_total,)."""
+    def _final_states(self, psi_T):
+        """phi_k(T) of all objectives for the caller: gathered now when sharded (a
+        collective), else left on the device until somebody looks at them."""
+        if self.world > 1:
+            return _LazyStates(self._gather_rows(psi_T.cpu().numpy()), self.likes)
+        return _LazyStates(None, self.likes, fetch=lambda: psi_T.cpu().numpy())
+
+    def chi_host(self):
+        """Normalised chi_k(T) and their norms of the last iteration, all objectives, on
+        the host (only the second-order ``sigma.refresh`` needs them)."""
+        chi, norms = self.last_chi
+        return self._gather_rows(chi.cpu().numpy()), self._gather_rows(norms.cpu().numpy())
+
+    def iterate(self, chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays, sigma=None, chi_coef=None):
+        """chi_T: (K_total, N) normalised co-states (host); chi_norms (K_total,) -- or
+        ``chi_coef = (c, d)``, (K_total,) each: chi_k(T) = c_k target_k + d_k phi_k(T) is
+        then formed and normalised on the device (kh_chi_boundary)."""
         t = self.torch
         eng = self.engine
         guess = self._pulses(guess_pulses)
@@ -534,8 +554,14 @@ class _HipBackend:
             if self.fw_next is None:
                 self.fw_next = t.empty_like(self.fw_prev)
             eng.set_second_order(self.fw_prev, self.fw_next, sig)
-        chi_loc = eng.dev(chi_T[self.k0:self.k1], t.complex128)
-        norms_loc = eng.dev(np.asarray(chi_norms, dtype=np.float64)[self.k0:self.k1], t.float64)
+        if chi_coef is not None:
+            c, d = chi_coef
+            psi = self.fw_T_dev if self.fw_T_dev is not None else self.init  # (d == 0 without phi(T))
+            chi_loc, norms_loc = eng.chi_boundary(self.targets, psi, c[self.k0:self.k1], d[self.k0:self.k1])
+        else:
+            chi_loc = eng.dev(chi_T[self.k0:self.k1], t.complex128)
+            norms_loc = eng.dev(np.asarray(chi_norms, dtype=np.float64)[self.k0:self.k1], t.float64)
+        self.last_chi = (chi_loc, norms_loc)
         self.chi_store = eng.backward(chi_loc, guess, out=self.chi_store)
         shapes = eng.dev(np.array(shape_arrays, dtype=np.float64).reshape(self.L, self.nt - 1), t.float64)
         lambdas = eng.dev(np.asarray(lambda_vals, dtype=np.float64), t.float64)
@@ -570,14 +596,14 @@ class _HipBackend:
                 self.chi_store, norms_loc, self.init, guess, shapes, lambdas, all_reduce, graph_chunk=chunk)
         self.fw_T_dev = psi_T
         eng.check()
-        fw_T = self._gather_rows(psi_T.cpu().numpy())
+        fw_states_T = self._final_states(psi_T)
         opt_host = opt.cpu().numpy()
         optimized = [opt_host[l].copy() for l in range(self.L)]
         backward_states = _DeviceTrajectories(self.chi_store, self.likes, self.k0)
         forward_states = None
         if sigma is not None:
-            forward_states = _DeviceTrajectories(self.fw_next, self.likes, self.k0, final=fw_T)
-        return backward_states, optimized, _LazyStates(fw_T, self.likes), g_a.cpu().numpy(), forward_states
+            forward_states = _DeviceTrajectories(self.fw_next, self.likes, self.k0, final=fw_states_T._array)
+        return backward_states, optimized, fw_states_T, g_a.cpu().numpy(), forward_states
 
     def advance_second_order(self):
         """The stored trajectory of the finished iteration becomes ``forward_states0``
@@ -754,19 +780,16 @@ def optimize_pulses(
         logger.info("Started Krotov iteration %d", krotov_iteration)
         tic = time.time()
 
-        chi_T = None
-        if device_path:
-            # stacked form of the built-in functionals: no K-long Python loop
-            fw_host = backend.fw_T_host(fw_states_T)
-            if (
-                default_norm
-                and backend.targets_host is not None
-                and (fw_host is not None or chi_constructor is _functionals.chis_re)
-            ):
-                chi_T = _functionals.chi_stacked(
-                    chi_constructor, backend.targets_host, backend.weights, fw_host, tau_vals
-                )
-        if chi_T is None:
+        chi_T = chi_coef = None
+        if device_path and default_norm and backend.targets is not None:
+            # built-in functionals: chi_k(T) is formed and normalised on the device from K scalars
+            # (no K-long Python loop, phi_k(T) and chi_k(T) stay in HBM)
+            if backend.fw_T_dev is not None or chi_constructor is _functionals.chis_re:
+                chi_coef = _functionals.chi_coefficients(
+                    chi_constructor, backend.weights, tau_vals, len(objectives))
+        if chi_coef is not None:
+            chi_states = chi_norms = None
+        else:
             chi_states = chi_constructor(fw_states_T=fw_states_T, objectives=objectives, tau_vals=tau_vals)
             chi_norms = [norm(chi) for chi in chi_states]
             chi_states = [chi / nrm for chi, nrm in zip(chi_states, chi_norms)]
@@ -775,16 +798,11 @@ def optimize_pulses(
                 if any(v is None for v in vecs):
                     raise ValueError("chi_constructor returned states that do not match the state dimension")
                 chi_T = np.array(vecs)
-        else:
-            # default norm on vectors: L2 (any norm gives the same update; optimize.py:407-410, 467)
-            chi_norms = np.linalg.norm(chi_T, axis=1)
-            chi_T = chi_T / chi_norms[:, None]
-            chi_states = None
 
         g_a_integrals[:] = 0.0
         if device_path:
             backward_states, optimized_pulses, fw_states_T, g_a, forward_states = backend.iterate(
-                chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays, sigma=sigma
+                chi_T, chi_norms, guess_pulses, lambda_vals, shape_arrays, sigma=sigma, chi_coef=chi_coef
             )
         else:
             backward_states, optimized_pulses, fw_states_T, g_a, forward_states = backend.iterate(
@@ -828,7 +846,8 @@ def optimize_pulses(
             break
         guess_pulses = optimized_pulses
         if second_order:
-            if chi_states is None:  # stacked co-states of the device path, in the caller's state type
+            if chi_states is None:  # co-states formed on the device, in the caller's state type
+                chi_T, chi_norms = backend.chi_host()
                 chi_states = _LazyStates(chi_T, backend.likes)
             sigma.refresh(
                 forward_states=forward_states, forward_states0=forward_states0, chi_states=chi_states,

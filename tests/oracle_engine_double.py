@@ -95,6 +95,15 @@ class OracleEngineDouble:
         p = self.dev(psi_T, torch.complex128).numpy()
         return torch.from_numpy(np.array([np.vdot(a, b) for a, b in zip(t, p)]))
 
+    def chi_boundary(self, targets, psi_T, c, d):
+        t = self.dev(targets, torch.complex128).numpy()
+        p = self.dev(psi_T, torch.complex128).numpy()
+        c = self.dev(c, torch.complex128).numpy()
+        d = self.dev(d, torch.complex128).numpy()
+        v = c[:, None] * t + d[:, None] * p
+        norms = np.linalg.norm(v, axis=1)
+        return torch.from_numpy(v / norms[:, None]), torch.from_numpy(norms)
+
     def check(self):
         pass
 

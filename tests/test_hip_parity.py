@@ -204,6 +204,29 @@ def test_second_order_optimize_pulses_vs_reference_loop():
         assert np.abs(probe[key].reshape(-1) - want).max() < 1e-12
 
 
+@pytest.mark.parametrize('name', ['re', 'ss', 'sm', 'hs'])
+def test_boundary_costates_on_device(name):
+    """kh_chi_boundary vs the host form of krotov.functionals.chis_* (reference
+    functionals.py:177-437) + the normalisation of optimize.py:407-410."""
+    from krotov_amd import functionals
+
+    spec = configs.config_c5(K=7, N=33, nt=5)
+    rng = np.random.default_rng(11)
+    eng = _engine(spec)
+    fw = rng.standard_normal((spec.K, spec.N)) + 1j * rng.standard_normal((spec.K, spec.N))
+    fw /= np.linalg.norm(fw, axis=1)[:, None]
+    weights = 0.5 + rng.random(spec.K)
+    tau = np.array([np.vdot(spec.target[k], fw[k]) for k in range(spec.K)])
+    fn = getattr(functionals, 'chis_' + name)
+    want = functionals.chi_stacked(fn, spec.target, weights, fw, tau)
+    norms = np.linalg.norm(want, axis=1)
+    c, d = functionals.chi_coefficients(fn, weights, tau, spec.K)
+    chi, got_norms = eng.chi_boundary(spec.target, fw, c, d)
+    assert np.abs(got_norms.cpu().numpy() - norms).max() < 1e-15
+    assert np.abs(chi.cpu().numpy() - want / norms[:, None]).max() < 1e-15
+    eng.close()
+
+
 GOLDEN_CASES = {
     'ref_c1_tls': lambda: configs.config_c1(),
     'ref_c2_hilbert': lambda: configs.config_c2_hilbert(),

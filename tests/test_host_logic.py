@@ -111,11 +111,18 @@ def test_functionals_known_answers():
         listed = np.array(fn(fw, objs, taus))
         stacked = functionals.chi_stacked(fn, np.array([o.target for o in objs]), None, np.array(fw), taus)
         assert np.abs(listed - stacked).max() < 1e-15, name
+        c, d = functionals.chi_coefficients(fn, None, taus, 2)  # what kh_chi_boundary is fed
+        combined = c[:, None] * np.array([o.target for o in objs]) + d[:, None] * np.array(fw)
+        assert np.abs(listed - combined).max() < 1e-15, name
+    assert functionals.chi_coefficients(functionals.chis_ss, None, [None, None], 2) is None
+    assert functionals.chi_coefficients(lambda **kw: None, None, taus, 2) is None
     objs[0].weight, objs[1].weight = 0.5, 1.5
     listed = np.array(functionals.chis_sm(None, objs, taus))
     stacked = functionals.chi_stacked(functionals.chis_sm, np.array([o.target for o in objs]),
                                       np.array([0.5, 1.5]), None, taus)
     assert np.abs(listed - stacked).max() < 1e-15
+    c, d = functionals.chi_coefficients(functionals.chis_sm, np.array([0.5, 1.5]), taus, 2)
+    assert np.abs(listed - c[:, None] * np.array([o.target for o in objs])).max() < 1e-15 and not d.any()
 
 
 def test_overlap_and_mu():
