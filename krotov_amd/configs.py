@@ -247,6 +247,35 @@ def config_c4(d=20, nt=1001, n_logical=4, gamma=1e-3):
     )
 
 
+def config_shared(K=20, N=96, nt=21, L=2, seed=3):
+    """K state-to-state objectives under ONE operator list (the ``gate_objectives``
+    pattern: same H, different basis states), Hilbert dimension N > 64, L controls:
+    the shared-operator (dense product) case of BASELINE config 4 in Hilbert space.
+    ``||H0|| dt = 0.4``, ``||H_l|| dt = 0.1``."""
+    rng = np.random.default_rng(seed)
+    T = (nt - 1) / 4000.0
+    dt = T / (nt - 1)
+    H0 = herm(rng, N, 0.4 / dt)
+    Hl = [herm(rng, N, 0.1 / dt) for _ in range(L)]
+    init = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
+    init /= np.linalg.norm(init, axis=1)[:, None]
+    target = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
+    target /= np.linalg.norm(target, axis=1)[:, None]
+
+    def make_guess(l):
+        return lambda t, args: 0.5 * np.sin((l + 1) * np.pi * t / T)
+
+    def S(t):
+        return _shapes.flattop(t, t_start=0.0, t_stop=T, t_rise=0.05 * T, func='sinsq')
+
+    return ProblemSpec(
+        name='shared_K%d_N%d_L%d' % (K, N, L),
+        H0=[H0] * K, Hc=[list(Hl)] * K, is_super=False, init=init, target=target,
+        tlist=np.linspace(0, T, nt), controls=[make_guess(l) for l in range(L)], update_shape=S,
+        lambda_a=2.0, chi='re',
+    )
+
+
 # --------------------------------------------------------------------------
 # C5: robustness ensemble (the headline configuration)
 # --------------------------------------------------------------------------

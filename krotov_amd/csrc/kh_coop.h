@@ -1,0 +1,396 @@
+// Cooperative sweep kernels for objectives that SHARE one operator list and whose state dimension
+// is too large for a register tile (64 < N <= 512): BASELINE config 4, 16 density matrices
+// under one 400 x 400 Liouvillian.
+//
+// With shared operators one Taylor term for all objectives is a genuine dense product
+//     W (N x K)  =  A (N x N)  .  T (N x K),        A = op_0 + sum_l eps_l op_l,
+// so it goes to the fp64 matrix cores: v_mfma_f64_16x16x4_f64, M = 16 rows of A, N = 16 objectives,
+// complex arithmetic as four real products accumulated in two accumulators.
+//
+// Decomposition: workgroup (g, y) owns rows [16 g, 16 g + 16) of A and objectives [16 y, 16 y + 16).
+// Its 8 waves split the k range (4 ks values each); the A fragments stay in LDS for a whole time
+// interval (lane-linear: every lane reads back only what it wrote), the 8 partial 16 x 16 blocks
+// are summed through LDS.  Every Taylor term needs the
+// whole previous term, i.e. the blocks of all row workgroups: they are exchanged through a
+// double-buffered N x 16 block in global memory made of epoch-tagged 8-byte granules
+// {epoch:32 | half of a double:32} written and read with relaxed agent-scope atomics -- the data
+// is its own "ready" flag, so a round costs ONE memory round trip instead of data + flag.
+// A workgroup can be at most one round ahead of the slowest reader (it needs everybody's block of
+// round r before it can publish r + 1), so the buffer of parity r + 2 is free when written.
+//
+// All workgroups must be co-resident (grid = ceil(N/16) x ceil(K/16) <= number of CUs); spins are
+// bounded by the exchange timeout and raise the engine's abort flag.
+#pragma once
+
+#include "kh_common.h"
+#include "kh_generic.h"
+
+#define KH_COOP_THREADS 512
+#define KH_COOP_WAVES 8
+#define KH_COOP_COLS 16
+#define KH_COOP_OWNERS 256  // threads 0..255 own one element (row r = tid/16, column tid%16) of the block
+#define KH_COOP_MAX_L 2     // controls (the update-sum exchange keeps 16 registers per control in flight)
+
+typedef double kh_d4 __attribute__((ext_vector_type(4)));
+
+struct KhCoopArgs {
+    kh_u64 *vbuf;             // [2][Y][G*16][16][4] granules
+    unsigned int epoch_base;  // rounds of earlier launches (tags are monotonic: the buffer is never cleared)
+    int G, Y;                 // row blocks, column groups
+    int ks;                   // k-steps (of 4 columns) per wave: 32 * ks >= N
+};
+
+struct KhCoopLds {
+    double part[KH_COOP_WAVES][8][64];     // per-wave partial blocks (re: regs 0-3, im: 4-7)
+    double red[2][4][KH_COOP_MAX_L];       // owner waves' pieces of the update sums, by interval parity
+    double D[2][KH_COOP_MAX_L + 1];        // reduced sums + ok flag, by interval parity
+    double deg[KH_MAX_DEGREE + 2];
+    int abort;
+    int pad;
+    double frag[1];  // [ks][2][KH_COOP_THREADS] operator fragment of the current interval (dynamic size)
+};
+
+__host__ __device__ inline size_t kh_coop_lds_bytes(int ks) {
+    return sizeof(KhCoopLds) + sizeof(double) * 2 * (size_t)ks * KH_COOP_THREADS;
+}
+
+// A thread's view of the fragment: element q is {re, im} at f[(2 q) T], f[(2 q + 1) T]
+struct KhCoopFrag {
+    double *f;  // s.frag + tid
+    __device__ __forceinline__ double &re(int q) const { return f[(size_t)(2 * q) * KH_COOP_THREADS]; }
+    __device__ __forceinline__ double &im(int q) const { return f[(size_t)(2 * q + 1) * KH_COOP_THREADS]; }
+};
+
+// rows rowbase + (lane & 15), columns (wave ks + q) 4 + (lane >> 4): the MFMA A-operand layout
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_load_frag(const cplx *op, int N, int rowbase, int wave, int lane, int ks,
+                                                  const KhCoopFrag &f) {
+    const int row = rowbase + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q) {
+        if (q < ks) {
+            const int col = (wave * ks + q) * 4 + (lane >> 4);
+            cplx v = c_make(0.0, 0.0);
+            if (op != nullptr && row < N && col < N) v = op[(size_t)row * N + col];
+            f.re(q) = v.x;
+            f.im(q) = v.y;
+        }
+    }
+}
+
+// a += eps * op  (same fragment layout)
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_axpy_frag(const cplx *op, double eps, int N, int rowbase, int wave, int lane,
+                                                  int ks, const KhCoopFrag &a) {
+    const int row = rowbase + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q) {
+        const int col = (wave * ks + q) * 4 + (lane >> 4);
+        if (q < ks && op != nullptr && row < N && col < N) {
+            const cplx v = op[(size_t)row * N + col];
+            a.re(q) = fma(eps, v.x, a.re(q));
+            a.im(q) = fma(eps, v.y, a.im(q));
+        }
+    }
+}
+
+__device__ __forceinline__ kh_u64 *kh_coop_slot(const KhCoopArgs &c, unsigned int rid, int y, int row, int col) {
+    return c.vbuf + ((((size_t)(rid & 1u) * c.Y + y) * ((size_t)c.G * 16) + row) * KH_COOP_COLS + col) * 4;
+}
+
+// owner thread: element (row, col) of round `rid`
+__device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned int rid, int y, int row, int col,
+                                                cplx v) {
+    kh_u64 *g = kh_coop_slot(c, rid, y, row, col);
+    const kh_u64 tag = (kh_u64)(c.epoch_base + rid) << 32;
+    const kh_u64 re = (kh_u64)__double_as_longlong(v.x), im = (kh_u64)__double_as_longlong(v.y);
+    __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 2, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 3, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One round: W = F . T_rid for this workgroup's 16 rows.  Every wave fetches its k slice of round
+// `rid` in the MFMA B-operand layout (element [k = (wave ks + q) 4 + (lane >> 4)][column lane & 15])
+// -- all granule loads of a polling pass in flight together, one memory round trip -- polls until
+// every granule carries the round's tag, and multiplies the slice on the matrix cores.  The 8
+// partial blocks are summed through LDS; owner threads get their element in `w`.  Contains two
+// __syncthreads; a timeout raises s.abort before the first.
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y,
+                                              int N, const KhCoopFrag &f, KhCoopLds &s, int tid, int wave, int lane,
+                                              cplx &w) {
+    const unsigned int epoch = c.epoch_base + rid;
+    const int col = lane & 15;
+    kh_u64 g[MAXKS][4];
+    const long long t0 = wall_clock64();
+    unsigned int spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < MAXKS; ++q) {
+            const int row = (wave * c.ks + q) * 4 + (lane >> 4);
+            if (q < c.ks && row < N) {
+                const kh_u64 *sl = kh_coop_slot(c, rid, y, row, col);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g[q][i] = __hip_atomic_load(sl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g[q][i] = (kh_u64)epoch << 32;  // padding: tag ok, value +0.0
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXKS; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ok = ok && ((unsigned int)(g[q][i] >> 32) == epoch);
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0) {
+            const bool gave_up =
+                (wall_clock64() - t0 > ex.timeout_ticks) ||
+                (__hip_atomic_load(ex.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+            if (__any(gave_up)) {
+                if (lane == 0) {
+                    __hip_atomic_store(ex.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s.abort = 1;
+                }
+                break;
+            }
+        }
+    }
+    kh_d4 acc_r = {0.0, 0.0, 0.0, 0.0}, acc_i = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q) {
+        if (q < c.ks) {
+            const double vr = __longlong_as_double((long long)(((g[q][0] & 0xffffffffull) << 32) | (g[q][1] & 0xffffffffull)));
+            const double vi = __longlong_as_double((long long)(((g[q][2] & 0xffffffffull) << 32) | (g[q][3] & 0xffffffffull)));
+            const double fr = f.re(q), fi = f.im(q);
+            acc_r = __builtin_amdgcn_mfma_f64_16x16x4f64(fr, vr, acc_r, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, -vi, acc_r, 0, 0, 0);
+            acc_i = __builtin_amdgcn_mfma_f64_16x16x4f64(fr, vi, acc_i, 0, 0, 0);
+            acc_i = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, vr, acc_i, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s.part[wave][i][lane] = acc_r[i];
+        s.part[wave][4 + i][lane] = acc_i[i];
+    }
+    __syncthreads();
+    w = c_make(0.0, 0.0);
+    if (tid < KH_COOP_OWNERS) {
+        // C/D layout of v_mfma_f64_16x16x4: column = lane & 15, row = (lane >> 4) + 4 reg
+        const int r = tid >> 4;
+        const int src = (r & 3) * 16 + (tid & 15), reg = r >> 2;
+#pragma unroll
+        for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
+            w.x += s.part[wv][reg][src];
+            w.y += s.part[wv][4 + reg][src];
+        }
+    }
+    __syncthreads();  // part[] is free for the next round
+}
+
+// A = op_0 + sum_l eps_l op_l (fragments rebuilt from L2 once per interval: 2 (1+L) 16 N elements)
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_build(const cplx *const *ops, const double *eps, int L, int N, int rowbase,
+                                              int wave, int lane, int ks, const KhCoopFrag &a) {
+    kh_coop_load_frag<MAXKS>(ops[0], N, rowbase, wave, lane, ks, a);
+#pragma unroll
+    for (int l = 0; l < KH_COOP_MAX_L; ++l)
+        if (l < L) kh_coop_axpy_frag<MAXKS>(ops[1 + l], eps[l], N, rowbase, wave, lane, ks, a);
+}
+
+// state <- exp(f A dt) state, term by term; round `rid` holds the state on entry and on exit.
+// Owner threads carry `state`; rid is advanced by the number of rounds.  Returns false if the
+// exchange timed out.
+template <int MAXKS>
+__device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const KhExchange &ex,
+                                                    const KhCoopFrag &a, cplx &state, unsigned int &rid,
+                                                    KhCoopLds &s, int N, int y, int row, int col,
+                                                    bool owner_valid, double fre, double fim, double dt, int nsub,
+                                                    int m, int tid, int wave, int lane) {
+    const double h = nsub == 1 ? dt : dt / nsub;
+    for (int sub = 0; sub < nsub; ++sub) {
+        for (int j = 1; j <= m; ++j) {
+            cplx w;
+            kh_coop_round<MAXKS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+            if (s.abort) return false;  // (raised before the barriers inside kh_coop_round)
+            if (tid < KH_COOP_OWNERS) {
+                const double hj = h / j;
+                const cplx t = c_mul(c_make(fre * hj, fim * hj), w);
+                state.x += t.x;
+                state.y += t.y;
+                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, j == m ? state : t);
+            }
+            ++rid;
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// plain propagation with storage (backward sweep / iteration-0 forward sweep)
+// ---------------------------------------------------------------------------
+template <int MAXKS>
+__global__ void __launch_bounds__(KH_COOP_THREADS)
+kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__restrict__ pulses,
+                    const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out,
+                    int direction) {
+    extern __shared__ __attribute__((aligned(16))) char kh_coop_smem[];
+    KhCoopLds &s = *(KhCoopLds *)kh_coop_smem;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = blockIdx.x, y = blockIdx.y, rowbase = g * 16;
+    const int N = p.N, nt = p.nt, L = p.L;
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
+    if (tid == 0) s.abort = 0;
+    const int r = tid >> 4, col = tid & 15, row = rowbase + r, k = y * KH_COOP_COLS + col;
+    const bool owner_valid = tid < KH_COOP_OWNERS && row < N;  // (columns beyond K carry zeros)
+    const bool has_state = owner_valid && k < p.K;
+    cplx state = has_state ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
+    unsigned int rid = 1;
+    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state);
+    if (has_state && store != nullptr) store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + row] = state;
+    __syncthreads();
+    double rounds = 0.0;
+    int m_hint = 12;
+    const KhCoopFrag a = {s.frag + tid};
+    for (int step = 0; step < nt - 1; ++step) {
+        const int n = direction > 0 ? step : nt - 2 - step;
+        double eps[KH_COOP_MAX_L];
+        double theta = p.op_norms[0];
+#pragma unroll
+        for (int l = 0; l < KH_COOP_MAX_L; ++l) {
+            eps[l] = 0.0;
+            if (l < L) {
+                eps[l] = pulses[(size_t)l * (nt - 1) + n];
+                theta += fabs(eps[l]) * p.op_norms[1 + l];
+            }
+        }
+        const double dt = p.dt[n];
+        int nsub, m;
+        kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
+        m_hint = m;
+        kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
+        if (!kh_coop_expm_action<MAXKS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt, nsub,
+                                        m, tid, wave, lane))
+            return;
+        rounds += (double)nsub * m;
+        if (has_state && store != nullptr) store[((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N + row] = state;
+    }
+    if (has_state && state_out != nullptr) state_out[(size_t)k * N + row] = state;
+    if (g == 0 && tid == 0 && p.stats != nullptr) {
+        const int cols = min(KH_COOP_COLS, p.K - y * KH_COOP_COLS);
+        atomicAdd(p.stats, rounds * cols);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward sweep with sequential pulse update (optimize.py:444-508); single launch, in-kernel sums
+// ---------------------------------------------------------------------------
+template <int MAXKS, bool SO>
+__global__ void __launch_bounds__(KH_COOP_THREADS)
+kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange ex) {
+    extern __shared__ __attribute__((aligned(16))) char kh_coop_smem[];
+    KhCoopLds &s = *(KhCoopLds *)kh_coop_smem;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = blockIdx.x, y = blockIdx.y, rowbase = g * 16;
+    const int wg = y * gridDim.x + g;  // linear workgroup index of the exchange
+    const int N = p.N, nt = p.nt, L = p.L;
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
+    if (tid == 0) s.abort = 0;
+    const int r = tid >> 4, col = tid & 15, row = rowbase + r, k = y * KH_COOP_COLS + col;
+    const bool owner_valid = tid < KH_COOP_OWNERS && row < N;
+    const bool has_state = owner_valid && k < p.K;
+    cplx state = has_state ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
+    const double chi_norm = has_state ? u.chi_norms[k] : 0.0;
+    unsigned int rid = 1;
+    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state);
+    __syncthreads();
+    double rounds = 0.0;
+    double g_a_loc[KH_COOP_MAX_L];
+#pragma unroll
+    for (int l = 0; l < KH_COOP_MAX_L; ++l) g_a_loc[l] = 0.0;
+    int m_hint = 12;
+    const KhCoopFrag a = {s.frag + tid};
+    for (int n = 0; n < nt - 1; ++n) {
+        const int par = n & 1;
+        // co-state (and, second order, previous-iteration state) element of this owner
+        cplx bra = has_state ? u.chi_store[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0);
+        if constexpr (SO) {
+            if (has_state) {
+                const cplx prev = u.fw_prev[((size_t)k * nt + n) * N + row];
+                const double hs = 0.5 * u.sigma[n] / chi_norm;
+                bra = c_make(fma(hs, state.x - prev.x, bra.x), fma(hs, state.y - prev.y, bra.y));
+                u.fw_store[((size_t)k * nt + n) * N + row] = state;
+            }
+        }
+        // ---- phi(t_n) of all objectives, then the update sums (optimize.py:454-470) ----
+#pragma unroll
+        for (int l = 0; l < KH_COOP_MAX_L; ++l) {
+            if (l >= L) break;
+            kh_coop_load_frag<MAXKS>(p.ops[1 + l], N, rowbase, wave, lane, c.ks, a);
+            cplx w;
+            kh_coop_round<MAXKS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+            if (tid < KH_COOP_OWNERS) {
+                cplx ov = c_make(0.0, 0.0);
+                c_fma_conj(ov, bra, w);
+                const double piece = sum64(chi_norm * (u.mu_re * ov.y + u.mu_im * ov.x));
+                if (lane == 0) s.red[par][wave][l] = piece;
+            }
+        }
+        rounds += L;
+        __syncthreads();
+        if (s.abort) return;
+        if (wave == 0) {
+            double part[KH_COOP_MAX_L], D[KH_COOP_MAX_L];
+#pragma unroll
+            for (int l = 0; l < KH_COOP_MAX_L; ++l)
+                part[l] = l < L ? (s.red[par][0][l] + s.red[par][1][l]) + (s.red[par][2][l] + s.red[par][3][l]) : 0.0;
+            const bool ok = kh_exchange<KH_COOP_MAX_L>(ex, n, wg, L, lane, part, D);
+            if (lane == 0) {
+#pragma unroll
+                for (int l = 0; l < KH_COOP_MAX_L; ++l) s.D[par][l] = D[l];
+                s.D[par][KH_COOP_MAX_L] = ok ? 1.0 : 0.0;
+            }
+        }
+        __syncthreads();
+        if (s.D[par][KH_COOP_MAX_L] == 0.0) return;
+        // ---- pulse update (optimize.py:471-477) ----
+        const double dt = p.dt[n];
+        double eps[KH_COOP_MAX_L];
+        double theta = p.op_norms[0];
+#pragma unroll
+        for (int l = 0; l < KH_COOP_MAX_L; ++l) {
+            if (l >= L) break;
+            const double d1 = s.D[par][l];
+            const double stepw = u.shape[(size_t)l * (nt - 1) + n] / u.lambda[l];
+            eps[l] = u.guess[(size_t)l * (nt - 1) + n] + stepw * d1;
+            g_a_loc[l] += stepw * (d1 * d1) * dt;
+            theta += fabs(eps[l]) * p.op_norms[1 + l];
+            if (wg == 0 && tid == 0) u.opt[(size_t)l * (nt - 1) + n] = eps[l];
+        }
+        // ---- propagate over interval n with the updated pulses (optimize.py:479-491) ----
+        int nsub, m;
+        kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
+        m_hint = m;
+        kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
+        if (!kh_coop_expm_action<MAXKS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt, nsub,
+                                        m, tid, wave, lane))
+            return;
+        rounds += (double)nsub * m;
+    }
+    if (has_state) {
+        u.phi[(size_t)k * N + row] = state;
+        if constexpr (SO) u.fw_store[((size_t)k * nt + (nt - 1)) * N + row] = state;
+    }
+    if (wg == 0 && tid == 0) {
+#pragma unroll
+        for (int l = 0; l < KH_COOP_MAX_L; ++l)
+            if (l < L) u.g_a[l] = g_a_loc[l];
+    }
+    if (g == 0 && tid == 0 && p.stats != nullptr) {
+        const int cols = min(KH_COOP_COLS, p.K - y * KH_COOP_COLS);
+        atomicAdd(p.stats, rounds * cols);
+    }
+}

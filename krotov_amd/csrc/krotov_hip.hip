@@ -20,6 +20,7 @@
 #include "kh_generic.h"
 #include "kh_tile64.h"
 #include "kh_tile64q2.h"
+#include "kh_coop.h"
 
 static thread_local std::string g_last_error;
 
@@ -41,7 +42,7 @@ static int kh_fail(int code, const char *fmt, ...) {
                            __FILE__, __LINE__);                                               \
     } while (0)
 
-enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3 };
+enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3, KIND_COOP = 4 };
 
 struct kh_engine {
     int K, N, L, nt, is_super;
@@ -49,6 +50,10 @@ struct kh_engine {
     int device, num_cus;
     KernelKind kind;
     int grid_update;  // workgroups of the single-launch update sweep
+    // cooperative shared-operator kernels (kh_coop.h): row blocks, column groups, k-steps per wave
+    int coop_G = 0, coop_Y = 0, coop_ks = 0;
+    kh_u64 *d_coop_vbuf = nullptr;
+    size_t coop_vbuf_bytes = 0;
     // device-side problem data
     const cplx **d_ops_fw = nullptr;  // [K*(1+L)]
     const cplx **d_ops_bw = nullptr;  // [K*(1+L)] adjoints
@@ -91,6 +96,7 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
         case KIND_TILE_RPT2: return "tile64/256";
         case KIND_TILE_RPT1: return "tile64/512";
         case KIND_TILE_Q2: return "tile64q2/512";
+        case KIND_COOP: return "coop16/mfma";
         default: return "generic";
     }
 }
@@ -135,6 +141,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_abort);
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_wg_partial);
+    (void)hipFree(e->d_coop_vbuf);
     for (void *ptr : e->p2p_opened) (void)hipIpcCloseMemHandle(ptr);
     (void)hipFree(e->p2p_window);
     (void)hipFree((void *)e->d_p2p_peers);
@@ -236,6 +243,24 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
         if (force && strcmp(force, "tile256") == 0 && e->L <= 2) e->kind = KIND_TILE_RPT2;
         e->grid_update = e->K;
     }
+    // objectives sharing ONE operator list with a state too large for a register tile: one Taylor
+    // term of all objectives is a dense (N x N)(N x K) product -> fp64 matrix cores (kh_coop.h)
+    {
+        bool shared = true;
+        for (size_t i = 0; i < nops && shared; ++i) shared = fw[i] == fw[i % (size_t)(1 + e->L)];
+        const int G = (e->N + 15) / 16, Y = (e->K + KH_COOP_COLS - 1) / KH_COOP_COLS;
+        const bool forced = force && strcmp(force, "coop") == 0;
+        const bool fits = shared && e->N <= 480 && e->L <= KH_COOP_MAX_L && G * Y <= max_wgs;
+        if (fits && (forced || (e->N > KH_TILE_N && force == nullptr))) {
+            e->kind = KIND_COOP;
+            e->coop_G = G;
+            e->coop_Y = Y;
+            e->coop_ks = (e->N + 31) / 32;
+            e->coop_vbuf_bytes = sizeof(kh_u64) * 2 * (size_t)Y * G * 16 * KH_COOP_COLS * 4;
+            KH_HIP_E(hipMalloc(&e->d_coop_vbuf, e->coop_vbuf_bytes));
+            e->grid_update = e->K < max_wgs ? e->K : max_wgs;  // (stepwise launches use the generic kernel)
+        }
+    }
     if (e->kind == KIND_TILE_Q2) {
         // stage P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 once per distinct operator (pair)
         const size_t bytes = sizeof(cplx) * (size_t)e->N * e->N;
@@ -293,7 +318,9 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
     // ---- workspaces
     KH_HIP_E(hipMalloc(&e->d_phi, sizeof(cplx) * (size_t)e->K * e->N));
     const int Lx = e->L > 0 ? e->L : 1;
-    e->slots_bytes = sizeof(kh_u64) * 2 * (size_t)e->grid_update * Lx * 2;
+    const int slot_wgs = e->kind == KIND_COOP && e->coop_G * e->coop_Y > e->grid_update ? e->coop_G * e->coop_Y
+                                                                                         : e->grid_update;
+    e->slots_bytes = sizeof(kh_u64) * 2 * (size_t)slot_wgs * Lx * 2;
     KH_HIP_E(hipMalloc(&e->d_slots, e->slots_bytes));
     KH_HIP_E(hipMalloc(&e->d_abort, sizeof(unsigned int)));
     KH_HIP_E(hipMemset(e->d_abort, 0, sizeof(unsigned int)));
@@ -335,6 +362,51 @@ static int dispatch_tile_store(const kh_engine *e, const KhSweepArgs &p, const d
     return KH_OK;
 }
 
+static KhExchange exchange_args(const kh_engine *e, bool internal_exchange);
+
+static KhCoopArgs coop_args(const kh_engine *e) {
+    KhCoopArgs c;
+    c.vbuf = e->d_coop_vbuf;
+    c.epoch_base = 0;  // the buffer is cleared before every launch
+    c.G = e->coop_G;
+    c.Y = e->coop_Y;
+    c.ks = e->coop_ks;
+    return c;
+}
+
+template <int MAXKS>
+static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
+                             cplx *out, int direction, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute((const void *)kh_coop_sweep_store<MAXKS>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)kh_coop_lds_bytes(15));
+    (void)attr;
+    KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
+    kh_coop_sweep_store<MAXKS><<<dim3(e->coop_G, e->coop_Y), KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(
+        p, coop_args(e), exchange_args(e, true), pulses, in, store, out, direction);
+    return KH_OK;
+}
+
+template <int MAXKS>
+static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u, const KhExchange &ex,
+                              hipStream_t st) {
+    static const hipError_t attr0 = hipFuncSetAttribute((const void *)kh_coop_forward_update<MAXKS, false>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)kh_coop_lds_bytes(15));
+    static const hipError_t attr1 = hipFuncSetAttribute((const void *)kh_coop_forward_update<MAXKS, true>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)kh_coop_lds_bytes(15));
+    (void)attr0;
+    (void)attr1;
+    KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
+    const dim3 grid(e->coop_G, e->coop_Y);
+    if (u.sigma != nullptr)
+        kh_coop_forward_update<MAXKS, true><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e), u, ex);
+    else
+        kh_coop_forward_update<MAXKS, false><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e), u, ex);
+    return KH_OK;
+}
+
 static int sweep_store(kh_engine *e, bool backward, const double *pulses, const cplx *in, cplx *store, cplx *out,
                        hipStream_t st) {
     const KhSweepArgs p = sweep_args(e, backward);
@@ -348,6 +420,9 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         rc = dispatch_tile_store<2>(e, p, pulses, in, store, out, direction, st);
     } else if (e->kind == KIND_TILE_RPT1) {
         rc = dispatch_tile_store<1>(e, p, pulses, in, store, out, direction, st);
+    } else if (e->kind == KIND_COOP) {
+        rc = e->coop_ks <= 8 ? launch_coop_store<8>(e, p, pulses, in, store, out, direction, st)
+                             : launch_coop_store<16>(e, p, pulses, in, store, out, direction, st);
     } else {
         const size_t lds = kh_gen_lds_bytes(e->N);
         if (lds > 64 * 1024)
@@ -396,22 +471,25 @@ static void launch_tile_update(const kh_engine *e, const KhSweepArgs &p, const K
         kh_tile_forward_update<RPT, LT, false><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
 }
 
-static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
-    const KhSweepArgs p = sweep_args(e, false);
+static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
     KhExchange ex;
     ex.slots = e->d_slots;
     ex.abort_flag = e->d_abort;
-    ex.G = e->grid_update;
+    ex.G = (e->kind == KIND_COOP && internal_exchange) ? e->coop_G * e->coop_Y : e->grid_update;
     ex.timeout_ticks = 100000000LL;  // 1 s of the 100 MHz wall clock
     ex.peer_windows = e->d_p2p_peers;
     ex.my_window = e->p2p_window;
-    ex.world = (e->p2p_ready && u.internal_exchange) ? e->p2p_world : 1;
+    ex.world = (e->p2p_ready && internal_exchange) ? e->p2p_world : 1;
     ex.rank = e->p2p_rank;
     ex.epoch_base = e->p2p_epoch_base;
-    {
-        const char *d = getenv("KH_POLL_DELAY");  // tuning knob, s_sleep units
-        ex.first_poll_delay = d ? atoi(d) : 16;  // ~0.4 us: measured best on MI355X
-    }
+    const char *d = getenv("KH_POLL_DELAY");  // tuning knob, s_sleep units
+    ex.first_poll_delay = d ? atoi(d) : 16;   // ~0.4 us: measured best on MI355X
+    return ex;
+}
+
+static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
+    const KhSweepArgs p = sweep_args(e, false);
+    const KhExchange ex = exchange_args(e, u.internal_exchange != 0);
     if (u.internal_exchange) KH_HIP(hipMemsetAsync(e->d_slots, 0, e->slots_bytes, st));
     // One launch per interval (sharded sweep): every launch re-stages its operator
     // tiles, so the q2 kernels (5 tiles, 320 KiB per objective) lose to the
@@ -422,7 +500,10 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             kh_q2_forward_update<true><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
         else
             kh_q2_forward_update<false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
-    } else if (e->kind != KIND_GENERIC) {
+    } else if (e->kind == KIND_COOP && !stepwise) {
+        const int rc = e->coop_ks <= 8 ? launch_coop_update<8>(e, p, u, ex, st) : launch_coop_update<16>(e, p, u, ex, st);
+        if (rc != KH_OK) return rc;
+    } else if (e->kind != KIND_GENERIC && e->kind != KIND_COOP) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
         switch (e->L) {
             case 1: rpt2 ? launch_tile_update<2, 1>(e, p, u, ex, st) : launch_tile_update<1, 1>(e, p, u, ex, st); break;
