@@ -11,12 +11,16 @@
 // Its 8 waves split the k range (4 ks values each); the A fragments stay in LDS for a whole time
 // interval (lane-linear: every lane reads back only what it wrote), the 8 partial 16 x 16 blocks
 // are summed through LDS.  Every Taylor term needs the
-// whole previous term, i.e. the blocks of all row workgroups: they are exchanged through a
-// double-buffered N x 16 block in global memory made of epoch-tagged 8-byte granules
-// {epoch:32 | half of a double:32} written and read with relaxed agent-scope atomics -- the data
-// is its own "ready" flag, so a round costs ONE memory round trip instead of data + flag.
-// A workgroup can be at most one round ahead of the slowest reader (it needs everybody's block of
-// round r before it can publish r + 1), so the buffer of parity r + 2 is free when written.
+// whole previous term, i.e. the blocks of all row workgroups: they are exchanged through a ring of
+// N x 16 blocks in global memory made of epoch-tagged 8-byte granules {epoch:32 | half of a
+// double:32}, written with agent-scope (write-through) atomic stores -- the data is its own
+// "ready" flag, so a round costs ONE memory round trip instead of data + flag.  A workgroup can be
+// at most one round ahead of the slowest reader (it needs everybody's block of round r before it
+// can publish r + 1), so any ring of >= 2 blocks is race free.  The ring is KH_COOP_RING deep so
+// that a block's lines have left the (per-XCD, not cross-XCD coherent) L2 before they are reused:
+// the first fetch of a round then goes through L2 at full bandwidth (workgroup-scope loads; the
+// agent-scope loads that bypass L2 run at ~10 GB/s per CU), and only granules whose tag shows a
+// stale line -- or data that had not landed yet -- are re-fetched with agent scope.
 //
 // All workgroups must be co-resident (grid = ceil(N/16) x ceil(K/16) <= number of CUs); spins are
 // bounded by the exchange timeout and raise the engine's abort flag.
@@ -29,15 +33,17 @@
 #define KH_COOP_WAVES 8
 #define KH_COOP_COLS 16
 #define KH_COOP_OWNERS 256  // threads 0..255 own one element (row r = tid/16, column tid%16) of the block
+#define KH_COOP_RING 32      // blocks in the exchange ring
 #define KH_COOP_MAX_L 2     // controls (the update-sum exchange keeps 16 registers per control in flight)
 
 typedef double kh_d4 __attribute__((ext_vector_type(4)));
 
 struct KhCoopArgs {
-    kh_u64 *vbuf;             // [2][Y][G*16][16][4] granules
+    kh_u64 *vbuf;             // [KH_COOP_RING][Y][G*16][4][16] granules
     unsigned int epoch_base;  // rounds of earlier launches (tags are monotonic: the buffer is never cleared)
     int G, Y;                 // row blocks, column groups
     int ks;                   // k-steps (of 4 columns) per wave: 32 * ks >= N
+    int first_poll_delay;     // s_sleep units (64 cycles) before a round's first fetch
 };
 
 struct KhCoopLds {
@@ -47,6 +53,9 @@ struct KhCoopLds {
     double deg[KH_MAX_DEGREE + 2];
     int abort;
     int pad;
+#ifdef KH_TIMING
+    double tim[5];
+#endif
     double frag[1];  // [ks][2][KH_COOP_THREADS] operator fragment of the current interval (dynamic size)
 };
 
@@ -94,8 +103,11 @@ __device__ __forceinline__ void kh_coop_axpy_frag(const cplx *op, double eps, in
     }
 }
 
+// granule i (re hi, re lo, im hi, im lo) of element (row, col) is slot(...)[i * 16]: the 16 columns
+// of one granule index are contiguous, so a wave's 8-byte accesses cover whole 128-byte lines
 __device__ __forceinline__ kh_u64 *kh_coop_slot(const KhCoopArgs &c, unsigned int rid, int y, int row, int col) {
-    return c.vbuf + ((((size_t)(rid & 1u) * c.Y + y) * ((size_t)c.G * 16) + row) * KH_COOP_COLS + col) * 4;
+    return c.vbuf +
+           (((size_t)(rid % KH_COOP_RING) * c.Y + y) * ((size_t)c.G * 16) + row) * (4 * KH_COOP_COLS) + col;
 }
 
 // owner thread: element (row, col) of round `rid`
@@ -104,10 +116,10 @@ __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned in
     kh_u64 *g = kh_coop_slot(c, rid, y, row, col);
     const kh_u64 tag = (kh_u64)(c.epoch_base + rid) << 32;
     const kh_u64 re = (kh_u64)__double_as_longlong(v.x), im = (kh_u64)__double_as_longlong(v.y);
-    __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g + 2, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g + 3, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 0 * KH_COOP_COLS, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1 * KH_COOP_COLS, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 2 * KH_COOP_COLS, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 3 * KH_COOP_COLS, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One round: W = F . T_rid for this workgroup's 16 rows.  Every wave fetches its k slice of round
@@ -124,7 +136,42 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
     const int col = lane & 15;
     kh_u64 g[MAXKS][4];
     const long long t0 = wall_clock64();
+#ifdef KH_TIMING
+    const long long tq0 = clock64();
+#endif
     unsigned int spins = 0;
+    // A pass issued before the slowest producer's stores have reached the memory side costs a whole
+    // extra round trip: give them a head start, and re-fetch only what was stale afterwards.
+    for (int d = 0; d < c.first_poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[q][i] = 0;  // tag 0 is never a round's tag
+    // first pass through L2 (fast; may see a stale line), then only what was stale, bypassing L2
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q) {
+        const int row = (wave * c.ks + q) * 4 + (lane >> 4);
+        if (q < c.ks && row < N) {
+            const kh_u64 *sl = kh_coop_slot(c, rid, y, row, col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                g[q][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+#ifdef KH_TIMING
+    {
+        bool fresh = true;
+#pragma unroll
+        for (int q = 0; q < MAXKS; ++q) {
+            const int row = (wave * c.ks + q) * 4 + (lane >> 4);
+            if (q < c.ks && row < N)
+                for (int i = 0; i < 4; ++i) fresh = fresh && ((unsigned int)(g[q][i] >> 32) == epoch);
+        }
+        if (!__all(fresh)) spins += 1000;
+    }
+    const long long tqf = clock64();
+    if (tid == 0 && blockIdx.x == 0) s.tim[4] += (double)(tqf - tq0);
+#endif
     for (;;) {
         bool ok = true;
 #pragma unroll
@@ -133,7 +180,9 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
             if (q < c.ks && row < N) {
                 const kh_u64 *sl = kh_coop_slot(c, rid, y, row, col);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) g[q][i] = __hip_atomic_load(sl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < 4; ++i)
+                    if ((unsigned int)(g[q][i] >> 32) != epoch)
+                        g[q][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g[q][i] = (kh_u64)epoch << 32;  // padding: tag ok, value +0.0
@@ -144,7 +193,7 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
 #pragma unroll
             for (int i = 0; i < 4; ++i) ok = ok && ((unsigned int)(g[q][i] >> 32) == epoch);
         if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(2);
         if ((++spins & 63u) == 0) {
             const bool gave_up =
                 (wall_clock64() - t0 > ex.timeout_ticks) ||
@@ -158,6 +207,9 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
             }
         }
     }
+#ifdef KH_TIMING
+    const long long tq1 = clock64();
+#endif
     kh_d4 acc_r = {0.0, 0.0, 0.0, 0.0}, acc_i = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
@@ -176,7 +228,19 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
         s.part[wave][i][lane] = acc_r[i];
         s.part[wave][4 + i][lane] = acc_i[i];
     }
+#ifdef KH_TIMING
+    const long long tq2 = clock64();
+#endif
     __syncthreads();
+#ifdef KH_TIMING
+    const long long tq3 = clock64();
+    if (tid == 0 && blockIdx.x == 0) {
+        s.tim[0] += (double)(tq1 - tq0);
+        s.tim[1] += (double)(tq2 - tq1);
+        s.tim[2] += (double)(tq3 - tq2);
+        s.tim[3] += (double)spins;
+    }
+#endif
     w = c_make(0.0, 0.0);
     if (tid < KH_COOP_OWNERS) {
         // C/D layout of v_mfma_f64_16x16x4: column = lane & 15, row = (lane >> 4) + 4 reg
@@ -244,6 +308,9 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
     const int N = p.N, nt = p.nt, L = p.L;
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
+#ifdef KH_TIMING
+    if (tid < 5) s.tim[tid] = 0.0;
+#endif
     const int r = tid >> 4, col = tid & 15, row = rowbase + r, k = y * KH_COOP_COLS + col;
     const bool owner_valid = tid < KH_COOP_OWNERS && row < N;  // (columns beyond K carry zeros)
     const bool has_state = owner_valid && k < p.K;
@@ -282,6 +349,11 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
     if (g == 0 && tid == 0 && p.stats != nullptr) {
         const int cols = min(KH_COOP_COLS, p.K - y * KH_COOP_COLS);
         atomicAdd(p.stats, rounds * cols);
+#ifdef KH_TIMING
+        p.stats[1] = s.tim[0] / rounds + 1e6 * (double)(long long)(s.tim[4] / rounds);
+        p.stats[2] = s.tim[1] / rounds;
+        p.stats[3] = s.tim[2] / rounds + 1e6 * (s.tim[3] / rounds);
+#endif
     }
 }
 

@@ -256,7 +256,7 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
             e->coop_G = G;
             e->coop_Y = Y;
             e->coop_ks = (e->N + 31) / 32;
-            e->coop_vbuf_bytes = sizeof(kh_u64) * 2 * (size_t)Y * G * 16 * KH_COOP_COLS * 4;
+            e->coop_vbuf_bytes = sizeof(kh_u64) * KH_COOP_RING * (size_t)Y * G * 16 * KH_COOP_COLS * 4;
             KH_HIP_E(hipMalloc(&e->d_coop_vbuf, e->coop_vbuf_bytes));
             e->grid_update = e->K < max_wgs ? e->K : max_wgs;  // (stepwise launches use the generic kernel)
         }
@@ -371,6 +371,8 @@ static KhCoopArgs coop_args(const kh_engine *e) {
     c.G = e->coop_G;
     c.Y = e->coop_Y;
     c.ks = e->coop_ks;
+    const char *d = getenv("KH_COOP_DELAY");  // tuning knob, s_sleep units
+    c.first_poll_delay = d ? atoi(d) : 12;
     return c;
 }
 

@@ -1,0 +1,19 @@
+import os, sys, ctypes
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+from krotov_amd import configs
+from krotov_amd.engine import HipKrotovEngine
+spec = configs.config_c4(nt=201)
+K, N, L = spec.K, spec.N, spec.L
+ops = [[spec.H0[k]] + [spec.Hc[k][l] for l in range(L)] for k in range(K)]
+eng = HipKrotovEngine(ops, np.diff(spec.tlist), is_super=True)
+tl = spec.tlist
+pulses = np.array([[spec.controls[l](t + 0.5 * (tl[1] - tl[0]), None) for t in tl[:-1]] for l in range(L)])
+chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+for _ in range(2):
+    chi = eng.backward(chi_T, pulses)
+buf = (ctypes.c_double * 4)()
+torch.cuda.synchronize()
+eng._lib.kh_last_stats(eng._handle, buf)
+print('rounds*cols', buf[0], ' cycles/round: poll %.0f (fast pass %d)  mfma+ldswrite %.0f  barrier %.0f  (spins/round %.3f; 1000 = stale after the fast pass)' % (
+    buf[1] % 1e6, int(buf[1] / 1e6), buf[2], buf[3] % 1e6, int(buf[3] / 1e6)))

@@ -523,19 +523,20 @@ def test_two_ranks_sharded_on_one_gpu():
     print("cross-GPU exchange through peer windows used:", [o[3] for o in out])
 
 
-def test_full_size_c4_liouville_properties():
+def test_full_size_c4_liouville_properties(monkeypatch):
     """BASELINE config 4 as concretised in SURVEY.md 8d: transmon in Liouville space,
     400-dim vec(rho), 16 density-matrix objectives sharing one operator list, 1000
-    intervals (generic kernels).  No reference golden exists for Liouville-space expm
-    (SURVEY.md 8c): checked by properties -- trace preservation, <chi|rho> conservation
-    between the adjoint (backward) and forward sweeps -- and against the oracle on a
-    short prefix of the time grid."""
+    intervals (cooperative matrix-core kernels).  No reference golden exists for
+    Liouville-space expm: checked by properties -- trace preservation,
+    <chi|rho> conservation between the adjoint (backward) and forward sweeps --, against
+    the per-objective generic kernels at full size, and against the oracle on a short
+    prefix of the time grid."""
     import torch
 
     spec = configs.config_c4()
     assert spec.N == 400 and spec.K == 16
     eng = _engine(spec)
-    assert eng.kernel == 'generic'
+    assert eng.kernel == 'coop16/mfma'
     gp, S, lam = oracle_controls(spec)
     pulses = np.array(gp)
     fw_T, states = eng.forward(pulses, spec.init, store=True)
@@ -552,6 +553,19 @@ def test_full_size_c4_liouville_properties():
     eng.check()
     assert np.all(np.isfinite(opt.cpu().numpy()))
     eng.close()
+    # the same full-size sweeps through the generic (one workgroup per objective) kernels
+    monkeypatch.setenv('KH_KERNEL', 'generic')
+    gen = _engine(spec)
+    assert gen.kernel == 'generic'
+    fw_gen = gen.forward(pulses, spec.init)
+    assert float((fw_gen - fw_T).abs().max()) < 1e-10
+    opt_gen, psi_gen, _ = gen.forward_update(chi, np.full(spec.K, 1.0 / (2 * spec.K)), spec.init, pulses,
+                                             np.array(S), np.array(lam))
+    gen.check()
+    assert float((opt_gen - opt).abs().max()) < 1e-10 * max(1.0, float(opt.abs().max()))
+    assert float((psi_gen - psi_T).abs().max()) < 1e-10
+    gen.close()
+    monkeypatch.delenv('KH_KERNEL')
     # oracle on the first 6 intervals, 2 objectives
     short = configs.config_c4(nt=1001)
     short.tlist = short.tlist[:7]
