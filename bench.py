@@ -107,6 +107,10 @@ def main():
     ap.add_argument('--nt', type=int, default=4001)
     ap.add_argument('--L', type=int, default=1)
     ap.add_argument('--distinct', action='store_true', help='every objective gets its own random drift')
+    ap.add_argument('--workload', choices=['c5', 'c4'], default='c5',
+                    help="c5 (default): BASELINE config 5, the configuration the metric is quoted on; c4: config 4 "
+                         "(transmon Liouvillian, N=400, 16 density matrices sharing one operator list), a "
+                         "single-GPU variant line for profiles/, not the headline")
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true',
@@ -149,7 +153,14 @@ def main():
     from krotov_amd import configs, engine as _engine_mod
 
     K_total = args.K * world if args.scaling == 'weak' else args.K
-    spec = configs.config_c5(K=K_total, N=args.N, nt=args.nt, L=args.L, distinct=args.distinct)
+    propagator = krotov_amd.propagators.expm
+    if args.workload == 'c4':
+        spec = configs.config_c4()
+        K_total, args.K, args.N, args.nt, args.L = spec.K, spec.K, spec.N, len(spec.tlist), spec.L
+        args.no_cpu_baseline = True
+        propagator = krotov_amd.propagators.HipExpm(liouville=True)
+    else:
+        spec = configs.config_c5(K=K_total, N=args.N, nt=args.nt, L=args.L, distinct=args.distinct)
     objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
 
     n_iter = args.warmup + args.steps
@@ -176,7 +187,7 @@ def main():
 
     res = krotov_amd.optimize_pulses(
         objectives, pulse_options, spec.tlist,
-        propagator=krotov_amd.propagators.expm,
+        propagator=propagator,
         chi_constructor=krotov_amd.functionals.chis_re,
         info_hook=hook, iter_stop=n_iter, process_group=group,
     )
@@ -191,6 +202,7 @@ def main():
     kernel_names = {
         'tile64q2/512': ('kh_q2_forward_update', 'kh_q2_sweep_store'),
         'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
+        'coop16/mfma': ('kh_coop_forward_update', 'kh_coop_sweep_store'),
     }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
     if group is not None and not getattr(eng, '_p2p_used', False) and eng.kernel != 'generic':
         # per-interval launches (RCCL path) run the two-tile kernel, see krotov_hip.hip:launch_update
@@ -207,8 +219,9 @@ def main():
         dominant = 'update' if t_up >= t_bw else 'backward'
         f_dom, t_dom = (f_up, t_up) if dominant == 'update' else (f_bw, t_bw)
         out = {
-            'metric': 'state*timestep propagations/s (Krotov iterations/s in iterations_per_sec), '
-                      '256-objective N=64 ensemble',
+            'metric': 'state*timestep propagations/s (Krotov iterations/s in iterations_per_sec), ' +
+                      ('16-objective N=400 Liouvillian (variant)' if args.workload == 'c4' else
+                       '256-objective N=64 ensemble'),
             'value': props / elapsed,
             'unit': 'props/s',
             'iterations_per_sec': args.steps / elapsed,
@@ -222,7 +235,11 @@ def main():
             'dtype': 'f64',
             'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE config 5: robustness ensemble, %d objectives%s x N=%d x %d time steps, '
+                'workload': ('BASELINE config 4 (variant line): transmon X-gate in Liouville space, %d density-matrix '
+                             'objectives sharing one %d-dim Liouvillian x %d time steps, L=%d control, chis_re, '
+                             'complex128; one step = one Krotov iteration' % (K_total, args.N, args.nt - 1, args.L))
+                if args.workload == 'c4' else
+                            'BASELINE config 5: robustness ensemble, %d objectives%s x N=%d x %d time steps, '
                             'L=%d control, chis_re, complex128; one step = one Krotov iteration '
                             '(backward sweep + forward/update sweep)' % (
                                 K_total, ' (%d per GPU)' % args.K if world > 1 else '', args.N, args.nt - 1, args.L),
@@ -242,9 +259,13 @@ def main():
                 'unit': 'TFLOP/s',
                 'frac': f_dom / t_dom / 1e12 / FP64_PEAK_TFLOPS,
                 'traffic': pmc_traffic(kernel_names[0] if dominant == 'update' else kernel_names[1], K_loc, args),
-                'note': 'fp64 vector-FMA bound (complex matrix-vector products cannot use MFMA tiles); the fp64 '
-                        'vector peak equals the fp64 MFMA peak on MI355X (78.6 TFLOP/s). Algorithmic flops: '
-                        'K*(nt-1)*(8 N^2 * 14 [+ L*(8 N^2 + 8 N) for the update sweep]).',
+                'note': ('fp64 MFMA (v_mfma_f64_16x16x4): the objectives share the operators, so a Taylor term is a '
+                         'dense (N x N)(N x K) product; latency-bound by one cross-workgroup exchange per term. '
+                         'Credited flops as below with m = 14 per propagation (SURVEY.md 8d), whatever was issued. '
+                         if eng.kernel == 'coop16/mfma' else
+                         'fp64 vector-FMA bound (complex matrix-vector products cannot use MFMA tiles); the fp64 '
+                         'vector peak equals the fp64 MFMA peak on MI355X (78.6 TFLOP/s). ') +
+                        'Algorithmic flops: K*(nt-1)*(8 N^2 * 14 [+ L*(8 N^2 + 8 N) for the update sweep]).',
                 'launch_ms': t_dom * 1e3,
             },
             'kernels': {
