@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): one bench line per variant of the workload -> gpurun_out/<tag>/variants/*.json
+# usage: scripts/collect_variants.sh <tag>
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG/variants
+mkdir -p $OUT
+cd $R
+run() { name=$1; shift; timeout 600 python bench.py --no-cpu-baseline --steps 4 --warmup 1 "$@" 2>/dev/null | tail -1 > $OUT/$name.json; cut -c1-160 $OUT/$name.json; }
+run distinct --distinct
+run L2 --L 2
+run L3 --L 3
+run L4 --L 4
+run K64 --K 64
+run K128 --K 128
+run c4_liouville_N400 --workload c4 --steps 3
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -o b -- python bench.py --workload c4 --steps 2 --warmup 1 > $OUT/c4_stats.log 2>&1
+ls $OUT

@@ -23,7 +23,7 @@ for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_lds'):
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        agg[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
+        agg[r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
     for kern, ctrs in agg.items():
         if not kern.startswith('kh_'):
             continue
@@ -46,3 +46,23 @@ for kern, c in summary.items():
     if 'SQ_WAVE_CYCLES' in c:
         wc = c['SQ_WAVE_CYCLES']['avg_per_launch']
         print(kern, {k: round(100 * v['avg_per_launch'] / wc, 1) for k, v in c.items() if k.startswith('SQ_') and k != 'SQ_WAVE_CYCLES'})
+
+# variant bench lines (scripts/collect_variants.sh) -> profiles/<tag>/variants.json (+ config-4 kernel stats)
+vdir = os.path.join(src, 'variants')
+if os.path.isdir(vdir):
+    variants = {}
+    for name in sorted(os.listdir(vdir)):
+        if name.endswith('.json'):
+            try:
+                variants[name[:-5]] = json.loads(open(os.path.join(vdir, name)).read().strip())
+            except ValueError:
+                variants[name[:-5]] = None
+    json.dump(variants, open(os.path.join(dst, 'variants.json'), 'w'), indent=1)
+    c4 = os.path.join(vdir, 'c4_stats', 'b_kernel_stats.csv')
+    if os.path.exists(c4):
+        shutil.copy(c4, os.path.join(dst, 'kernel_stats_config4.csv'))
+    for k, v in variants.items():
+        if v:
+            print('%-20s %8.2f M props/s  %7.2f ms/iteration  kernel %s  (%s %.1f%% of fp64 peak)' % (
+                k, v['value'] / 1e6, v['ms_per_step'], v['config']['kernel'], v['roofline']['kernel'],
+                100 * v['roofline']['frac']))
