@@ -7,6 +7,7 @@ kernels behind a C ABI (include/krotov_hip.h).  See DESIGN.md.
 """
 from . import (
     configs,
+    convergence,
     conversions,
     functionals,
     info_hooks,
@@ -27,6 +28,7 @@ __version__ = '0.1.0'
 __all__ = [
     'Objective',
     'Result',
+    'convergence',
     'conversions',
     'ensemble_objectives',
     'functionals',

@@ -11,6 +11,8 @@ is ``chi_k = c_k target_k + d_k phi_k(T)`` with per-objective scalars
 ``kh_chi_boundary``.  :func:`chi_stacked` is the same thing as a (K, N) array
 expression on the host; the list forms are what user code calls.
 """
+import logging
+
 import numpy as np
 
 from .second_order import _overlap
@@ -42,9 +44,13 @@ def _taus(fw_states_T, objectives, tau_vals):
 
 
 def f_tau(fw_states_T, objectives, tau_vals=None, **kwargs):
-    """(1/K) sum_k w_k tau_k  (reference functionals.py:82-113)."""
-    total = 0
+    """(1/K) sum_k w_k tau_k  (reference functionals.py:82-141); a tau that is
+    None (no forward propagation yet) is skipped with a warning."""
+    total = 0j
     for obj, tau in zip(objectives, _taus(fw_states_T, objectives, tau_vals)):
+        if tau is None:
+            logging.getLogger('krotov').warning("τ is None in f_tau")
+            continue
         w = _weight(obj)
         total += tau if w is None else w * tau
     return total / len(objectives)

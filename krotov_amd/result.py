@@ -5,10 +5,11 @@ controls_mapping, all_pulses, states, message, start_local_time,
 end_local_time``.  Host bookkeeping only.
 """
 import copy
+import logging
 import pickle
 import time
 
-__all__ = ['Result']
+__all__ = ['Result', 'ControlPlaceholder']
 
 _FIELDS = (
     'objectives', 'tlist', 'iters', 'iter_seconds', 'info_vals', 'tau_vals',
@@ -58,11 +59,30 @@ class Result:
     @property
     def optimized_objectives(self):
         """Copies of the objectives with every control replaced by its
-        optimised array (reference result.py:124-152)."""
+        optimised array (reference result.py:127-130)."""
+        return self.objectives_with_controls(self.optimized_controls)
+
+    def objectives_with_controls(self, controls):
+        """Copies of :attr:`objectives` with the given ``controls`` (one per
+        entry of :attr:`guess_controls`, on the points of :attr:`tlist`)
+        plugged into the nested lists (reference result.py:132-188).  Raises
+        ``ValueError`` for a wrong number of controls or arrays that do not
+        match the time grid."""
+        if len(controls) != len(self.guess_controls):
+            raise ValueError("Expected %d controls, %d given" % (len(self.guess_controls), len(controls)))
+        for control in controls:
+            try:
+                if len(control) != len(self.tlist):
+                    raise ValueError(
+                        "controls are not defined on the points of the time grid: control has %d values "
+                        "for %d time grid points" % (len(control), len(self.tlist))
+                    )
+            except TypeError:
+                pass  # a callable
         out = []
         for i_obj, obj in enumerate(self.objectives):
-            new = copy.copy(obj)
-            for i_control, control in enumerate(self.optimized_controls):
+            new = copy.copy(obj)  # nested lists copied, operators shared
+            for i_control, control in enumerate(controls):
                 for i in self.controls_mapping[i_obj][0][i_control]:
                     new.H[i][1] = control
                 for i_c, _ in enumerate(new.c_ops):
@@ -72,24 +92,76 @@ class Result:
         return out
 
     def dump(self, filename):
-        """Pickle the numeric record (controls that are functions are dropped
-        from the stored objectives' nested lists by replacing them with their
-        discretised guess arrays)."""
+        """Pickle the result.  Controls that are Python functions cannot be
+        pickled: in the stored objectives they are replaced by
+        :class:`ControlPlaceholder` s (pass the objectives again to
+        :meth:`load`), as in the reference (result.py:247-262)."""
         clone = copy.copy(self)
         clone.objectives = []
-        for i_obj, obj in enumerate(self.objectives):
+        for obj in self.objectives:
             new = copy.copy(obj)
-            for i_control, control in enumerate(self.guess_controls):
-                for i in self.controls_mapping[i_obj][0][i_control]:
-                    new.H[i][1] = control
+            ids = {}
+            for lst in [new.H] + list(new.c_ops):
+                if isinstance(lst, list):
+                    for term in lst:
+                        if isinstance(term, list) and callable(term[1]):
+                            term[1] = ControlPlaceholder(ids.setdefault(id(term[1]), len(ids)))
             clone.objectives.append(new)
         with open(filename, 'wb') as fh:
             pickle.dump(clone, fh)
 
     @classmethod
-    def load(cls, filename, objectives=None):
+    def load(cls, filename, objectives=None, finalize=False):
+        """Read a :meth:`dump`.  ``objectives`` replaces the stored ones (which
+        have lost their function controls); with ``finalize=True`` optimized
+        controls that were dumped mid-optimisation (``dump_result``), still on
+        the intervals of the time grid, are mapped onto its points.  Warnings
+        are logged like the reference's (result.py:190-244)."""
+        from .conversions import pulse_onto_tlist
+
+        logger = logging.getLogger('krotov')
         with open(filename, 'rb') as fh:
             res = pickle.load(fh)
-        if objectives is not None:
+        if objectives is None:
+            if any(_has_placeholder(obj.H) or any(_has_placeholder(c) for c in obj.c_ops) for obj in res.objectives):
+                logger.warning(
+                    "Result.objectives contains control placeholders. You should overwrite it by passing "
+                    "`objectives`."
+                )
+        else:
             res.objectives = objectives
+        nt = len(res.tlist)
+        for i, control in enumerate(res.optimized_controls):
+            if len(control) == nt:
+                continue
+            if len(control) == nt - 1:
+                if finalize:
+                    res.optimized_controls[i] = pulse_onto_tlist(control)
+                    continue
+                logger.warning("Result.optimized_controls are not finalized. Consider loading with `finalize=True`.")
+            else:
+                logger.error("Result.optimized_controls are incongruent with Result.tlist")
+            break  # one message is enough
         return res
+
+
+class ControlPlaceholder:
+    """Stands in for a control function in a dumped objective."""
+
+    def __init__(self, index):
+        self.id = index
+
+    def __eq__(self, other):
+        return isinstance(other, ControlPlaceholder) and other.id == self.id
+
+    def __hash__(self):
+        return hash(('ControlPlaceholder', self.id))
+
+    def __repr__(self):
+        return "ControlPlaceholder(%d)" % self.id
+
+
+def _has_placeholder(lst):
+    if isinstance(lst, list):
+        return any(_has_placeholder(v) for v in lst)
+    return isinstance(lst, ControlPlaceholder)

@@ -336,6 +336,37 @@ def make_second_order():
     print('ref_so_c3: A history', sig.history, ' tau[-1][:2]', out['tau_vals'][-1][:2])
 
 
+def make_print_table_cases():
+    """Text written by the reference's own ``krotov.info_hooks.print_table`` for three
+    synthetic iteration records (two pulses with per-pulse columns; ASCII headers;
+    custom formats/headers) -> tests/golden/print_table_cases.txt."""
+    import io
+
+    krotov = import_reference_krotov()
+    out = io.StringIO()
+    J = lambda **kw: kw['J']  # noqa: E731
+    common = dict(guess_pulses=[None, None], iter_stop=10, start_time=0.0, stop_time=2.4)
+    hook = krotov.info_hooks.print_table(J_T=J, show_g_a_int_per_pulse=True, out=out)
+    hook(iteration=0, J=1.0, g_a_integrals=np.zeros(2), info_vals=[], **common)
+    hook(iteration=1, J=0.5, g_a_integrals=np.array([0.1, 0.2]), info_vals=[1.0], **common)
+    hook(iteration=2, J=0.6, g_a_integrals=np.array([0.0, 0.05]), info_vals=[1.0, 0.5], **common)
+    out.write("--\n")
+    hook = krotov.info_hooks.print_table(J_T=J, unicode=False, out=out)
+    one = dict(guess_pulses=[None], iter_stop=12345, start_time=0.0, stop_time=0.0)
+    hook(iteration=0, J=1.0, g_a_integrals=np.zeros(1), info_vals=[], **one)
+    hook(iteration=1, J=0.25, g_a_integrals=np.array([0.5]), info_vals=[1.0], **one)
+    out.write("--\n")
+    hook = krotov.info_hooks.print_table(
+        J_T=J, show_g_a_int_per_pulse=True, out=out,
+        col_formats=('%03d', '%.6f', '%.3e', '%.3e', '%.6f', '%+.1e', '%+.1e', '%4d'),
+        col_headers=('#', 'error', 'ga[{l}]', 'ga', 'total', 'd(error)', 'd(total)', 's'))
+    hook(iteration=0, J=1.0, g_a_integrals=np.zeros(2), info_vals=[], **common)
+    hook(iteration=1, J=0.5, g_a_integrals=np.array([0.1, 0.2]), info_vals=[1.0], **common)
+    with open(os.path.join(HERE, 'print_table_cases.txt'), 'w', encoding='utf8') as fh:
+        fh.write(out.getvalue())
+    print(out.getvalue())
+
+
 def make_c5_full():
     """Headline configuration through the real reference loop: 1 iteration
     (~2.5 sweeps * 256 * 4000 props at ~0.8 ms each => ~35 min, one core)."""
@@ -357,6 +388,8 @@ if __name__ == '__main__':
         make_c5_full()
     if 'second_order' in what:
         make_second_order()
+    if 'print_table' in what:
+        make_print_table_cases()
     for w in what:
         if w in REF_CASES:
             make_ref_fixtures([w])

@@ -1,0 +1,183 @@
+"""Host helpers around the path: ``convergence``,
+``info_hooks.print_table``, ``Result.dump/load`` -- the reference's big
+integration test (tests/test_krotov.py:202-445, ``test_continue_optimization``)
+restated on the plugin path with NumPy plugins, against the reference's own
+log file tests/test_krotov/oct.log (kept as tests/golden/oct.log)."""
+import io
+import logging
+import os
+
+import numpy as np
+import pytest
+
+import krotov_amd
+from krotov_amd import convergence, shapes
+from krotov_amd.result import Result
+
+from helpers import numpy_plugins
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _system():
+    """reference tests/test_krotov.py:136-163 (notebook 01's two-level system, constant guess)."""
+    H0 = -0.5 * np.array([[1, 0], [0, -1]], dtype=complex)
+    H1 = np.array([[0, 1], [1, 0]], dtype=complex)
+    H = [H0, [H1, lambda t, args: 0.2]]
+    psi0, psi1 = np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)
+    objectives = [krotov_amd.Objective(initial_state=psi0, target=psi1, H=H)]
+
+    def S(t):
+        return shapes.flattop(t, t_start=0, t_stop=5, t_rise=0.3, t_fall=0.3, func='sinsq')
+
+    return objectives, {H[1][1]: dict(lambda_a=5, update_shape=S)}, np.linspace(0, 5, 500)
+
+
+def test_continue_optimization_log_and_dumps(tmp_path, caplog):
+    objectives, pulse_options, tlist = _system()
+    prop, mu, vdot = numpy_plugins()
+
+    def overlap(a, b):  # like the default overlap: None when there is no state yet
+        return None if a is None or b is None else vdot(a, b)
+
+    dumpfile = str(tmp_path / "oct_result_{iter:03d}.dump")
+    log = io.StringIO()
+
+    def run(**kw):
+        return krotov_amd.optimize_pulses(
+            objectives, pulse_options=pulse_options, tlist=tlist, propagator=prop, mu=mu, overlap=overlap,
+            norm=np.linalg.norm, chi_constructor=krotov_amd.functionals.chis_re, store_all_pulses=True,
+            info_hook=krotov_amd.info_hooks.print_table(J_T=krotov_amd.functionals.J_T_re, out=log),
+            check_convergence=convergence.Or(
+                convergence.check_monotonic_error, convergence.dump_result(dumpfile, every=2)),
+            **kw)
+
+    with caplog.at_level(logging.WARNING):
+        r1 = run(iter_stop=3, skip_initial_forward_propagation=True)
+    assert "You should not use `skip_initial_forward_propagation`" in caplog.text
+    assert len(r1.iters) == len(r1.iter_seconds) == len(r1.info_vals) == len(r1.all_pulses) == 4
+    assert len(r1.states) == 1 and len(r1.guess_controls) == len(r1.optimized_controls) == 1
+    assert len(r1.guess_controls[0]) == len(r1.optimized_controls[0]) == len(r1.tlist)
+    assert all(len(p) == len(tlist) - 1 for pulses in r1.all_pulses for p in pulses)
+    assert "3 iterations" in r1.message
+    run(continue_from=r1, iter_stop=3)  # only propagates the guess pulse
+    r2 = run(continue_from=r1, iter_stop=5)
+    assert len(r2.iters) == len(r2.info_vals) == len(r2.all_pulses) == 6 and "5 iterations" in r2.message
+    r3 = run(continue_from=r2, iter_stop=7, skip_initial_forward_propagation=True)
+    assert len(r3.iters) == len(r3.info_vals) == len(r3.all_pulses) == 8 and "7 iterations" in r3.message
+    r4 = run(continue_from=r3, iter_stop=5, skip_initial_forward_propagation=True)  # no-op
+    assert r4.iters == r3.iters and r4.message == r3.message
+    assert r4.start_local_time_str == r3.start_local_time_str
+
+    # the combined log vs the reference's (the seconds column, beyond character 63, differs)
+    got = log.getvalue().splitlines()
+    want = open(os.path.join(GOLDEN, 'oct.log'), encoding='utf8').read().splitlines()
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a[:63] == b[:63]
+
+    # continuing from an incomplete dump
+    caplog.clear()
+    with caplog.at_level(logging.WARNING):
+        loaded = Result.load(str(tmp_path / "oct_result_004.dump"))
+    assert 'Result.objectives contains control placeholders' in caplog.text
+    plain = dict(propagator=prop, mu=mu, overlap=overlap, norm=np.linalg.norm,
+                 chi_constructor=krotov_amd.functionals.chis_re, store_all_pulses=True)
+    with pytest.raises(ValueError, match="objectives must remain unchanged"):
+        krotov_amd.optimize_pulses(objectives, pulse_options, tlist, continue_from=loaded, iter_stop=7,
+                                   skip_initial_forward_propagation=True, **plain)
+    loaded = Result.load(str(tmp_path / "oct_result_004.dump"), objectives=objectives)
+    assert loaded.iters[-1] == 4
+    r5 = krotov_amd.optimize_pulses(objectives, pulse_options, tlist, continue_from=loaded, iter_stop=7,
+                                    info_hook=krotov_amd.functionals.J_T_re,
+                                    skip_initial_forward_propagation=True, **plain)
+    assert r5.iters == r3.iters and len(r5.info_vals) == 8
+    assert abs(r5.info_vals[-1] - r3.info_vals[-1]) < 1e-10  # reference tests/test_krotov.py:426-432
+    assert np.abs(r5.optimized_controls[0] - r3.optimized_controls[0]).max() < 1e-10
+
+    # dumps taken mid-optimisation hold pulses on the intervals: load(finalize=True) maps them onto tlist
+    caplog.clear()
+    with caplog.at_level(logging.WARNING):
+        raw = Result.load(str(tmp_path / "oct_result_004.dump"), objectives=objectives)
+    assert 'not finalized' in caplog.text and len(raw.optimized_controls[0]) == len(tlist) - 1
+    fin = Result.load(str(tmp_path / "oct_result_004.dump"), objectives=objectives, finalize=True)
+    assert len(fin.optimized_controls[0]) == len(tlist)
+    opt_objs = r3.optimized_objectives
+    assert opt_objs[0].H[1][1] is r3.optimized_controls[0] and objectives[0].H[1][1] is not opt_objs[0].H[1][1]
+    with pytest.raises(ValueError, match="Expected 1 controls"):
+        r3.objectives_with_controls([])
+    with pytest.raises(ValueError, match="time grid"):
+        r3.objectives_with_controls([np.zeros(3)])
+
+
+def test_convergence_checks():
+    """Doctest values of reference convergence.py:140-157, 236-262, 316-367."""
+    r = Result()
+    check = convergence.value_below(limit='1e-4', spec=lambda res: res.info_vals[-1], name='J_T')
+    r.info_vals.append(1e-4)
+    assert check(r) is None
+    r.info_vals.append(9e-5)
+    assert check(r) == 'J_T < 1e-4'
+    assert convergence.value_above('0.99', name='F')(r) is None
+    r.info_vals.append(0.999)
+    assert convergence.value_above('0.99', name='F')(r) == 'F > 0.99'
+    r = Result()
+    delta = convergence.delta_below(limit='1e-4', name='ΔJ_T')
+    r.info_vals.append(9e-1)
+    assert delta(r) is None  # only one value yet
+    r.info_vals.append(1e-1)
+    assert delta(r) is None
+    r.info_vals.append(4e-4)
+    assert delta(r) is None
+    r.info_vals.append(3.5e-4)
+    assert delta(r) == 'ΔJ_T < 1e-4'
+    with pytest.raises(IndexError):
+        delta(Result())  # neither value exists
+    r = Result()
+    for v, want in ((9e-1, None), (1e-1, None), (2e-1, 'Loss of monotonic convergence; error decrease < 0')):
+        r.info_vals.append(v)
+        assert convergence.check_monotonic_error(r) == want
+    r = Result()
+    for v, want in ((0.0, None), (0.2, None), (0.15, 'Loss of monotonic convergence; fidelity increase < 0')):
+        r.info_vals.append(v)
+        assert convergence.check_monotonic_fidelity(r) == want
+    either = convergence.Or(convergence.value_below(0.1), convergence.check_monotonic_fidelity)
+    assert either(r) == 'Loss of monotonic convergence; fidelity increase < 0'
+    with pytest.raises(ValueError):
+        convergence.dump_result('x.dump', every=0)
+    r.iters.append(2)
+    assert convergence.dump_result('/nonexistent-dir/x_{iter}.dump', every=2)(r).startswith('Could not store')
+
+
+def test_print_table_layout():
+    """Several pulses with per-pulse columns, ASCII headers, a wide iteration column, custom
+    formats and headers, the monotonicity flags: character for character what the reference's
+    print_table writes (tests/golden/print_table_cases.txt, made by make_reference_goldens.py)."""
+    out = io.StringIO()
+    J = lambda **kw: kw['J']  # noqa: E731
+    common = dict(guess_pulses=[None, None], iter_stop=10, start_time=0.0, stop_time=2.4)
+    hook = krotov_amd.info_hooks.print_table(J_T=J, show_g_a_int_per_pulse=True, out=out)
+    assert hook(iteration=0, J=1.0, g_a_integrals=np.zeros(2), info_vals=[], **common) == 1.0
+    hook(iteration=1, J=0.5, g_a_integrals=np.array([0.1, 0.2]), info_vals=[1.0], **common)
+    hook(iteration=2, J=0.6, g_a_integrals=np.array([0.0, 0.05]), info_vals=[1.0, 0.5], **common)
+    out.write("--\n")
+    hook = krotov_amd.info_hooks.print_table(J_T=J, unicode=False, out=out)
+    one = dict(guess_pulses=[None], iter_stop=12345, start_time=0.0, stop_time=0.0)
+    hook(iteration=0, J=1.0, g_a_integrals=np.zeros(1), info_vals=[], **one)
+    hook(iteration=1, J=0.25, g_a_integrals=np.array([0.5]), info_vals=[1.0], **one)
+    out.write("--\n")
+    hook = krotov_amd.info_hooks.print_table(
+        J_T=J, show_g_a_int_per_pulse=True, out=out,
+        col_formats=('%03d', '%.6f', '%.3e', '%.3e', '%.6f', '%+.1e', '%+.1e', '%4d'),
+        col_headers=('#', 'error', 'ga[{l}]', 'ga', 'total', 'd(error)', 'd(total)', 's'))
+    hook(iteration=0, J=1.0, g_a_integrals=np.zeros(2), info_vals=[], **common)
+    hook(iteration=1, J=0.5, g_a_integrals=np.array([0.1, 0.2]), info_vals=[1.0], **common)
+    want = open(os.path.join(GOLDEN, 'print_table_cases.txt'), encoding='utf8').read()
+    assert out.getvalue() == want
+    with pytest.raises(ValueError, match="exactly 8"):
+        krotov_amd.info_hooks.print_table(J_T=None, col_formats=('%d',))
+    with pytest.raises(ValueError, match="format"):
+        krotov_amd.info_hooks.print_table(J_T=None, col_headers=("i", "J", 3, "g", "J", "dJT", "dJ", "s"))
+    with pytest.raises(ValueError, match="Invalid col_formats"):
+        krotov_amd.info_hooks.print_table(J_T=None, col_formats=('%d', '%.2e', '%.2e', '%.2e %d', '%.2e', '%.2e',
+                                                                 '%.2e', '%d'))

@@ -15,29 +15,7 @@ import krotov_amd
 from krotov_amd import configs, conversions, functionals, shapes
 from oracle import krotov_oracle as ko
 
-from helpers import golden
-
-
-def numpy_plugins(is_super=False):
-    """propagator / mu / overlap callables as in reference notebook 09."""
-
-    def propagator(H, state, dt, c_ops=None, backwards=False, initialize=False):
-        f = (1.0 + 0j) if is_super else -1j
-        if backwards:
-            f = f.conjugate()
-        A = f * H[0]
-        for part in H[1:]:
-            A = A + (f * part[1]) * part[0]
-        return ko.expm_dense(A * dt, use_scipy=False) @ state
-
-    def mu(objs, i_obj, pulses, mapping, i_pulse, n):
-        op = objs[i_obj].H[1 + i_pulse][0]
-        return (lambda s: 1j * (op @ s)) if is_super else (lambda s: op @ s)
-
-    def overlap(a, b):
-        return complex(np.vdot(a, b))
-
-    return propagator, mu, overlap
+from helpers import golden, numpy_plugins
 
 
 def test_controls_roundtrip_and_boundaries():
