@@ -93,7 +93,37 @@ const char *kh_version(void);
 int kh_engine_create(const kh_problem *problem, kh_engine **out);
 void kh_engine_destroy(kh_engine *engine);
 
-/* Which kernel family the engine selected: "tile64" or "generic". */
+/* Sparse operators (large Liouvillians with a few entries per row -- the regime of the
+ * reference's DensityMatrixODEPropagator, propagators.py:162-327, which integrates
+ * d/dt vec(rho) = L vec(rho) with a sparse L).  Same engine, same entry points below;
+ * the exponential action is the same truncated Taylor series with CSR
+ * matrix-vector products, so results agree with the dense path to round-off (the
+ * reference's zvode integration is only accurate to its rtol = 1e-6).
+ *   indptr [N+1], indices [nnz] int32, data [nnz] complex: device pointers;
+ *   data == NULL: operator absent.  ops_adj[i] is the conjugate transpose of
+ *   ops[i] (the adjoint objectives, objectives.py:240-258), supplied by the caller;
+ *   op_norms (upper bounds on the spectral norms, e.g. sqrt(||A||_1 ||A||_inf))
+ *   are required. */
+typedef struct kh_csr {
+    int64_t nnz;
+    const int32_t *indptr;
+    const int32_t *indices;
+    const kh_cdouble *data;
+} kh_csr;
+
+typedef struct kh_problem_csr {
+    int32_t K, N, L, nt, is_super, reserved;  /* as in kh_problem */
+    const double *dt;                          /* host [nt-1] */
+    const kh_csr *ops;                         /* host [K*(1+L)] */
+    const kh_csr *ops_adj;                     /* host [K*(1+L)] */
+    const double *op_norms;                    /* host [K*(1+L)] */
+    double tol, theta_max;                     /* as in kh_problem */
+} kh_problem_csr;
+
+int kh_engine_create_csr(const kh_problem_csr *problem, kh_engine **out);
+
+/* Which kernel family the engine selected: "tile64q2/512", "tile64/512", "tile64/256",
+ * "coop16/mfma", "generic" or "generic/csr". */
 const char *kh_engine_kernel(const kh_engine *engine);
 
 /* Forward propagation of K states over the whole grid under fixed pulses.

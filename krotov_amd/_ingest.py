@@ -24,6 +24,25 @@ def to_dense(op):
     return arr
 
 
+def to_sparse(op):
+    """``scipy.sparse.csr_matrix`` (complex128) of an operator-like object: a
+    SciPy sparse matrix, a Qobj-like whose ``.data`` is one (QuTiP 4), or
+    anything :func:`to_dense` accepts."""
+    import scipy.sparse as sp
+
+    data = getattr(op, 'data', None)
+    if sp.issparse(op):
+        mat = op
+    elif data is not None and sp.issparse(data):
+        mat = data
+    else:
+        mat = to_dense(op)
+    mat = sp.csr_matrix(mat, dtype=np.complex128)
+    if mat.shape[0] != mat.shape[1]:
+        raise ValueError("operator must be a square matrix, got shape %s" % (mat.shape,))
+    return mat
+
+
 def obj_type(x):
     """``x.type`` if it has one ('ket', 'bra', 'oper', 'super'), else None."""
     return getattr(x, 'type', None)

@@ -31,12 +31,39 @@ class kh_problem(ctypes.Structure):
     ]
 
 
+class kh_csr(ctypes.Structure):
+    _fields_ = [
+        ('nnz', ctypes.c_int64),
+        ('indptr', ctypes.c_void_p),
+        ('indices', ctypes.c_void_p),
+        ('data', ctypes.c_void_p),
+    ]
+
+
+class kh_problem_csr(ctypes.Structure):
+    _fields_ = [
+        ('K', ctypes.c_int32),
+        ('N', ctypes.c_int32),
+        ('L', ctypes.c_int32),
+        ('nt', ctypes.c_int32),
+        ('is_super', ctypes.c_int32),
+        ('reserved', ctypes.c_int32),
+        ('dt', ctypes.POINTER(ctypes.c_double)),
+        ('ops', ctypes.POINTER(kh_csr)),
+        ('ops_adj', ctypes.POINTER(kh_csr)),
+        ('op_norms', ctypes.POINTER(ctypes.c_double)),
+        ('tol', ctypes.c_double),
+        ('theta_max', ctypes.c_double),
+    ]
+
+
 # every symbol include/krotov_hip.h declares: name -> (restype, argtypes)
 _P = ctypes.c_void_p
 SYMBOLS = {
     'kh_last_error': (ctypes.c_char_p, []),
     'kh_version': (ctypes.c_char_p, []),
     'kh_engine_create': (ctypes.c_int, [ctypes.POINTER(kh_problem), ctypes.POINTER(_P)]),
+    'kh_engine_create_csr': (ctypes.c_int, [ctypes.POINTER(kh_problem_csr), ctypes.POINTER(_P)]),
     'kh_engine_destroy': (None, [_P]),
     'kh_engine_kernel': (ctypes.c_char_p, [_P]),
     'kh_forward_store': (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),

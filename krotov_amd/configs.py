@@ -276,6 +276,54 @@ def config_shared(K=20, N=96, nt=21, L=2, seed=3):
     )
 
 
+def config_sparse_lindblad(d=12, nt=61, K=3, gamma=0.05):
+    """A driven, damped d-level ladder in Liouville space: nearest-neighbour
+    hopping + anharmonic levels, decay through the lowering operator, control on
+    the level energies.  The Liouvillians (dimension d^2) have a handful of
+    entries per row -- the regime of the reference's DensityMatrixODEPropagator
+    (propagators.py:162-327).  ``H0``/``Hc`` hold dense arrays; see
+    :func:`sparse_ops` for the ``scipy.sparse`` form."""
+    T = 4.0
+    n = np.arange(d)
+    hop = np.diag(np.sqrt(np.arange(1, d)), k=1)
+    H0 = (np.diag(0.3 * n - 0.02 * n * (n - 1)) + 0.25 * (hop + hop.T)).astype(np.complex128)
+    H1 = np.diag(n / (d - 1.0)).astype(np.complex128)
+    C = np.sqrt(gamma) * hop
+    L0 = liouvillian_dense(H0, [C])
+    L1 = liouvillian_dense(H1)
+
+    def guess(t, args):
+        return 0.8 * np.sin(np.pi * t / T) ** 2
+
+    def S(t):
+        return _shapes.flattop(t, t_start=0.0, t_stop=T, t_rise=0.4, func='sinsq')
+
+    basis = np.eye(d, dtype=np.complex128)
+    init = np.array([_vec(np.outer(basis[j], basis[j].conj())) for j in range(K)])
+    target = np.array([_vec(np.outer(basis[(j + 1) % d], basis[(j + 1) % d].conj())) for j in range(K)])
+    return ProblemSpec(
+        name='sparse_lindblad_d%d' % d, H0=[L0] * K, Hc=[[L1]] * K, is_super=True, init=init, target=target,
+        tlist=np.linspace(0, T, nt), controls=[guess], update_shape=S, lambda_a=2.0, chi='re',
+    )
+
+
+def sparse_ops(spec):
+    """``[[op_0, op_1, ...] per objective]`` of a spec as ``scipy.sparse.csr_matrix``
+    objects (one per distinct array, so sharing is preserved)."""
+    import scipy.sparse as sp
+
+    made = {}
+
+    def conv(a):
+        if id(a) not in made:
+            m = sp.csr_matrix(a)
+            m.eliminate_zeros()
+            made[id(a)] = (m, a)
+        return made[id(a)][0]
+
+    return [[conv(spec.H0[k])] + [conv(spec.Hc[k][l]) for l in range(spec.L)] for k in range(spec.K)]
+
+
 # --------------------------------------------------------------------------
 # C5: robustness ensemble (the headline configuration)
 # --------------------------------------------------------------------------

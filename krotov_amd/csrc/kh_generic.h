@@ -11,9 +11,18 @@
 
 #define KH_GEN_THREADS 256
 
+// An operator in compressed-sparse-row form (device pointers); column indices need not be sorted.
+struct KhCsr {
+    long long nnz;
+    const int *indptr;   // [N+1]
+    const int *indices;  // [nnz]
+    const cplx *data;    // [nnz]
+};
+
 struct KhSweepArgs {
     int K, N, L, nt;
-    const cplx *const *ops;   // [K*(1+L)] operator pointers for this direction
+    const cplx *const *ops;   // [K*(1+L)] operator pointers for this direction (CSR engines: the data arrays)
+    const KhCsr *csr;         // [K*(1+L)] sparse operators of this direction, or NULL: dense row-major ops
     const double *op_norms;   // [K*(1+L)]
     const double *dt;         // [nt-1]
     double fre, fim;          // equation-of-motion factor f (propagators.py:94-99)
@@ -49,10 +58,24 @@ __host__ inline size_t kh_gen_lds_bytes(int N) {
 // y[row] = sum_c (h0[row][c] + sum_l eps_l h_l[row][c]) * x[c] for the rows this
 // 16-lane group owns in this pass.  Returns the row sum in every lane of the
 // group (undefined for row >= N).
-__device__ __forceinline__ cplx kh_gen_row_dot(const cplx *const *ops_k, const double *eps, int L, int N, int row,
-                                               int c16, const cplx *x) {
+__device__ __forceinline__ cplx kh_gen_row_dot(const cplx *const *ops_k, const KhCsr *csr_k, const double *eps, int L,
+                                               int N, int row, int c16, const cplx *x) {
     cplx sum = c_make(0.0, 0.0);
-    if (row < N) {
+    if (csr_k != nullptr) {
+        // sparse rows (the reference's DensityMatrixODEPropagator regime, propagators.py:162-327: large
+        // Liouvillians with a few entries per row): the 16 lanes stride over the row's non-zeros
+        if (row < N) {
+            for (int o = 0; o <= L; ++o) {
+                const KhCsr &a = csr_k[o];
+                if (a.data == nullptr) continue;
+                const double w = o == 0 ? 1.0 : eps[o - 1];
+                cplx part = c_make(0.0, 0.0);
+                for (int j = a.indptr[row] + c16; j < a.indptr[row + 1]; j += 16) c_fma(part, a.data[j], x[a.indices[j]]);
+                sum.x = fma(w, part.x, sum.x);
+                sum.y = fma(w, part.y, sum.y);
+            }
+        }
+    } else if (row < N) {
         const size_t off = (size_t)row * N;
         // four column chunks per trip, all operator loads issued before the FMAs:
         // with one load in flight per lane the row stream is latency-bound (~20 GB/s per CU)
@@ -98,8 +121,8 @@ __device__ __forceinline__ cplx kh_gen_row_dot(const cplx *const *ops_k, const d
 // acc <- exp(f * A(eps) * dt) acc, A = H0 + sum eps_l H_l, by s Taylor
 // sub-steps of degree m.  All threads of the workgroup call this.
 __device__ __forceinline__ int kh_gen_expm_action(const KhSweepArgs &p, const cplx *const *ops_k,
-                                                  const double *norms_k, const double *eps, double dt,
-                                                  const KhGenLds &s) {
+                                                  const KhCsr *csr_k, const double *norms_k, const double *eps,
+                                                  double dt, const KhGenLds &s) {
     const int tid = threadIdx.x, N = p.N, L = p.L;
     const int grp = tid >> 4, c16 = tid & 15;  // 16 groups of 16 lanes
     double theta = norms_k[0];
@@ -117,7 +140,7 @@ __device__ __forceinline__ int kh_gen_expm_action(const KhSweepArgs &p, const cp
             const cplx coef = c_make(p.fre * hj, p.fim * hj);
             for (int row0 = 0; row0 < N; row0 += 16) {
                 const int row = row0 + grp;
-                const cplx d = kh_gen_row_dot(ops_k, eps, L, N, row, c16, xin);
+                const cplx d = kh_gen_row_dot(ops_k, csr_k, eps, L, N, row, c16, xin);
                 if (c16 == 0 && row < N) {
                     const cplx t = c_mul(coef, d);
                     xout[row] = t;
@@ -159,7 +182,8 @@ kh_gen_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx 
             const int n = direction > 0 ? step : nt - 2 - step;
             double eps[KH_MAX_L];
             for (int l = 0; l < L; ++l) eps[l] = pulses[(size_t)l * (nt - 1) + n];
-            matvecs += kh_gen_expm_action(p, ops_k, norms_k, eps, p.dt[n], s);
+            matvecs += kh_gen_expm_action(p, ops_k, p.csr ? p.csr + (size_t)k * (1 + L) : nullptr, norms_k, eps,
+                                          p.dt[n], s);
             if (store != nullptr) {
                 const int idx = direction > 0 ? n + 1 : n;
                 for (int i = tid; i < N; i += KH_GEN_THREADS) store[((size_t)k * nt + idx) * N + i] = s.acc[i];
@@ -220,9 +244,10 @@ __device__ __forceinline__ void kh_gen_partials(const KhSweepArgs &p, const KhUp
             cplx ov = c_make(0.0, 0.0);  // <chi + hs * dphi | H_l phi>, partial over this thread's rows
             if (h != nullptr) {
                 const cplx *one_op[1] = {h};
+                const KhCsr *one_csr = p.csr ? p.csr + (size_t)k * (1 + L) + 1 + l : nullptr;
                 for (int row0 = 0; row0 < N; row0 += 16) {
                     const int row = row0 + grp;
-                    const cplx d = kh_gen_row_dot(one_op, zero_eps, 0, N, row, c16, s.xa);
+                    const cplx d = kh_gen_row_dot(one_op, one_csr, zero_eps, 0, N, row, c16, s.xa);
                     if (c16 == 0 && row < N) {
                         cplx bra = s.chi[row];
                         if (u.sigma != nullptr) {  // second order: + 0.5 sigma <phi - phi_prev | (optimize.py:469)
@@ -323,7 +348,8 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
             __syncthreads();
             if (u.fw_store != nullptr && n == 0)
                 for (int i = tid; i < N; i += KH_GEN_THREADS) u.fw_store[((size_t)k * nt) * N + i] = s.acc[i];
-            matvecs += kh_gen_expm_action(p, ops_k, norms_k, eps, dt, s);
+            matvecs += kh_gen_expm_action(p, ops_k, p.csr ? p.csr + (size_t)k * (1 + L) : nullptr, norms_k, eps, dt,
+                                          s);
             for (int i = tid; i < N; i += KH_GEN_THREADS) u.phi[(size_t)k * N + i] = s.acc[i];
             if (u.fw_store != nullptr)
                 for (int i = tid; i < N; i += KH_GEN_THREADS) u.fw_store[((size_t)k * nt + n + 1) * N + i] = s.acc[i];

@@ -60,6 +60,8 @@ struct kh_engine {
     double *d_norms = nullptr;        // [K*(1+L)]
     double *d_dt = nullptr;           // [nt-1]
     double *d_deg_theta = nullptr;    // [KH_MAX_DEGREE+1] degree thresholds for tol
+    KhCsr *d_csr_fw = nullptr;        // [K*(1+L)] sparse operators (kh_engine_create_csr), else NULL
+    KhCsr *d_csr_bw = nullptr;        // [K*(1+L)] their conjugate transposes
     const cplx **d_sq_fw = nullptr;   // [K*3] P0, P1, P2 of A^2 (q2 kernels), forward operators
     const cplx **d_sq_bw = nullptr;   // [K*3] the same for the adjoint operators
     std::vector<void *> owned;        // adjoint operator copies
@@ -97,7 +99,7 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
         case KIND_TILE_RPT1: return "tile64/512";
         case KIND_TILE_Q2: return "tile64q2/512";
         case KIND_COOP: return "coop16/mfma";
-        default: return "generic";
+        default: return e->d_csr_fw != nullptr ? "generic/csr" : "generic";
     }
 }
 
@@ -108,6 +110,7 @@ static KhSweepArgs sweep_args(const kh_engine *e, bool backward) {
     p.L = e->L;
     p.nt = e->nt;
     p.ops = backward ? e->d_ops_bw : e->d_ops_fw;
+    p.csr = backward ? e->d_csr_bw : e->d_csr_fw;
     p.op_norms = e->d_norms;
     p.dt = e->d_dt;
     // equation-of-motion factor (propagators.py:94-99): -i, conj for backwards; 1 for Liouvillians
@@ -134,6 +137,8 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_norms);
     (void)hipFree(e->d_dt);
     (void)hipFree(e->d_deg_theta);
+    (void)hipFree(e->d_csr_fw);
+    (void)hipFree(e->d_csr_bw);
     (void)hipFree((void *)e->d_sq_fw);
     (void)hipFree((void *)e->d_sq_bw);
     (void)hipFree(e->d_phi);
@@ -148,7 +153,9 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     delete e;
 }
 
-extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
+// csr_fw / csr_bw: [K*(1+L)] sparse operators and their conjugate transposes (pr->ops then holds their
+// data arrays), or both NULL for dense row-major operators
+static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_csr *csr_bw, kh_engine **out) {
     if (pr == nullptr || out == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
     *out = nullptr;
     if (pr->K < 1 || pr->N < 1 || pr->L < 0 || pr->nt < 2)
@@ -197,6 +204,10 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
             bw[i] = nullptr;
             continue;
         }
+        if (csr_fw != nullptr) {  // the caller supplies the conjugate transposes
+            bw[i] = (const cplx *)csr_bw[i].data;
+            continue;
+        }
         auto it = adj_of.find(src);
         if (it == adj_of.end()) {
             cplx *dst = nullptr;
@@ -214,6 +225,13 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
     KH_HIP_E(hipMemcpy((void *)e->d_ops_fw, fw.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
     KH_HIP_E(hipMemcpy((void *)e->d_ops_bw, bw.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
     KH_HIP_E(hipMalloc(&e->d_norms, sizeof(double) * nops));
+    if (csr_fw != nullptr) {
+        static_assert(sizeof(KhCsr) == sizeof(kh_csr), "kh_csr layout");
+        KH_HIP_E(hipMalloc(&e->d_csr_fw, sizeof(KhCsr) * nops));
+        KH_HIP_E(hipMalloc(&e->d_csr_bw, sizeof(KhCsr) * nops));
+        KH_HIP_E(hipMemcpy(e->d_csr_fw, csr_fw, sizeof(KhCsr) * nops, hipMemcpyHostToDevice));
+        KH_HIP_E(hipMemcpy(e->d_csr_bw, csr_bw, sizeof(KhCsr) * nops, hipMemcpyHostToDevice));
+    }
     if (pr->op_norms != nullptr) {
         KH_HIP_E(hipMemcpy(e->d_norms, pr->op_norms, sizeof(double) * nops, hipMemcpyHostToDevice));
     } else {
@@ -234,7 +252,7 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
     const int max_wgs = e->num_cus < 64 * KH_GATHER_CHUNKS ? e->num_cus : 64 * KH_GATHER_CHUNKS;
     e->grid_update = e->K < max_wgs ? e->K : max_wgs;
     const char *force = getenv("KH_KERNEL");  // "generic" | "tile256" | "tile512" (testing)
-    const bool tile_ok = e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && e->K <= max_wgs;
+    const bool tile_ok = csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && e->K <= max_wgs;
     if (tile_ok && !(force && strcmp(force, "generic") == 0)) {
         // two waves per SIMD are needed to keep the fp64 FMA pipe issuing back to back
         e->kind = KIND_TILE_RPT1;
@@ -250,7 +268,7 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
         for (size_t i = 0; i < nops && shared; ++i) shared = fw[i] == fw[i % (size_t)(1 + e->L)];
         const int G = (e->N + 15) / 16, Y = (e->K + KH_COOP_COLS - 1) / KH_COOP_COLS;
         const bool forced = force && strcmp(force, "coop") == 0;
-        const bool fits = shared && e->N <= 480 && e->L <= KH_COOP_MAX_L && G * Y <= max_wgs;
+        const bool fits = csr_fw == nullptr && shared && e->N <= 480 && e->L <= KH_COOP_MAX_L && G * Y <= max_wgs;
         if (fits && (forced || (e->N > KH_TILE_N && force == nullptr))) {
             e->kind = KIND_COOP;
             e->coop_G = G;
@@ -336,6 +354,42 @@ extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
 #undef KH_HIP_E
     *out = e;
     return KH_OK;
+}
+
+extern "C" int kh_engine_create(const kh_problem *pr, kh_engine **out) {
+    return engine_create(pr, nullptr, nullptr, out);
+}
+
+extern "C" int kh_engine_create_csr(const kh_problem_csr *pc, kh_engine **out) {
+    if (pc == nullptr || out == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (pc->ops == nullptr || pc->ops_adj == nullptr || pc->op_norms == nullptr)
+        return kh_fail(KH_ERR_INVALID, "ops, ops_adj and op_norms are required for sparse operators");
+    if (pc->K < 1 || pc->L < 0) return kh_fail(KH_ERR_INVALID, "bad sizes K=%d L=%d", pc->K, pc->L);
+    const size_t nops = (size_t)pc->K * (1 + pc->L);
+    std::vector<const kh_cdouble *> data(nops);
+    for (size_t i = 0; i < nops; ++i) {
+        const kh_csr &a = pc->ops[i], &b = pc->ops_adj[i];
+        if ((a.data == nullptr) != (b.data == nullptr))
+            return kh_fail(KH_ERR_INVALID, "operator %zu: ops and ops_adj must both be present or both absent", i);
+        if (a.data != nullptr && (a.indptr == nullptr || a.indices == nullptr || b.indptr == nullptr ||
+                                  b.indices == nullptr || a.nnz != b.nnz))
+            return kh_fail(KH_ERR_INVALID, "operator %zu: incomplete CSR arrays", i);
+        data[i] = a.data;
+    }
+    kh_problem pr;
+    pr.K = pc->K;
+    pr.N = pc->N;
+    pr.L = pc->L;
+    pr.nt = pc->nt;
+    pr.is_super = pc->is_super;
+    pr.reserved = 0;
+    pr.dt = pc->dt;
+    pr.ops = data.data();
+    pr.op_norms = pc->op_norms;
+    pr.tol = pc->tol;
+    pr.theta_max = pc->theta_max;
+    return engine_create(&pr, pc->ops, pc->ops_adj, out);
 }
 
 // ---------------------------------------------------------------------------

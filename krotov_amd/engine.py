@@ -22,6 +22,10 @@ __all__ = ['HipKrotovEngine', 'LAST_ENGINE']
 _last_engine = None
 
 
+def _is_sparse(op):
+    return op is not None and hasattr(op, 'tocsr') and hasattr(op, 'nnz')
+
+
 def LAST_ENGINE():
     """The most recently created engine that is still alive (for benchmarks
     that need the per-launch timings of an engine built inside optimize_pulses)."""
@@ -62,52 +66,16 @@ class HipKrotovEngine:
         self.nt = len(dt) + 1
         self._dt = dt
         self._handle = ctypes.c_void_p()
-        # upload each distinct operator once
         self._op_tensors = {}
-        norms_cache = {}
-        ptrs = (ctypes.c_void_p * (self.K * (1 + self.L)))()
-        norms = np.zeros(self.K * (1 + self.L), dtype=np.float64)
         self.N = None
+        for k, row in enumerate(ops):
+            if len(row) != 1 + self.L:
+                raise ValueError("objective %d has %d operators, expected %d" % (k, len(row), 1 + self.L))
         with torch.cuda.device(self.device):
-            for k, row in enumerate(ops):
-                if len(row) != 1 + self.L:
-                    raise ValueError("objective %d has %d operators, expected %d" % (k, len(row), 1 + self.L))
-                for j, op in enumerate(row):
-                    idx = k * (1 + self.L) + j
-                    if op is None:
-                        ptrs[idx] = None
-                        continue
-                    key = id(op)
-                    if key not in self._op_tensors:
-                        if isinstance(op, torch.Tensor):
-                            host = op.detach().cpu().numpy()
-                        else:
-                            host = np.asarray(op)
-                        host = np.ascontiguousarray(host, dtype=np.complex128)
-                        if host.ndim != 2 or host.shape[0] != host.shape[1]:
-                            raise ValueError("operators must be square matrices")
-                        if self.N is None:
-                            self.N = host.shape[0]
-                        elif host.shape[0] != self.N:
-                            raise ValueError("all operators must have the same dimension")
-                        t = torch.from_numpy(host).to(self.device)
-                        self._op_tensors[key] = (t, op)  # keep `op` alive: id() stays unique
-                        norms_cache[key] = float(np.linalg.norm(host, 2)) if host.size else 0.0
-                    ptrs[idx] = self._op_tensors[key][0].data_ptr()
-                    norms[idx] = norms_cache[key]
-            if op_norms is not None:
-                norms = np.ascontiguousarray(np.asarray(op_norms, dtype=np.float64).reshape(-1))
-                if norms.size != self.K * (1 + self.L):
-                    raise ValueError("op_norms must have K*(1+L) entries")
-            pr = _lib.kh_problem()
-            pr.K, pr.N, pr.L, pr.nt = self.K, self.N, self.L, self.nt
-            pr.is_super = 1 if self.is_super else 0
-            pr.dt = dt.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-            pr.ops = ctypes.cast(ptrs, ctypes.POINTER(ctypes.c_void_p))
-            pr.op_norms = norms.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-            pr.tol = float(tol)
-            pr.theta_max = float(theta_max)
-            _lib.check(self._lib.kh_engine_create(ctypes.byref(pr), ctypes.byref(self._handle)))
+            if any(_is_sparse(op) for row in ops for op in row):
+                norms = self._create_sparse(ops, dt, op_norms, tol, theta_max)
+            else:
+                norms = self._create_dense(ops, dt, op_norms, tol, theta_max)
         self.op_norms = norms.reshape(self.K, 1 + self.L)
         self.kernel = self._lib.kh_engine_kernel(self._handle).decode()
         # optional per-launch timing with HIP events on the launch stream
@@ -115,6 +83,112 @@ class HipKrotovEngine:
         self._events = {'forward': [], 'backward': [], 'update': []}
         global _last_engine
         _last_engine = weakref.ref(self)
+
+    def _check_dim(self, shape):
+        if len(shape) != 2 or shape[0] != shape[1]:
+            raise ValueError("operators must be square matrices")
+        if self.N is None:
+            self.N = shape[0]
+        elif shape[0] != self.N:
+            raise ValueError("all operators must have the same dimension")
+
+    def _norms(self, norms, op_norms):
+        if op_norms is not None:
+            norms = np.ascontiguousarray(np.asarray(op_norms, dtype=np.float64).reshape(-1))
+            if norms.size != self.K * (1 + self.L):
+                raise ValueError("op_norms must have K*(1+L) entries")
+        return norms
+
+    def _create_dense(self, ops, dt, op_norms, tol, theta_max):
+        """Dense row-major operators; each distinct object is uploaded once."""
+        n_ops = self.K * (1 + self.L)
+        ptrs = (ctypes.c_void_p * n_ops)()
+        norms = np.zeros(n_ops, dtype=np.float64)
+        norms_cache = {}
+        for k, row in enumerate(ops):
+            for j, op in enumerate(row):
+                idx = k * (1 + self.L) + j
+                if op is None:
+                    ptrs[idx] = None
+                    continue
+                key = id(op)
+                if key not in self._op_tensors:
+                    host = op.detach().cpu().numpy() if isinstance(op, torch.Tensor) else np.asarray(op)
+                    host = np.ascontiguousarray(host, dtype=np.complex128)
+                    self._check_dim(host.shape)
+                    t = torch.from_numpy(host).to(self.device)
+                    self._op_tensors[key] = (t, op)  # keep `op` alive: id() stays unique
+                    norms_cache[key] = float(np.linalg.norm(host, 2)) if host.size else 0.0
+                ptrs[idx] = self._op_tensors[key][0].data_ptr()
+                norms[idx] = norms_cache[key]
+        norms = self._norms(norms, op_norms)
+        pr = _lib.kh_problem()
+        pr.K, pr.N, pr.L, pr.nt = self.K, self.N, self.L, self.nt
+        pr.is_super = 1 if self.is_super else 0
+        pr.dt = dt.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        pr.ops = ctypes.cast(ptrs, ctypes.POINTER(ctypes.c_void_p))
+        pr.op_norms = norms.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        pr.tol = float(tol)
+        pr.theta_max = float(theta_max)
+        _lib.check(self._lib.kh_engine_create(ctypes.byref(pr), ctypes.byref(self._handle)))
+        return norms
+
+    def _create_sparse(self, ops, dt, op_norms, tol, theta_max):
+        """``scipy.sparse`` operators (any mix with dense ones, which are converted):
+        CSR arrays of every distinct operator and of its conjugate transpose go to
+        the device once; spectral norms are bounded by sqrt(||A||_1 ||A||_inf)."""
+        import scipy.sparse as sp
+
+        n_ops = self.K * (1 + self.L)
+        fw = (_lib.kh_csr * n_ops)()
+        bw = (_lib.kh_csr * n_ops)()
+        norms = np.zeros(n_ops, dtype=np.float64)
+        cache = {}
+
+        def upload(mat):
+            mat = sp.csr_matrix(mat, dtype=np.complex128)
+            mat.sum_duplicates()
+            arrays = (
+                torch.from_numpy(np.ascontiguousarray(mat.indptr, dtype=np.int32)).to(self.device),
+                torch.from_numpy(np.ascontiguousarray(mat.indices, dtype=np.int32)).to(self.device),
+                torch.from_numpy(np.ascontiguousarray(mat.data, dtype=np.complex128)).to(self.device),
+            )
+            return arrays, int(mat.nnz)
+
+        def fill(slot, arrays, nnz):
+            slot.nnz = nnz
+            slot.indptr, slot.indices, slot.data = (a.data_ptr() for a in arrays)
+
+        for k, row in enumerate(ops):
+            for j, op in enumerate(row):
+                idx = k * (1 + self.L) + j
+                if op is None:
+                    continue
+                key = id(op)
+                if key not in cache:
+                    mat = sp.csr_matrix(op.detach().cpu().numpy() if isinstance(op, torch.Tensor) else op)
+                    self._check_dim(mat.shape)
+                    a_fw, nnz = upload(mat)
+                    a_bw, _ = upload(mat.conj().T)
+                    bound = float(np.sqrt(abs(mat).sum(axis=0).max() * abs(mat).sum(axis=1).max())) if nnz else 0.0
+                    cache[key] = (a_fw, a_bw, nnz, bound)
+                    self._op_tensors[key] = ((a_fw, a_bw), op)
+                a_fw, a_bw, nnz, bound = cache[key]
+                fill(fw[idx], a_fw, nnz)
+                fill(bw[idx], a_bw, nnz)
+                norms[idx] = bound
+        norms = self._norms(norms, op_norms)
+        pr = _lib.kh_problem_csr()
+        pr.K, pr.N, pr.L, pr.nt = self.K, self.N, self.L, self.nt
+        pr.is_super = 1 if self.is_super else 0
+        pr.dt = dt.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        pr.ops = fw
+        pr.ops_adj = bw
+        pr.op_norms = norms.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        pr.tol = float(tol)
+        pr.theta_max = float(theta_max)
+        _lib.check(self._lib.kh_engine_create_csr(ctypes.byref(pr), ctypes.byref(self._handle)))
+        return norms
 
     def _timed(self, name):
         """Context manager recording HIP events around a launch when profiling."""

@@ -35,7 +35,7 @@ from functools import partial
 import numpy as np
 
 from . import functionals as _functionals
-from ._ingest import obj_type, state_to_vector, to_dense, vector_to_state
+from ._ingest import obj_type, state_to_vector, to_dense, to_sparse, vector_to_state
 from .conversions import (
     control_onto_interval,
     discretize,
@@ -421,11 +421,16 @@ class _HipBackend:
         self.K_total = K_total
         L = n_controls
         dense = {}
+        props = propagator if isinstance(propagator, list) else [propagator]
+        # operators stay in CSR form on the device when the propagator asks for it
+        # (DensityMatrixODEPropagator / HipExpm(sparse=True): large sparse Liouvillians)
+        self.sparse = any(isinstance(p, HipExpm) and getattr(p, 'sparse', False) for p in props)
+        convert = to_sparse if self.sparse else to_dense
 
         def dense_of(op):
             key = id(op)
             if key not in dense:
-                dense[key] = (to_dense(op), op)
+                dense[key] = (convert(op), op)
             return dense[key][0]
 
         sums = {}
@@ -444,7 +449,6 @@ class _HipBackend:
             return sums[key][0]
 
         liouville = None
-        props = propagator if isinstance(propagator, list) else [propagator]
         for p in props:
             if isinstance(p, HipExpm) and p.liouville is not None:
                 liouville = bool(p.liouville)

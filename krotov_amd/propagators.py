@@ -21,7 +21,7 @@ import numpy as np
 
 from ._ingest import obj_type, state_to_vector, to_dense, vector_to_state
 
-__all__ = ['expm', 'Propagator', 'HipExpm']
+__all__ = ['expm', 'Propagator', 'HipExpm', 'DensityMatrixODEPropagator']
 
 
 class Propagator(ABC):
@@ -104,10 +104,33 @@ def expm(H, state, dt, c_ops=None, backwards=False, initialize=False):
 
 class HipExpm(Propagator):
     """:func:`expm` as a :class:`Propagator` object with an explicit
-    ``liouville`` switch (None = infer from ``.type`` / state shape)."""
+    ``liouville`` switch (None = infer from ``.type`` / state shape).  With
+    ``sparse=True`` ``optimize_pulses`` keeps the operators in CSR form on the
+    device (large operators with a few entries per row); results are the same
+    to round-off."""
 
-    def __init__(self, liouville=None):
+    def __init__(self, liouville=None, sparse=False):
         self.liouville = liouville
+        self.sparse = bool(sparse)
 
     def __call__(self, H, state, dt, c_ops=None, backwards=False, initialize=False):
         return _single_step(H, state, dt, c_ops, backwards, self.liouville)
+
+
+class DensityMatrixODEPropagator(HipExpm):
+    """Drop-in for ``krotov.propagators.DensityMatrixODEPropagator`` (reference
+    propagators.py:162-327): density matrices under a sparse Liouvillian
+    ``d/dt vec(rho) = L vec(rho)`` (``H`` is the Liouvillian in nested-list form,
+    ``c_ops`` empty).  The reference integrates with SciPy's ``zvode`` to
+    ``rtol``/``atol``; here every interval is the exponential action of the
+    sparse generator to machine precision (CSR matrix-vector products inside the
+    same sweep kernels), so the integrator options are accepted for
+    compatibility and have no effect, and the object holds no state
+    (``reentrant`` is moot: one instance serves any number of objectives)."""
+
+    def __init__(self, method='adams', order=12, atol=1e-8, rtol=1e-6, nsteps=1000, first_step=0, min_step=0,
+                 max_step=0, reentrant=False):
+        super().__init__(liouville=True, sparse=True)
+        self.method, self.order, self.atol, self.rtol = method, order, atol, rtol
+        self.nsteps, self.first_step, self.min_step, self.max_step = nsteps, first_step, min_step, max_step
+        self.reentrant = reentrant
