@@ -90,7 +90,7 @@ struct kh_engine {
 
 extern "C" const char *kh_last_error(void) { return g_last_error.c_str(); }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.1 (gfx950; tile64 + generic kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.2 (gfx950; tile64q2, tile64, coop16/mfma, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
