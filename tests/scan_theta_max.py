@@ -1,5 +1,11 @@
+"""Dev check (GPU, run by hand: python tests/scan_theta_max.py): Taylor sub-step bound theta_max of the
+cooperative kernels vs rounds per interval and error against the oracle.  Lives under tests/ because it uses the
+oracle (test infrastructure)."""
 import sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from krotov_amd import configs
 from krotov_amd.engine import HipKrotovEngine
