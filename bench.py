@@ -17,6 +17,7 @@ objectives are sharded over the ranks (weak scaling: 256 per GPU) and the L
 update sums are all-reduced once per time interval over RCCL.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -172,12 +173,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    stamps = []
+
     def hook(**kw):
         it = kw['iteration']
+        if os.environ.get('KH_BENCH_DEBUG'):
+            torch.cuda.synchronize()
+            stamps.append((it, time.perf_counter()))
         if it == args.warmup:
             eng = _engine_mod.LAST_ENGINE()
             if eng is not None:
                 eng.kernel_times_ms(reset=True)
+            gc.collect()  # set-up garbage (K objectives, nested lists) is collected before, not inside, the timed steps
             barrier()
             marks['t0'] = time.perf_counter()
         elif it == n_iter:
@@ -192,6 +199,8 @@ def main():
         info_hook=hook, iter_stop=n_iter, process_group=group,
     )
     elapsed = marks['t1'] - marks['t0']
+    if stamps and rank == 0:
+        print('per-iteration ms:', [round(1e3 * (b[1] - a[1]), 2) for a, b in zip(stamps, stamps[1:])], file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -104,6 +104,11 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
     const double h = nsub == 1 ? dt : dt / nsub;
     const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
     const int phases = (m + 1) >> 1;
+    if (store_in != nullptr && wave == 0 && lane < N) {
+        // the interval's incoming state goes to HBM from here (one LDS read + one fire-and-forget
+        // coalesced store, outside the phase loop so the loop carries no exec-mask juggling for it)
+        store_in[lane] = buf[cur][lane];
+    }
     for (int sub = 0; sub < nsub; ++sub) {
         // this lane's share of sum_p h/(2p+1) A t_2p: the odd-term sum without its factor f
         cplx sA = c_make(0.0, 0.0);
@@ -114,11 +119,6 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
             cplx xv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[j] = buf[cur][cg + 8 * j];
-            if (store_in != nullptr && sub == 0 && ph == 0 && wave == 0 && lane < N) {
-                // the interval's incoming state goes to HBM from here: one extra LDS read
-                // issued with the vector reads, one fire-and-forget coalesced store
-                store_in[lane] = buf[cur][lane];
-            }
             const bool last = (ph + 1 == phases);
             cplx yb = c_make(0.0, 0.0);
 #pragma unroll
