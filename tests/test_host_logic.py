@@ -307,6 +307,41 @@ def test_info_hook_and_convergence_contract():
     assert len(res.info_vals) == 3 and res.info_vals[2] < res.info_vals[0]
 
 
+def test_sparse_ingestion_and_ode_propagator_surface():
+    """to_sparse: SciPy matrices, QuTiP-4-like objects (sparse .data), dense arrays; the
+    DensityMatrixODEPropagator drop-in keeps the reference's constructor (propagators.py:180-205)."""
+    import scipy.sparse as sp
+
+    from krotov_amd._ingest import to_sparse
+    from krotov_amd.optimize import _use_device_path
+    from krotov_amd.propagators import DensityMatrixODEPropagator, HipExpm
+
+    a = np.array([[0, 2j, 0], [0, 0, 0], [1, 0, 3]], dtype=complex)
+
+    class QobjLike:
+        def __init__(self, arr):
+            self.data = sp.csr_matrix(arr)
+
+        def full(self):
+            return self.data.toarray()
+
+    for src in (a, sp.coo_matrix(a), sp.csc_matrix(a), QobjLike(a)):
+        m = to_sparse(src)
+        assert sp.isspmatrix_csr(m) and m.dtype == np.complex128 and np.array_equal(m.toarray(), a)
+    with pytest.raises(ValueError):
+        to_sparse(np.zeros((2, 3)))
+    p = DensityMatrixODEPropagator(method='bdf', order=5, atol=1e-10, rtol=1e-8, nsteps=10, reentrant=True)
+    assert (p.method, p.order, p.atol, p.rtol, p.nsteps, p.reentrant) == ('bdf', 5, 1e-10, 1e-8, 10, True)
+    assert p.sparse and p.liouville is True and isinstance(p, HipExpm) and not HipExpm().sparse
+
+    class Obj:
+        c_ops = []
+
+    assert _use_device_path(p, None, None, None, 'array', [Obj()])
+    assert _use_device_path([p, HipExpm()], None, None, None, 'array', [Obj(), Obj()])
+    assert not _use_device_path(lambda *a, **k: None, None, None, None, 'array', [Obj()])
+
+
 def test_device_path_fails_loudly_without_gpu():
     import torch
 
