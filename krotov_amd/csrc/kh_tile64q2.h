@@ -240,8 +240,9 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     kh_q2_load_tile(ops_k[1], N, wave, lane, h1);  // also dH/d eps (mu.py:123-134)
     kh_q2_load_tile(sq_k[1], N, wave, lane, p1);
     kh_q2_load_tile(sq_k[2], N, wave, lane, p2);
-    const double nrm0 = p.op_norms[(size_t)k * 2], nrm1 = p.op_norms[(size_t)k * 2 + 1];
-    const double chi_norm = u.chi_norms[k];
+    // (wave-uniform scalars live in SGPRs: the VGPR file is full of operator tiles)
+    const double nrm0 = kh_uniform(p.op_norms[(size_t)k * 2]), nrm1 = kh_uniform(p.op_norms[(size_t)k * 2 + 1]);
+    const double chi_norm = kh_uniform(u.chi_norms[k]);
 
     cplx state = row < N ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     int cur = 0;
@@ -300,8 +301,9 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         return;
     }
 
-    double dt_next = p.dt[u.n_begin], guess_next = u.guess[u.n_begin], shape_next = u.shape[u.n_begin];
-    const double lam = u.lambda[0];
+    double dt_next = kh_uniform(p.dt[u.n_begin]), guess_next = kh_uniform(u.guess[u.n_begin]),
+           shape_next = kh_uniform(u.shape[u.n_begin]);
+    const double lam = kh_uniform(u.lambda[0]);
     KhDegreeCache dc = {12, 1.0, 0.0};
 
 #ifdef KH_TIMING
@@ -330,10 +332,11 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
             D_sh[par][1] = 1.0;
         }
         const double dt = dt_next, guess = guess_next, shape = shape_next;
+        double dt_ld = 0.0, guess_ld = 0.0, shape_ld = 0.0;  // in flight across the barrier
         if (n + 1 < nt - 1) {
-            dt_next = p.dt[n + 1];
-            guess_next = u.guess[n + 1];
-            shape_next = u.shape[n + 1];
+            dt_ld = p.dt[n + 1];
+            guess_ld = u.guess[n + 1];
+            shape_ld = u.shape[n + 1];
         }
         __syncthreads();
 #ifdef KH_TIMING
@@ -344,8 +347,11 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         // ---- pulse update (optimize.py:471-477) ----
         const double d1 = D_sh[par][0];
         const double stepw = shape / lam;
-        const double eps = guess + stepw * d1;
-        g_a_loc += stepw * (d1 * d1) * dt;
+        const double eps = kh_uniform(guess + stepw * d1);
+        g_a_loc = kh_uniform(g_a_loc + stepw * (d1 * d1) * dt);
+        dt_next = kh_uniform(dt_ld);
+        guess_next = kh_uniform(guess_ld);
+        shape_next = kh_uniform(shape_ld);
         if (k == 0 && tid == 0) u.opt[n] = eps;
         // ---- propagate over interval n with the updated pulse (optimize.py:479-491) ----
         int nsub, m;
