@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Per-interval breakdown of the update sweep (needs /tmp/libkrotov_hip_timing.so built with -DKH_TIMING)."""
+"""Per-interval breakdown of the update sweep (needs gpurun_out/libkrotov_hip_timing.so built with -DKH_TIMING; gpurun_out/ is not shipped, so build it on the box: see the command in DESIGN.md section 6)."""
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from krotov_amd import _lib
-_lib.LIB_PATH = '/tmp/libkrotov_hip_timing.so'
+_lib.LIB_PATH = os.environ.get('KH_TIMING_LIB', os.path.join(ROOT, 'gpurun_out', 'libkrotov_hip_timing.so'))
 from krotov_amd import configs
 from krotov_amd.engine import HipKrotovEngine
 import torch
