@@ -31,7 +31,7 @@
 
 #define KH_COOP_THREADS 512
 #define KH_COOP_WAVES 8
-#define KH_COOP_COLS 16
+#define KH_COOP_COLS 16     // MFMA N: a workgroup handles c.cols <= 16 objectives (the rest of the tile is zero)
 #define KH_COOP_OWNERS 256  // threads 0..255 own one element (row r = tid/16, column tid%16) of the block
 #define KH_COOP_RING 32      // blocks in the exchange ring
 #define KH_COOP_MAX_L 2     // controls (the update-sum exchange keeps 16 registers per control in flight)
@@ -39,9 +39,11 @@
 typedef double kh_d4 __attribute__((ext_vector_type(4)));
 
 struct KhCoopArgs {
-    kh_u64 *vbuf;             // [KH_COOP_RING][Y][G*16][4][16] granules
+    kh_u64 *vbuf;             // [KH_COOP_RING][Y][G*16][4][16] granules (columns >= cols unused)
     unsigned int epoch_base;  // rounds of earlier launches (tags are monotonic: the buffer is never cleared)
     int G, Y;                 // row blocks, column groups
+    int cols;                 // objectives per column group: 16, 8, 4 or 2.  Fewer columns = more workgroups, each
+                              // fetching a narrower block per term (the fetch, not the MFMA work, bounds a round)
     int ks;                   // k-steps (of 4 columns) per wave: 32 * ks >= N
     int first_poll_delay;     // s_sleep units (64 cycles) before a round's first fetch
 };
@@ -54,7 +56,7 @@ struct KhCoopLds {
     int abort;
     int pad;
 #ifdef KH_TIMING
-    double tim[5];
+    double tim[7];
 #endif
     double frag[1];  // [ks][2][KH_COOP_THREADS] operator fragment of the current interval (dynamic size)
 };
@@ -143,55 +145,62 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
     // A pass issued before the slowest producer's stores have reached the memory side costs a whole
     // extra round trip: give them a head start, and re-fetch only what was stale afterwards.
     for (int d = 0; d < c.first_poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-    for (int q = 0; q < MAXKS; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[q][i] = 0;  // tag 0 is never a round's tag
-    // first pass through L2 (fast; may see a stale line), then only what was stale, bypassing L2
+    // first pass through L2 (fast; may see a stale line); padding: tag ok, value +0.0
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
         const int row = (wave * c.ks + q) * 4 + (lane >> 4);
-        if (q < c.ks && row < N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[q][i] = (kh_u64)epoch << 32;
+        if (q < c.ks && row < N && col < c.cols) {
             const kh_u64 *sl = kh_coop_slot(c, rid, y, row, col);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 g[q][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    // the usual case -- everything fresh -- must stay cheap: one pass of compares, no reload code
+    bool all_fresh = true;
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) all_fresh = all_fresh && ((unsigned int)(g[q][i] >> 32) == epoch);
 #ifdef KH_TIMING
     {
         bool fresh = true;
 #pragma unroll
         for (int q = 0; q < MAXKS; ++q) {
             const int row = (wave * c.ks + q) * 4 + (lane >> 4);
-            if (q < c.ks && row < N)
+            if (q < c.ks && row < N && col < c.cols)
                 for (int i = 0; i < 4; ++i) fresh = fresh && ((unsigned int)(g[q][i] >> 32) == epoch);
         }
-        if (!__all(fresh)) spins += 1000;
+        const int stale_lanes = __popcll(__ballot(!fresh));
+        if (tid == 0 && blockIdx.x == 0) s.tim[5] += (double)stale_lanes;
     }
     const long long tqf = clock64();
     if (tid == 0 && blockIdx.x == 0) s.tim[4] += (double)(tqf - tq0);
 #endif
-    for (;;) {
+    // otherwise: only what was stale, bypassing L2, until everything carries the round's tag
+    while (!__all(all_fresh)) {
+#ifdef KH_TIMING
+        if (tid == 0 && blockIdx.x == 0) s.tim[6] += 1.0;
+#endif
         bool ok = true;
 #pragma unroll
         for (int q = 0; q < MAXKS; ++q) {
             const int row = (wave * c.ks + q) * 4 + (lane >> 4);
-            if (q < c.ks && row < N) {
+            if (q < c.ks && row < N && col < c.cols) {
                 const kh_u64 *sl = kh_coop_slot(c, rid, y, row, col);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if ((unsigned int)(g[q][i] >> 32) != epoch)
                         g[q][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) g[q][i] = (kh_u64)epoch << 32;  // padding: tag ok, value +0.0
             }
         }
 #pragma unroll
         for (int q = 0; q < MAXKS; ++q)
 #pragma unroll
             for (int i = 0; i < 4; ++i) ok = ok && ((unsigned int)(g[q][i] >> 32) == epoch);
+        all_fresh = ok;
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(2);
         if ((++spins & 63u) == 0) {
@@ -309,10 +318,10 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
 #ifdef KH_TIMING
-    if (tid < 5) s.tim[tid] = 0.0;
+    if (tid < 7) s.tim[tid] = 0.0;
 #endif
-    const int r = tid >> 4, col = tid & 15, row = rowbase + r, k = y * KH_COOP_COLS + col;
-    const bool owner_valid = tid < KH_COOP_OWNERS && row < N;  // (columns beyond K carry zeros)
+    const int r = tid >> 4, col = tid & 15, row = rowbase + r, k = y * c.cols + col;
+    const bool owner_valid = tid < KH_COOP_OWNERS && row < N && col < c.cols;  // (columns beyond K carry zeros)
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
     unsigned int rid = 1;
@@ -347,12 +356,12 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
     }
     if (has_state && state_out != nullptr) state_out[(size_t)k * N + row] = state;
     if (g == 0 && tid == 0 && p.stats != nullptr) {
-        const int cols = min(KH_COOP_COLS, p.K - y * KH_COOP_COLS);
+        const int cols = min(c.cols, p.K - y * c.cols);
         atomicAdd(p.stats, rounds * cols);
 #ifdef KH_TIMING
         p.stats[1] = s.tim[0] / rounds + 1e6 * (double)(long long)(s.tim[4] / rounds);
-        p.stats[2] = s.tim[1] / rounds;
-        p.stats[3] = s.tim[2] / rounds + 1e6 * (s.tim[3] / rounds);
+        p.stats[2] = s.tim[1] / rounds + 1e6 * (double)(long long)(100.0 * s.tim[5] / rounds);
+        p.stats[3] = s.tim[2] / rounds + 1e6 * (double)(long long)(100.0 * s.tim[6] / rounds);
 #endif
     }
 }
@@ -371,8 +380,8 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
     const int N = p.N, nt = p.nt, L = p.L;
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
-    const int r = tid >> 4, col = tid & 15, row = rowbase + r, k = y * KH_COOP_COLS + col;
-    const bool owner_valid = tid < KH_COOP_OWNERS && row < N;
+    const int r = tid >> 4, col = tid & 15, row = rowbase + r, k = y * c.cols + col;
+    const bool owner_valid = tid < KH_COOP_OWNERS && row < N && col < c.cols;
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     const double chi_norm = has_state ? u.chi_norms[k] : 0.0;
@@ -462,7 +471,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
             if (l < L) u.g_a[l] = g_a_loc[l];
     }
     if (g == 0 && tid == 0 && p.stats != nullptr) {
-        const int cols = min(KH_COOP_COLS, p.K - y * KH_COOP_COLS);
+        const int cols = min(c.cols, p.K - y * c.cols);
         atomicAdd(p.stats, rounds * cols);
     }
 }

@@ -51,7 +51,7 @@ struct kh_engine {
     KernelKind kind;
     int grid_update;  // workgroups of the single-launch update sweep
     // cooperative shared-operator kernels (kh_coop.h): row blocks, column groups, k-steps per wave
-    int coop_G = 0, coop_Y = 0, coop_ks = 0;
+    int coop_G = 0, coop_Y = 0, coop_ks = 0, coop_cols = KH_COOP_COLS;
     kh_u64 *d_coop_vbuf = nullptr;
     size_t coop_vbuf_bytes = 0;
     // device-side problem data
@@ -266,7 +266,17 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     {
         bool shared = true;
         for (size_t i = 0; i < nops && shared; ++i) shared = fw[i] == fw[i % (size_t)(1 + e->L)];
-        const int G = (e->N + 15) / 16, Y = (e->K + KH_COOP_COLS - 1) / KH_COOP_COLS;
+        // objectives per workgroup: as few as keeps the grid within the co-resident limit (a round is bound by
+        // the block fetch, which shrinks with the column count; the MFMA work per workgroup does not grow)
+        const int G = (e->N + 15) / 16;
+        int cols = KH_COOP_COLS;
+        if (const char *cenv = getenv("KH_COOP_COLS")) {
+            cols = atoi(cenv);
+            if (cols != 2 && cols != 4 && cols != 8) cols = KH_COOP_COLS;
+        } else {
+            while (cols > 4 && G * ((e->K + cols / 2 - 1) / (cols / 2)) <= max_wgs / 2) cols /= 2;
+        }
+        const int Y = (e->K + cols - 1) / cols;
         const bool forced = force && strcmp(force, "coop") == 0;
         const bool fits = csr_fw == nullptr && shared && e->N <= 480 && e->L <= KH_COOP_MAX_L && G * Y <= max_wgs;
         if (fits && (forced || (e->N > KH_TILE_N && force == nullptr))) {
@@ -274,6 +284,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             e->coop_G = G;
             e->coop_Y = Y;
             e->coop_ks = (e->N + 31) / 32;
+            e->coop_cols = cols;
             e->coop_vbuf_bytes = sizeof(kh_u64) * KH_COOP_RING * (size_t)Y * G * 16 * KH_COOP_COLS * 4;
             KH_HIP_E(hipMalloc(&e->d_coop_vbuf, e->coop_vbuf_bytes));
             e->grid_update = e->K < max_wgs ? e->K : max_wgs;  // (stepwise launches use the generic kernel)
@@ -430,6 +441,7 @@ static KhCoopArgs coop_args(const kh_engine *e) {
     c.G = e->coop_G;
     c.Y = e->coop_Y;
     c.ks = e->coop_ks;
+    c.cols = e->coop_cols;
     const char *d = getenv("KH_COOP_DELAY");  // tuning knob, s_sleep units
     c.first_poll_delay = d ? atoi(d) : 12;
     return c;

@@ -1,9 +1,11 @@
 import os, sys, ctypes
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
+from krotov_amd import _lib
+_lib.LIB_PATH = os.environ.get('KH_TIMING_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'libkrotov_hip_timing.so'))
 from krotov_amd import configs
 from krotov_amd.engine import HipKrotovEngine
-spec = configs.config_c4(nt=201)
+spec = configs.config_c4(nt=1001)
 K, N, L = spec.K, spec.N, spec.L
 ops = [[spec.H0[k]] + [spec.Hc[k][l] for l in range(L)] for k in range(K)]
 eng = HipKrotovEngine(ops, np.diff(spec.tlist), is_super=True)
@@ -15,5 +17,6 @@ for _ in range(2):
 buf = (ctypes.c_double * 4)()
 torch.cuda.synchronize()
 eng._lib.kh_last_stats(eng._handle, buf)
-print('rounds*cols', buf[0], ' cycles/round: poll %.0f (fast pass %d)  mfma+ldswrite %.0f  barrier %.0f  (spins/round %.3f; 1000 = stale after the fast pass)' % (
-    buf[1] % 1e6, int(buf[1] / 1e6), buf[2], buf[3] % 1e6, int(buf[3] / 1e6)))
+print('rounds*cols %d  cycles/round: poll %.0f (fast pass %d)  mfma+lds write %.0f  barrier %.0f | stale lanes after the fast pass %.2f/64, '
+      'agent-scope passes per round %.2f' % (buf[0], buf[1] % 1e6, int(buf[1] / 1e6), buf[2] % 1e6, buf[3] % 1e6,
+                                           int(buf[2] / 1e6) / 100.0, int(buf[3] / 1e6) / 100.0))
