@@ -42,8 +42,8 @@ struct KhCoopArgs {
     kh_u64 *vbuf;             // [KH_COOP_RING][Y][G*16][4][16] granules (columns >= cols unused)
     unsigned int epoch_base;  // rounds of earlier launches (tags are monotonic: the buffer is never cleared)
     int G, Y;                 // row blocks, column groups
-    int cols;                 // objectives per column group: 16, 8, 4 or 2.  Fewer columns = more workgroups, each
-                              // fetching a narrower block per term (the fetch, not the MFMA work, bounds a round)
+    int cols;                 // objectives per column group (the kernels' COLS): 16 or 4.  Fewer columns = more
+                              // workgroups, each fetching a narrower block per term with fewer loads
     int ks;                   // k-steps (of 4 columns) per wave: 32 * ks >= N
     int first_poll_delay;     // s_sleep units (64 cycles) before a round's first fetch
 };
@@ -130,13 +130,19 @@ __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned in
 // every granule carries the round's tag, and multiplies the slice on the matrix cores.  The 8
 // partial blocks are summed through LDS; owner threads get their element in `w`.  Contains two
 // __syncthreads; a timeout raises s.abort before the first.
-template <int MAXKS>
+// COLS (16 or 4) objectives per workgroup.  With 4, a load instruction fetches FOUR k-steps of the narrow
+// block (lane -> k offset lane / 4, column lane % 4) instead of one with 48 idle lanes -- the round is
+// bound by the number of wave-level loads the CU issues (8 waves x 52 at N = 400), not by their bytes --
+// and the elements are moved into the MFMA operand layout with ds_bpermute.
+template <int MAXKS, int COLS>
 __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y,
                                               int N, const KhCoopFrag &f, KhCoopLds &s, int tid, int wave, int lane,
                                               cplx &w) {
+    constexpr int KPL = 16 / COLS;               // k-steps per load group
+    constexpr int NG = (MAXKS + KPL - 1) / KPL;  // load groups
     const unsigned int epoch = c.epoch_base + rid;
-    const int col = lane & 15;
-    kh_u64 g[MAXKS][4];
+    const int lcol = lane % COLS, lk = lane / COLS;  // this lane's element of a load group: k offset, column
+    kh_u64 g[NG][4];
     const long long t0 = wall_clock64();
 #ifdef KH_TIMING
     const long long tq0 = clock64();
@@ -147,33 +153,27 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
     for (int d = 0; d < c.first_poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
     // first pass through L2 (fast; may see a stale line); padding: tag ok, value +0.0
 #pragma unroll
-    for (int q = 0; q < MAXKS; ++q) {
-        const int row = (wave * c.ks + q) * 4 + (lane >> 4);
+    for (int j = 0; j < NG; ++j) {
+        const int kstep = j * KPL + (lk >> 2);  // k-step of this lane's element within the wave's slice
+        const int row = (wave * c.ks) * 4 + j * 4 * KPL + lk;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[q][i] = (kh_u64)epoch << 32;
-        if (q < c.ks && row < N && col < c.cols) {
-            const kh_u64 *sl = kh_coop_slot(c, rid, y, row, col);
+        for (int i = 0; i < 4; ++i) g[j][i] = (kh_u64)epoch << 32;
+        if (kstep < c.ks && row < N) {
+            const kh_u64 *sl = kh_coop_slot(c, rid, y, row, lcol);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                g[q][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     // the usual case -- everything fresh -- must stay cheap: one pass of compares, no reload code
     bool all_fresh = true;
 #pragma unroll
-    for (int q = 0; q < MAXKS; ++q)
+    for (int j = 0; j < NG; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) all_fresh = all_fresh && ((unsigned int)(g[q][i] >> 32) == epoch);
+        for (int i = 0; i < 4; ++i) all_fresh = all_fresh && ((unsigned int)(g[j][i] >> 32) == epoch);
 #ifdef KH_TIMING
     {
-        bool fresh = true;
-#pragma unroll
-        for (int q = 0; q < MAXKS; ++q) {
-            const int row = (wave * c.ks + q) * 4 + (lane >> 4);
-            if (q < c.ks && row < N && col < c.cols)
-                for (int i = 0; i < 4; ++i) fresh = fresh && ((unsigned int)(g[q][i] >> 32) == epoch);
-        }
-        const int stale_lanes = __popcll(__ballot(!fresh));
+        const int stale_lanes = __popcll(__ballot(!all_fresh));
         if (tid == 0 && blockIdx.x == 0) s.tim[5] += (double)stale_lanes;
     }
     const long long tqf = clock64();
@@ -186,20 +186,21 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
 #endif
         bool ok = true;
 #pragma unroll
-        for (int q = 0; q < MAXKS; ++q) {
-            const int row = (wave * c.ks + q) * 4 + (lane >> 4);
-            if (q < c.ks && row < N && col < c.cols) {
-                const kh_u64 *sl = kh_coop_slot(c, rid, y, row, col);
+        for (int j = 0; j < NG; ++j) {
+            const int kstep = j * KPL + (lk >> 2);
+            const int row = (wave * c.ks) * 4 + j * 4 * KPL + lk;
+            if (kstep < c.ks && row < N) {
+                const kh_u64 *sl = kh_coop_slot(c, rid, y, row, lcol);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if ((unsigned int)(g[q][i] >> 32) != epoch)
-                        g[q][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned int)(g[j][i] >> 32) != epoch)
+                        g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 #pragma unroll
-        for (int q = 0; q < MAXKS; ++q)
+        for (int j = 0; j < NG; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ok = ok && ((unsigned int)(g[q][i] >> 32) == epoch);
+            for (int i = 0; i < 4; ++i) ok = ok && ((unsigned int)(g[j][i] >> 32) == epoch);
         all_fresh = ok;
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(2);
@@ -220,11 +221,25 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
     const long long tq1 = clock64();
 #endif
     kh_d4 acc_r = {0.0, 0.0, 0.0, 0.0}, acc_i = {0.0, 0.0, 0.0, 0.0};
+    // MFMA B operand of k-step q: lane -> element [k = 4 q + (lane >> 4)][column lane & 15]
+    const bool col_used = (lane & 15) < COLS;
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
         if (q < c.ks) {
-            const double vr = __longlong_as_double((long long)(((g[q][0] & 0xffffffffull) << 32) | (g[q][1] & 0xffffffffull)));
-            const double vi = __longlong_as_double((long long)(((g[q][2] & 0xffffffffull) << 32) | (g[q][3] & 0xffffffffull)));
+            const int j = q / KPL;
+            int h[4];  // the payload halves: re hi, re lo, im hi, im lo
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = (int)(unsigned int)(g[j][i] & 0xffffffffull);
+            if constexpr (COLS != 16) {
+                const int src = (((q % KPL) * 4 + (lane >> 4)) * COLS + (lane & (COLS - 1))) * 4;  // byte address
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = __builtin_amdgcn_ds_bpermute(src, h[i]);
+            }
+            double vr = __hiloint2double(h[0], h[1]), vi = __hiloint2double(h[2], h[3]);
+            if constexpr (COLS != 16) {
+                vr = col_used ? vr : 0.0;
+                vi = col_used ? vi : 0.0;
+            }
             const double fr = f.re(q), fi = f.im(q);
             acc_r = __builtin_amdgcn_mfma_f64_16x16x4f64(fr, vr, acc_r, 0, 0, 0);
             acc_r = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, -vi, acc_r, 0, 0, 0);
@@ -277,7 +292,7 @@ __device__ __forceinline__ void kh_coop_build(const cplx *const *ops, const doub
 // state <- exp(f A dt) state, term by term; round `rid` holds the state on entry and on exit.
 // Owner threads carry `state`; rid is advanced by the number of rounds.  Returns false if the
 // exchange timed out.
-template <int MAXKS>
+template <int MAXKS, int COLS>
 __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const KhExchange &ex,
                                                     const KhCoopFrag &a, cplx &state, unsigned int &rid,
                                                     KhCoopLds &s, int N, int y, int row, int col,
@@ -287,7 +302,7 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
     for (int sub = 0; sub < nsub; ++sub) {
         for (int j = 1; j <= m; ++j) {
             cplx w;
-            kh_coop_round<MAXKS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+            kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
             if (s.abort) return false;  // (raised before the barriers inside kh_coop_round)
             if (tid < KH_COOP_OWNERS) {
                 const double hj = h / j;
@@ -305,7 +320,7 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
 // ---------------------------------------------------------------------------
 // plain propagation with storage (backward sweep / iteration-0 forward sweep)
 // ---------------------------------------------------------------------------
-template <int MAXKS>
+template <int MAXKS, int COLS>
 __global__ void __launch_bounds__(KH_COOP_THREADS)
 kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__restrict__ pulses,
                     const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out,
@@ -348,7 +363,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
-        if (!kh_coop_expm_action<MAXKS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt, nsub,
+        if (!kh_coop_expm_action<MAXKS, COLS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt, nsub,
                                         m, tid, wave, lane))
             return;
         rounds += (double)nsub * m;
@@ -369,7 +384,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
 // ---------------------------------------------------------------------------
 // forward sweep with sequential pulse update (optimize.py:444-508); single launch, in-kernel sums
 // ---------------------------------------------------------------------------
-template <int MAXKS, bool SO>
+template <int MAXKS, int COLS, bool SO>
 __global__ void __launch_bounds__(KH_COOP_THREADS)
 kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange ex) {
     extern __shared__ __attribute__((aligned(16))) char kh_coop_smem[];
@@ -412,7 +427,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
             if (l >= L) break;
             kh_coop_load_frag<MAXKS>(p.ops[1 + l], N, rowbase, wave, lane, c.ks, a);
             cplx w;
-            kh_coop_round<MAXKS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+            kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
             if (tid < KH_COOP_OWNERS) {
                 cplx ov = c_make(0.0, 0.0);
                 c_fma_conj(ov, bra, w);
@@ -456,7 +471,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
-        if (!kh_coop_expm_action<MAXKS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt, nsub,
+        if (!kh_coop_expm_action<MAXKS, COLS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt, nsub,
                                         m, tid, wave, lane))
             return;
         rounds += (double)nsub * m;

@@ -269,12 +269,11 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         // objectives per workgroup: as few as keeps the grid within the co-resident limit (a round is bound by
         // the block fetch, which shrinks with the column count; the MFMA work per workgroup does not grow)
         const int G = (e->N + 15) / 16;
-        int cols = KH_COOP_COLS;
-        if (const char *cenv = getenv("KH_COOP_COLS")) {
-            cols = atoi(cenv);
-            if (cols != 2 && cols != 4 && cols != 8) cols = KH_COOP_COLS;
-        } else {
-            while (cols > 4 && G * ((e->K + cols / 2 - 1) / (cols / 2)) <= max_wgs / 2) cols /= 2;
+        int cols = G * ((e->K + 3) / 4) <= max_wgs ? 4 : KH_COOP_COLS;
+        if (const char *cenv = getenv("KH_COOP_COLS")) {  // testing
+            const int want = atoi(cenv);
+            if ((want == 4 || want == 16) && G * ((e->K + want - 1) / want) <= max_wgs)
+                cols = want;
         }
         const int Y = (e->K + cols - 1) / cols;
         const bool forced = force && strcmp(force, "coop") == 0;
@@ -447,26 +446,26 @@ static KhCoopArgs coop_args(const kh_engine *e) {
     return c;
 }
 
-template <int MAXKS>
+template <int MAXKS, int COLS>
 static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
                              cplx *out, int direction, hipStream_t st) {
-    static const hipError_t attr = hipFuncSetAttribute((const void *)kh_coop_sweep_store<MAXKS>,
+    static const hipError_t attr = hipFuncSetAttribute((const void *)kh_coop_sweep_store<MAXKS, COLS>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)kh_coop_lds_bytes(15));
     (void)attr;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
-    kh_coop_sweep_store<MAXKS><<<dim3(e->coop_G, e->coop_Y), KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(
+    kh_coop_sweep_store<MAXKS, COLS><<<dim3(e->coop_G, e->coop_Y), KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(
         p, coop_args(e), exchange_args(e, true), pulses, in, store, out, direction);
     return KH_OK;
 }
 
-template <int MAXKS>
+template <int MAXKS, int COLS>
 static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u, const KhExchange &ex,
                               hipStream_t st) {
-    static const hipError_t attr0 = hipFuncSetAttribute((const void *)kh_coop_forward_update<MAXKS, false>,
+    static const hipError_t attr0 = hipFuncSetAttribute((const void *)kh_coop_forward_update<MAXKS, COLS, false>,
                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)kh_coop_lds_bytes(15));
-    static const hipError_t attr1 = hipFuncSetAttribute((const void *)kh_coop_forward_update<MAXKS, true>,
+    static const hipError_t attr1 = hipFuncSetAttribute((const void *)kh_coop_forward_update<MAXKS, COLS, true>,
                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)kh_coop_lds_bytes(15));
     (void)attr0;
@@ -474,9 +473,9 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     const dim3 grid(e->coop_G, e->coop_Y);
     if (u.sigma != nullptr)
-        kh_coop_forward_update<MAXKS, true><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e), u, ex);
+        kh_coop_forward_update<MAXKS, COLS, true><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e), u, ex);
     else
-        kh_coop_forward_update<MAXKS, false><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e), u, ex);
+        kh_coop_forward_update<MAXKS, COLS, false><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e), u, ex);
     return KH_OK;
 }
 
@@ -494,8 +493,12 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     } else if (e->kind == KIND_TILE_RPT1) {
         rc = dispatch_tile_store<1>(e, p, pulses, in, store, out, direction, st);
     } else if (e->kind == KIND_COOP) {
-        rc = e->coop_ks <= 8 ? launch_coop_store<8>(e, p, pulses, in, store, out, direction, st)
-                             : launch_coop_store<16>(e, p, pulses, in, store, out, direction, st);
+        if (e->coop_cols == 4)
+            rc = e->coop_ks <= 8 ? launch_coop_store<8, 4>(e, p, pulses, in, store, out, direction, st)
+                                 : launch_coop_store<16, 4>(e, p, pulses, in, store, out, direction, st);
+        else
+            rc = e->coop_ks <= 8 ? launch_coop_store<8, 16>(e, p, pulses, in, store, out, direction, st)
+                                 : launch_coop_store<16, 16>(e, p, pulses, in, store, out, direction, st);
     } else {
         const size_t lds = kh_gen_lds_bytes(e->N);
         if (lds > 64 * 1024)
@@ -574,7 +577,11 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         else
             kh_q2_forward_update<false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_COOP && !stepwise) {
-        const int rc = e->coop_ks <= 8 ? launch_coop_update<8>(e, p, u, ex, st) : launch_coop_update<16>(e, p, u, ex, st);
+        int rc;
+        if (e->coop_cols == 4)
+            rc = e->coop_ks <= 8 ? launch_coop_update<8, 4>(e, p, u, ex, st) : launch_coop_update<16, 4>(e, p, u, ex, st);
+        else
+            rc = e->coop_ks <= 8 ? launch_coop_update<8, 16>(e, p, u, ex, st) : launch_coop_update<16, 16>(e, p, u, ex, st);
         if (rc != KH_OK) return rc;
     } else if (e->kind != KIND_GENERIC && e->kind != KIND_COOP) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
