@@ -220,9 +220,14 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
 #ifdef KH_TIMING
     const long long tq1 = clock64();
 #endif
+    // COLS = 16: v_mfma_f64_16x16x4 (A: lane -> [row lane & 15][k lane >> 4]; B: [k lane >> 4][column lane & 15];
+    //   C/D: column lane & 15, row (lane >> 4) + 4 reg).
+    // COLS = 4: v_mfma_f64_4x4x4_4b, four independent 4x4x4 blocks per instruction, one per group of four rows
+    //   (layout probed with scripts/ubench_mfma4.hip: A lane 16 k + 4 blk + row -- the SAME lanes as the 16x16x4
+    //   A operand with row index 4 blk + row --, B lane 16 k + 4 blk + column, D lane 16 row + 4 blk + column).
+    //   Exactly the 16 x 4 x 4 product of a k-step at a quarter of the 16x16x4 issue time.
     kh_d4 acc_r = {0.0, 0.0, 0.0, 0.0}, acc_i = {0.0, 0.0, 0.0, 0.0};
-    // MFMA B operand of k-step q: lane -> element [k = 4 q + (lane >> 4)][column lane & 15]
-    const bool col_used = (lane & 15) < COLS;
+    double acc4_r = 0.0, acc4_i = 0.0;
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
         if (q < c.ks) {
@@ -231,26 +236,35 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
 #pragma unroll
             for (int i = 0; i < 4; ++i) h[i] = (int)(unsigned int)(g[j][i] & 0xffffffffull);
             if constexpr (COLS != 16) {
+                // element [k-step q, k = lane >> 4][column lane & 3] sits in load lane (k offset) * COLS + column
                 const int src = (((q % KPL) * 4 + (lane >> 4)) * COLS + (lane & (COLS - 1))) * 4;  // byte address
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = __builtin_amdgcn_ds_bpermute(src, h[i]);
             }
-            double vr = __hiloint2double(h[0], h[1]), vi = __hiloint2double(h[2], h[3]);
-            if constexpr (COLS != 16) {
-                vr = col_used ? vr : 0.0;
-                vi = col_used ? vi : 0.0;
-            }
+            const double vr = __hiloint2double(h[0], h[1]), vi = __hiloint2double(h[2], h[3]);
             const double fr = f.re(q), fi = f.im(q);
-            acc_r = __builtin_amdgcn_mfma_f64_16x16x4f64(fr, vr, acc_r, 0, 0, 0);
-            acc_r = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, -vi, acc_r, 0, 0, 0);
-            acc_i = __builtin_amdgcn_mfma_f64_16x16x4f64(fr, vi, acc_i, 0, 0, 0);
-            acc_i = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, vr, acc_i, 0, 0, 0);
+            if constexpr (COLS == 4) {
+                acc4_r = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vr, acc4_r, 0, 0, 0);
+                acc4_r = __builtin_amdgcn_mfma_f64_4x4x4f64(fi, -vi, acc4_r, 0, 0, 0);
+                acc4_i = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vi, acc4_i, 0, 0, 0);
+                acc4_i = __builtin_amdgcn_mfma_f64_4x4x4f64(fi, vr, acc4_i, 0, 0, 0);
+            } else {
+                acc_r = __builtin_amdgcn_mfma_f64_16x16x4f64(fr, vr, acc_r, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, -vi, acc_r, 0, 0, 0);
+                acc_i = __builtin_amdgcn_mfma_f64_16x16x4f64(fr, vi, acc_i, 0, 0, 0);
+                acc_i = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, vr, acc_i, 0, 0, 0);
+            }
         }
     }
+    if constexpr (COLS == 4) {
+        s.part[wave][0][lane] = acc4_r;
+        s.part[wave][1][lane] = acc4_i;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        s.part[wave][i][lane] = acc_r[i];
-        s.part[wave][4 + i][lane] = acc_i[i];
+        for (int i = 0; i < 4; ++i) {
+            s.part[wave][i][lane] = acc_r[i];
+            s.part[wave][4 + i][lane] = acc_i[i];
+        }
     }
 #ifdef KH_TIMING
     const long long tq2 = clock64();
@@ -267,13 +281,23 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
 #endif
     w = c_make(0.0, 0.0);
     if (tid < KH_COOP_OWNERS) {
-        // C/D layout of v_mfma_f64_16x16x4: column = lane & 15, row = (lane >> 4) + 4 reg
-        const int r = tid >> 4;
-        const int src = (r & 3) * 16 + (tid & 15), reg = r >> 2;
+        const int r = tid >> 4;  // owner of element (row r, column tid & 15)
+        if constexpr (COLS == 4) {
+            if ((tid & 15) < 4) {
+                const int src = 16 * (r & 3) + 4 * (r >> 2) + (tid & 3);  // D lane of row 4 blk + row', column
 #pragma unroll
-        for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
-            w.x += s.part[wv][reg][src];
-            w.y += s.part[wv][4 + reg][src];
+                for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
+                    w.x += s.part[wv][0][src];
+                    w.y += s.part[wv][1][src];
+                }
+            }
+        } else {
+            const int src = (r & 3) * 16 + (tid & 15), reg = r >> 2;
+#pragma unroll
+            for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
+                w.x += s.part[wv][reg][src];
+                w.y += s.part[wv][4 + reg][src];
+            }
         }
     }
     __syncthreads();  // part[] is free for the next round
