@@ -32,7 +32,7 @@
 #define KH_COOP_THREADS 512
 #define KH_COOP_WAVES 8
 #define KH_COOP_COLS 16     // MFMA N: a workgroup handles c.cols <= 16 objectives (the rest of the tile is zero)
-#define KH_COOP_OWNERS 256  // threads 0..255 own one element (row r = tid/16, column tid%16) of the block
+// owner threads: tid < 16 COLS owns element (row tid / COLS, column tid % COLS) of the block (one wave for COLS = 4)
 #define KH_COOP_RING 32      // blocks in the exchange ring
 #define KH_COOP_MAX_L 2     // controls (the update-sum exchange keeps 16 registers per control in flight)
 
@@ -280,19 +280,17 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
     }
 #endif
     w = c_make(0.0, 0.0);
-    if (tid < KH_COOP_OWNERS) {
-        const int r = tid >> 4;  // owner of element (row r, column tid & 15)
+    if (tid < 16 * COLS) {
+        const int r = tid / COLS, oc = tid % COLS;  // owner of element (row r, column oc)
         if constexpr (COLS == 4) {
-            if ((tid & 15) < 4) {
-                const int src = 16 * (r & 3) + 4 * (r >> 2) + (tid & 3);  // D lane of row 4 blk + row', column
+            const int src = 16 * (r & 3) + 4 * (r >> 2) + oc;  // D lane of row 4 blk + row', column
 #pragma unroll
-                for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
-                    w.x += s.part[wv][0][src];
-                    w.y += s.part[wv][1][src];
-                }
+            for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
+                w.x += s.part[wv][0][src];
+                w.y += s.part[wv][1][src];
             }
         } else {
-            const int src = (r & 3) * 16 + (tid & 15), reg = r >> 2;
+            const int src = (r & 3) * 16 + oc, reg = r >> 2;
 #pragma unroll
             for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
                 w.x += s.part[wv][reg][src];
@@ -328,7 +326,7 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
             cplx w;
             kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
             if (s.abort) return false;  // (raised before the barriers inside kh_coop_round)
-            if (tid < KH_COOP_OWNERS) {
+            if (tid < 16 * COLS) {
                 const double hj = h / j;
                 const cplx t = c_mul(c_make(fre * hj, fim * hj), w);
                 state.x += t.x;
@@ -359,8 +357,8 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
 #ifdef KH_TIMING
     if (tid < 7) s.tim[tid] = 0.0;
 #endif
-    const int r = tid >> 4, col = tid & 15, row = rowbase + r, k = y * c.cols + col;
-    const bool owner_valid = tid < KH_COOP_OWNERS && row < N && col < c.cols;  // (columns beyond K carry zeros)
+    const int r = tid / COLS, col = tid % COLS, row = rowbase + r, k = y * COLS + col;
+    const bool owner_valid = tid < 16 * COLS && row < N;  // (columns beyond K carry zeros)
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
     unsigned int rid = 1;
@@ -419,8 +417,8 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
     const int N = p.N, nt = p.nt, L = p.L;
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
-    const int r = tid >> 4, col = tid & 15, row = rowbase + r, k = y * c.cols + col;
-    const bool owner_valid = tid < KH_COOP_OWNERS && row < N && col < c.cols;
+    const int r = tid / COLS, col = tid % COLS, row = rowbase + r, k = y * COLS + col;
+    const bool owner_valid = tid < 16 * COLS && row < N;
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     const double chi_norm = has_state ? u.chi_norms[k] : 0.0;
@@ -452,7 +450,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
             kh_coop_load_frag<MAXKS>(p.ops[1 + l], N, rowbase, wave, lane, c.ks, a);
             cplx w;
             kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
-            if (tid < KH_COOP_OWNERS) {
+            if (wave < 4) {  // (lanes that own no element contribute zeros: chi_norm, bra, w are 0 there)
                 cplx ov = c_make(0.0, 0.0);
                 c_fma_conj(ov, bra, w);
                 const double piece = sum64(chi_norm * (u.mu_re * ov.y + u.mu_im * ov.x));
