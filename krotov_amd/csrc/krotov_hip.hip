@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -86,7 +87,17 @@ struct kh_engine {
     bool p2p_ready = false;
     size_t slots_bytes = 0;
     double last_intervals = 0, last_wgs = 0;
+    std::set<const void *> lds_raised;  // kernels whose dynamic-LDS limit was raised on this engine's device
 };
+
+// Kernels with more than 64 KiB of dynamic LDS need the limit raised once per device: remembered per
+// engine (an engine is bound to one device), not per process.
+static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
+    if (bytes <= 48 * 1024 || e->lds_raised.count(func)) return KH_OK;
+    KH_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    e->lds_raised.insert(func);
+    return KH_OK;
+}
 
 extern "C" const char *kh_last_error(void) { return g_last_error.c_str(); }
 
@@ -407,28 +418,25 @@ extern "C" int kh_engine_create_csr(const kh_problem_csr *pc, kh_engine **out) {
 // ---------------------------------------------------------------------------
 
 template <int RPT, int LT>
-static void launch_tile_store(const kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in,
-                              cplx *store, cplx *out, int direction, hipStream_t st) {
-    constexpr size_t lds = KhTileLds<RPT, LT>::bytes(KhTileLds<RPT, LT>::STORE);
-    if constexpr (lds != 0) {  // operator tiles parked in LDS: more than the default dynamic limit
-        static const hipError_t attr = hipFuncSetAttribute(
-            (const void *)kh_tile_sweep_store<RPT, LT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)attr;
-    }
+static int launch_tile_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in,
+                             cplx *store, cplx *out, int direction, hipStream_t st) {
+    constexpr size_t lds = KhTileLds<RPT, LT>::bytes(KhTileLds<RPT, LT>::STORE);  // operator tiles parked in LDS
+    const int rc = ensure_dynamic_lds(e, (const void *)kh_tile_sweep_store<RPT, LT>, lds);
+    if (rc != KH_OK) return rc;
     kh_tile_sweep_store<RPT, LT><<<e->K, 512 / RPT, lds, st>>>(p, pulses, in, store, out, direction);
+    return KH_OK;
 }
 
 template <int RPT>
-static int dispatch_tile_store(const kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in,
+static int dispatch_tile_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in,
                                cplx *store, cplx *out, int direction, hipStream_t st) {
     switch (e->L) {
-        case 1: launch_tile_store<RPT, 1>(e, p, pulses, in, store, out, direction, st); break;
-        case 2: launch_tile_store<RPT, 2>(e, p, pulses, in, store, out, direction, st); break;
-        case 3: launch_tile_store<1, 3>(e, p, pulses, in, store, out, direction, st); break;
-        case 4: launch_tile_store<1, 4>(e, p, pulses, in, store, out, direction, st); break;
+        case 1: return launch_tile_store<RPT, 1>(e, p, pulses, in, store, out, direction, st);
+        case 2: return launch_tile_store<RPT, 2>(e, p, pulses, in, store, out, direction, st);
+        case 3: return launch_tile_store<1, 3>(e, p, pulses, in, store, out, direction, st);
+        case 4: return launch_tile_store<1, 4>(e, p, pulses, in, store, out, direction, st);
         default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");
     }
-    return KH_OK;
 }
 
 static KhExchange exchange_args(const kh_engine *e, bool internal_exchange);
@@ -449,10 +457,8 @@ static KhCoopArgs coop_args(const kh_engine *e) {
 template <int MAXKS, int COLS>
 static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
                              cplx *out, int direction, hipStream_t st) {
-    static const hipError_t attr = hipFuncSetAttribute((const void *)kh_coop_sweep_store<MAXKS, COLS>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)kh_coop_lds_bytes(15));
-    (void)attr;
+    const int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS>, kh_coop_lds_bytes(15));
+    if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     kh_coop_sweep_store<MAXKS, COLS><<<dim3(e->coop_G, e->coop_Y), KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(
         p, coop_args(e), exchange_args(e, true), pulses, in, store, out, direction);
@@ -462,14 +468,10 @@ static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *p
 template <int MAXKS, int COLS>
 static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u, const KhExchange &ex,
                               hipStream_t st) {
-    static const hipError_t attr0 = hipFuncSetAttribute((const void *)kh_coop_forward_update<MAXKS, COLS, false>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)kh_coop_lds_bytes(15));
-    static const hipError_t attr1 = hipFuncSetAttribute((const void *)kh_coop_forward_update<MAXKS, COLS, true>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)kh_coop_lds_bytes(15));
-    (void)attr0;
-    (void)attr1;
+    const void *func = u.sigma != nullptr ? (const void *)kh_coop_forward_update<MAXKS, COLS, true>
+                                          : (const void *)kh_coop_forward_update<MAXKS, COLS, false>;
+    const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(15));
+    if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     const dim3 grid(e->coop_G, e->coop_Y);
     if (u.sigma != nullptr)
@@ -501,10 +503,8 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
                                  : launch_coop_store<16, 16>(e, p, pulses, in, store, out, direction, st);
     } else {
         const size_t lds = kh_gen_lds_bytes(e->N);
-        if (lds > 64 * 1024)
-            KH_HIP(hipFuncSetAttribute((const void *)kh_gen_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-        kh_gen_sweep_store<<<e->K, KH_GEN_THREADS, lds, st>>>(p, pulses, in, store, out, direction);
+        rc = ensure_dynamic_lds(e, (const void *)kh_gen_sweep_store, lds);
+        if (rc == KH_OK) kh_gen_sweep_store<<<e->K, KH_GEN_THREADS, lds, st>>>(p, pulses, in, store, out, direction);
     }
     if (rc != KH_OK) return rc;
     KH_HIP(hipGetLastError());
@@ -530,21 +530,18 @@ extern "C" int kh_backward_store(kh_engine *e, const kh_cdouble *chi_T_dev, cons
 }
 
 template <int RPT, int LT>
-static void launch_tile_update(const kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u, const KhExchange &ex,
-                               hipStream_t st) {
+static int launch_tile_update(kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u, const KhExchange &ex,
+                              hipStream_t st) {
     constexpr size_t lds = KhTileLds<RPT, LT>::bytes(KhTileLds<RPT, LT>::UPDATE);
-    if constexpr (lds != 0) {
-        static const hipError_t attr1 = hipFuncSetAttribute(
-            (const void *)kh_tile_forward_update<RPT, LT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        static const hipError_t attr0 = hipFuncSetAttribute(
-            (const void *)kh_tile_forward_update<RPT, LT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)attr1;
-        (void)attr0;
-    }
+    const void *func = u.sigma != nullptr ? (const void *)kh_tile_forward_update<RPT, LT, true>
+                                          : (const void *)kh_tile_forward_update<RPT, LT, false>;
+    const int rc = ensure_dynamic_lds(e, func, lds);
+    if (rc != KH_OK) return rc;
     if (u.sigma != nullptr)
         kh_tile_forward_update<RPT, LT, true><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
     else
         kh_tile_forward_update<RPT, LT, false><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
+    return KH_OK;
 }
 
 static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
@@ -571,34 +568,32 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     // tiles, so the q2 kernels (5 tiles, 320 KiB per objective) lose to the
     // plain tile kernel (2 tiles) there -- measured 39 vs ~20 us per interval.
     const bool stepwise = !u.internal_exchange;
+    int rc = KH_OK;
     if (e->kind == KIND_TILE_Q2 && !stepwise) {
         if (u.sigma != nullptr)
             kh_q2_forward_update<true><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
         else
             kh_q2_forward_update<false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_COOP && !stepwise) {
-        int rc;
         if (e->coop_cols == 4)
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 4>(e, p, u, ex, st) : launch_coop_update<16, 4>(e, p, u, ex, st);
         else
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 16>(e, p, u, ex, st) : launch_coop_update<16, 16>(e, p, u, ex, st);
-        if (rc != KH_OK) return rc;
     } else if (e->kind != KIND_GENERIC && e->kind != KIND_COOP) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
         switch (e->L) {
-            case 1: rpt2 ? launch_tile_update<2, 1>(e, p, u, ex, st) : launch_tile_update<1, 1>(e, p, u, ex, st); break;
-            case 2: rpt2 ? launch_tile_update<2, 2>(e, p, u, ex, st) : launch_tile_update<1, 2>(e, p, u, ex, st); break;
-            case 3: launch_tile_update<1, 3>(e, p, u, ex, st); break;
-            case 4: launch_tile_update<1, 4>(e, p, u, ex, st); break;
+            case 1: rc = rpt2 ? launch_tile_update<2, 1>(e, p, u, ex, st) : launch_tile_update<1, 1>(e, p, u, ex, st); break;
+            case 2: rc = rpt2 ? launch_tile_update<2, 2>(e, p, u, ex, st) : launch_tile_update<1, 2>(e, p, u, ex, st); break;
+            case 3: rc = launch_tile_update<1, 3>(e, p, u, ex, st); break;
+            case 4: rc = launch_tile_update<1, 4>(e, p, u, ex, st); break;
             default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");
         }
     } else {
         const size_t lds = kh_gen_lds_bytes(e->N);
-        if (lds > 64 * 1024)
-            KH_HIP(hipFuncSetAttribute((const void *)kh_gen_forward_update,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kh_gen_forward_update<<<e->grid_update, KH_GEN_THREADS, lds, st>>>(p, u, ex);
+        rc = ensure_dynamic_lds(e, (const void *)kh_gen_forward_update, lds);
+        if (rc == KH_OK) kh_gen_forward_update<<<e->grid_update, KH_GEN_THREADS, lds, st>>>(p, u, ex);
     }
+    if (rc != KH_OK) return rc;
     KH_HIP(hipGetLastError());
     return KH_OK;
 }
