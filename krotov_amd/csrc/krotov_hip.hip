@@ -88,6 +88,9 @@ struct kh_engine {
     size_t slots_bytes = 0;
     double last_intervals = 0, last_wgs = 0;
     std::set<const void *> lds_raised;  // kernels whose dynamic-LDS limit was raised on this engine's device
+    // tuning knobs (s_sleep units of 64 cycles), read from the environment once at creation
+    int poll_delay = 16;       // KH_POLL_DELAY: head start of the update-sum stores, ~0.4 us: measured best
+    int coop_poll_delay = 12;  // KH_COOP_DELAY: the same for the cooperative kernels' block exchange
 };
 
 // Kernels with more than 64 KiB of dynamic LDS need the limit raised once per device: remembered per
@@ -262,7 +265,9 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     e->kind = KIND_GENERIC;
     const int max_wgs = e->num_cus < 64 * KH_GATHER_CHUNKS ? e->num_cus : 64 * KH_GATHER_CHUNKS;
     e->grid_update = e->K < max_wgs ? e->K : max_wgs;
-    const char *force = getenv("KH_KERNEL");  // "generic" | "tile256" | "tile512" (testing)
+    if (const char *d = getenv("KH_POLL_DELAY")) e->poll_delay = atoi(d);
+    if (const char *d = getenv("KH_COOP_DELAY")) e->coop_poll_delay = atoi(d);
+    const char *force = getenv("KH_KERNEL");  // "generic" | "tile256" | "tile512" | "q2" | "coop" (testing)
     const bool tile_ok = csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && e->K <= max_wgs;
     if (tile_ok && !(force && strcmp(force, "generic") == 0)) {
         // two waves per SIMD are needed to keep the fp64 FMA pipe issuing back to back
@@ -449,8 +454,7 @@ static KhCoopArgs coop_args(const kh_engine *e) {
     c.Y = e->coop_Y;
     c.ks = e->coop_ks;
     c.cols = e->coop_cols;
-    const char *d = getenv("KH_COOP_DELAY");  // tuning knob, s_sleep units
-    c.first_poll_delay = d ? atoi(d) : 12;
+    c.first_poll_delay = e->coop_poll_delay;
     return c;
 }
 
@@ -555,8 +559,7 @@ static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
     ex.world = (e->p2p_ready && internal_exchange) ? e->p2p_world : 1;
     ex.rank = e->p2p_rank;
     ex.epoch_base = e->p2p_epoch_base;
-    const char *d = getenv("KH_POLL_DELAY");  // tuning knob, s_sleep units
-    ex.first_poll_delay = d ? atoi(d) : 16;   // ~0.4 us: measured best on MI355X
+    ex.first_poll_delay = e->poll_delay;
     return ex;
 }
 
