@@ -532,7 +532,18 @@ def test_full_size_c5_properties():
     eng.close()
 
 
-def _two_rank_worker(rank, world, port, queue):
+def _two_rank_spec(case):
+    """'c5': per-objective operators, register-tile kernels; 'c4': objectives sharing one
+    operator list with N > 64 (BASELINE config 4's shape, small): cooperative matrix-core
+    kernels, 4 density matrices per rank; 'c4so': the same with the second-order update."""
+    if case == 'c5':
+        spec = configs.config_c5(K=6, N=64, nt=61, L=1)
+        spec.chi = 'sm'
+        return spec
+    return configs.config_c4(d=9, nt=41, n_logical=3)  # N = 81, K = 9 -> 5 + 4 objectives
+
+
+def _two_rank_worker(rank, world, port, queue, case='c5'):
     """One of two ranks sharing the single GPU (gloo moves the CUDA tensors through
     the host): the real multi-rank device path -- kh_update_begin/step/end with an
     all-reduce per interval, tau / state all-gathers -- minus RCCL itself."""
@@ -552,22 +563,31 @@ def _two_rank_worker(rank, world, port, queue):
         import krotov_amd as ka
         from krotov_amd import configs as cfg
 
-        spec = cfg.config_c5(K=6, N=64, nt=61, L=1)
-        spec.chi = 'sm'
+        from test_hip_parity import _two_rank_spec
+
+        spec = _two_rank_spec(case)
         objectives, pulse_options = cfg.spec_to_objectives(spec, ka)
+        prop = ka.propagators.HipExpm(liouville=True) if spec.is_super else ka.propagators.expm
+        extra = {}
+        if case == 'c4so':
+            from helpers import product_sigma
+
+            extra['sigma'] = product_sigma(0.0, 2e-3)  # (||L_1|| ~ 1e2: keeps the pulses O(1))
         res = ka.optimize_pulses(
-            objectives, pulse_options, spec.tlist, propagator=ka.propagators.expm,
-            chi_constructor=ka.functionals.chis_sm, iter_stop=2, store_all_pulses=True,
-            process_group=dist.group.WORLD)
+            objectives, pulse_options, spec.tlist, propagator=prop,
+            chi_constructor=getattr(ka.functionals, 'chis_' + spec.chi), iter_stop=2, store_all_pulses=True,
+            process_group=dist.group.WORLD, **extra)
         import krotov_amd.engine as engine_mod
 
-        used_p2p = bool(getattr(engine_mod.LAST_ENGINE(), '_p2p_used', False))
-        queue.put((rank, np.array(res.all_pulses), np.array(res.tau_vals), used_p2p))
+        eng = engine_mod.LAST_ENGINE()
+        used_p2p = bool(getattr(eng, '_p2p_used', False))
+        queue.put((rank, np.array(res.all_pulses), np.array(res.tau_vals), used_p2p, eng.kernel))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_sharded_on_one_gpu():
+@pytest.mark.parametrize('case', ['c5', 'c4', 'c4so'])
+def test_two_ranks_sharded_on_one_gpu(case):
     import socket
 
     import torch.multiprocessing as mp
@@ -578,19 +598,25 @@ def test_two_ranks_sharded_on_one_gpu():
     s.close()
     ctx = mp.get_context('spawn')
     queue = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, queue)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, queue, case)) for r in range(2)]
     for p in procs:
         p.start()
     out = sorted([queue.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    spec = configs.config_c5(K=6, N=64, nt=61, L=1)
-    spec.chi = 'sm'
-    ref = oracle_optimize(spec, 2)
-    for _, pulses, tau, used_p2p in out:
-        assert np.abs(pulses - ref['all_pulses']).max() < 1e-12
-        assert np.abs(tau - ref['tau_vals']).max() < 1e-12
+    spec = _two_rank_spec(case)
+    if case == 'c4so':
+        from helpers import SigmaA
+
+        ref = oracle_optimize(spec, 2, sigma=SigmaA(0.0, 2e-3))
+    else:
+        ref = oracle_optimize(spec, 2)
+    tol = 1e-12 if case == 'c5' else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
+    for _, pulses, tau, used_p2p, kernel in out:
+        assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
+        assert np.abs(tau - ref['tau_vals']).max() < tol
+        assert kernel == ('tile64q2/512' if case == 'c5' else 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
     print("cross-GPU exchange through peer windows used:", [o[3] for o in out])
 
