@@ -37,3 +37,17 @@ def test_bad_arguments_are_reported_not_crashed():
     rc = lib.kh_engine_create(ctypes.byref(pr), ctypes.byref(out))
     assert rc == -1 and b'bad sizes' in lib.kh_last_error()
     assert lib.kh_check(None) == -1
+    # the other entry points validate before touching the device
+    assert lib.kh_engine_create_csr(None, ctypes.byref(out)) == -1
+    pc = _lib.kh_problem_csr()
+    pc.K, pc.N, pc.L, pc.nt = 1, 2, 0, 3
+    assert lib.kh_engine_create_csr(ctypes.byref(pc), ctypes.byref(out)) == -1
+    assert b'required' in lib.kh_last_error()
+    for call in (lambda: lib.kh_forward_store(None, None, None, None, None, None),
+                 lambda: lib.kh_backward_store(None, None, None, None, None),
+                 lambda: lib.kh_forward_update(None, None, None, None, None, None, None, None, None, None, None),
+                 lambda: lib.kh_set_second_order(None, None, None, None),
+                 lambda: lib.kh_chi_boundary(None, None, None, None, None, None, None, None),
+                 lambda: lib.kh_tau(None, None, None, None, None)):
+        assert call() == -1
+        assert lib.kh_last_error() != b''
