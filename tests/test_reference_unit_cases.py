@@ -1,0 +1,188 @@
+"""The reference's own unit tests of the host logic around the path, restated against
+``krotov_amd`` with NumPy stand-ins for QuTiP objects (same inputs, same expectations):
+tests/test_shapes.py, test_pulse_options.py, test_structural_conversions.py,
+test_overlap.py (file:line given per test)."""
+import logging
+from functools import partial
+
+import numpy as np
+import pytest
+
+import krotov_amd
+from krotov_amd import conversions, shapes
+from krotov_amd.conversions import (
+    discretize, extract_controls, extract_controls_mapping, pulse_options_dict_to_list,
+)
+from krotov_amd.optimize import _initialize_krotov_controls
+from krotov_amd.second_order import _overlap
+from krotov_amd.shapes import flattop, qutip_callback
+
+
+class Op:
+    """An opaque operator stand-in (the structural conversions never look inside)."""
+
+
+@pytest.mark.parametrize('func', ['blackman', 'sinsq'])
+def test_flattop_basic_properties(func):
+    """reference tests/test_shapes.py:8-25"""
+    shape = partial(flattop, t_start=10, t_stop=20, t_rise=2, func=func)
+    assert shape(9.9) == 0
+    assert shape(10) < 1e-14
+    assert shape(20) < 1e-14
+    assert shape(20.1) == 0
+    assert shape(15) == 1
+
+
+def test_invalid_flattop():
+    """reference tests/test_shapes.py:28-31"""
+    with pytest.raises(ValueError):
+        flattop(0, t_start=10, t_stop=20, t_rise=2, func='xxx')
+
+
+def _dummy_objective(control):
+    H = [Op(), [Op(), control]]
+    return [krotov_amd.Objective(initial_state=np.zeros(2, dtype=complex), target=None, H=H)], H[1][1]
+
+
+def test_shape_validation():
+    """reference tests/test_pulse_options.py:9-73"""
+    objectives, u = _dummy_objective(lambda t, args: 0)
+    tlist = np.linspace(0, 10, 100)
+    res = _initialize_krotov_controls(objectives, {u: dict(lambda_a=1, update_shape=1)}, tlist)
+    shape_arrays, lambda_vals = res[4], res[3]
+    assert len(shape_arrays) == 1 and len(shape_arrays[0]) == len(tlist) - 1 and np.all(shape_arrays[0] == 1)
+    assert len(lambda_vals) == 1 and lambda_vals[0] == 1 and isinstance(lambda_vals[0], float)
+    res = _initialize_krotov_controls(objectives, {u: dict(lambda_a=1, update_shape=0)}, tlist)
+    assert np.all(res[4][0] == 0)
+    for options, message in (
+        (dict(lambda_a=1), "key 'update_shape'"),
+        ({'update_shape': 1}, "key 'lambda_a'"),
+        (dict(lambda_a=1, update_shape=2), 'update_shape must be a callable'),
+        (dict(lambda_a=1, update_shape=lambda t: 2.0), 'in the range [0, 1]'),
+        (dict(lambda_a=1, update_shape=lambda t: 0.5j), 'real-valued'),
+    ):
+        with pytest.raises(ValueError) as exc_info:
+            _initialize_krotov_controls(objectives, {u: options}, tlist)
+        assert message in str(exc_info.value)
+
+
+def test_conversion_control_pulse_inverse():
+    """reference tests/test_structural_conversions.py:18-32"""
+    tlist = np.linspace(0, 10, 20)
+    blackman = qutip_callback(shapes.blackman, t_start=0, t_stop=10)
+    pulse_orig = conversions.control_onto_interval(discretize(blackman, tlist))
+    control = conversions.pulse_onto_tlist(pulse_orig)
+    assert np.max(np.abs(conversions.control_onto_interval(control) - pulse_orig)) < 1e-14
+
+
+def test_discretize():
+    """reference tests/test_structural_conversions.py:35-60"""
+    tlist = np.linspace(0, 10, 20)
+    with pytest.raises(TypeError):
+        discretize(partial(shapes.blackman, t_start=0, t_stop=10), tlist)  # not a (t, args) callback
+    with pytest.raises(TypeError):
+        discretize('sin(t)', tlist)
+    control = qutip_callback(shapes.blackman, t_start=0, t_stop=10)
+    with pytest.raises(ValueError):
+        discretize(np.array([control(t, None) for t in tlist[:-1]]), tlist)
+    control_array = discretize(control, tlist)
+    assert len(control_array) == len(tlist)
+    assert abs(control_array[0]) < 1e-15 and abs(control_array[-1]) < 1e-15
+    sampled = np.array([control(t, None) for t in tlist])
+    assert np.max(np.abs(sampled - control_array)) < 1e-15
+    assert np.max(np.abs(discretize(sampled, tlist) - control_array)) < 1e-15
+
+
+def test_discretization_as_float():
+    """reference tests/test_structural_conversions.py:63-82 (an int-valued control is discretised as float)"""
+    objectives, u = _dummy_objective(lambda t, args: 0)
+    tlist = np.linspace(0, 10, 100)
+    res = _initialize_krotov_controls(objectives, {u: dict(lambda_a=1, update_shape=lambda t: 0)}, tlist)
+    assert res[0][0].dtype == np.float64 and res[1][0].dtype == np.float64 and res[4][0].dtype == np.float64
+
+
+def test_initialize_krotov_controls_boundary_conditions():
+    """reference tests/test_structural_conversions.py:85-141"""
+    T = 10
+    blackman = qutip_callback(shapes.blackman, t_start=0, t_stop=T)
+    objectives = [krotov_amd.Objective(initial_state=np.zeros(2, dtype=complex), target=None,
+                                       H=['H0', ['H1', blackman]])]
+    tlist = np.linspace(0, T, 10)
+    assert abs(blackman(0, None)) < 1e-15 and abs(blackman(T, None)) < 1e-15
+    guess_controls, guess_pulses, pulses_mapping, lambda_vals, shape_arrays = _initialize_krotov_controls(
+        objectives, {blackman: dict(lambda_a=1.0, update_shape=1)}, tlist)
+    assert isinstance(guess_controls[0], np.ndarray) and len(guess_controls[0]) == len(tlist)
+    assert abs(guess_controls[0][0]) < 1e-15 and abs(guess_controls[0][-1]) < 1e-15
+    assert isinstance(guess_pulses[0], np.ndarray) and len(guess_pulses[0]) == len(tlist) - 1
+    assert abs(guess_pulses[0][0]) < 1e-15 and abs(guess_pulses[0][-1]) < 1e-15
+    assert pulses_mapping == [[[[1]]]]
+    assert lambda_vals == [1.0]
+    assert len(shape_arrays) == 1 and isinstance(shape_arrays[0], np.ndarray) and len(shape_arrays[0]) == len(tlist) - 1
+
+
+def test_extract_controls_with_arrays():
+    """reference tests/test_structural_conversions.py:144-167"""
+    X, Y, Z = Op(), Op(), Op()
+    u1, u2 = np.array([]), np.array([])
+    psi0, psi_tgt = np.zeros(2), np.ones(2)
+    objectives = [
+        krotov_amd.Objective(initial_state=psi0, target=psi_tgt, H=[X, [Y, u1], [Z, u2]]),
+        krotov_amd.Objective(initial_state=psi0, target=psi_tgt, H=[X, [Y, u2]]),
+    ]
+    controls = extract_controls(objectives)
+    control_map = extract_controls_mapping(objectives, controls)
+    assert len(controls) == 2 and controls[0] is u1 and controls[1] is u2
+    assert control_map[0] == [[[1], [2]]]
+    assert control_map[1] == [[[], [1]]]
+
+
+def test_extract_controls():
+    """reference tests/test_structural_conversions.py:170-218"""
+    X, Y = Op(), Op()
+    f, g, h, d = (lambda t: 0), (lambda t: 0), (lambda t: 0), (lambda t: 0)
+    H1, H2, H3 = [X, [X, f], [X, g]], [X, [X, f], [X, h]], [X, [X, d], X]
+    objectives = [
+        krotov_amd.Objective(initial_state=np.zeros(1), target=Y, H=H1),
+        krotov_amd.Objective(initial_state=np.ones(1), target=X, H=H1),
+    ]
+    controls = extract_controls(objectives)
+    assert len(controls) == 2 and f in controls and g in controls
+    assert extract_controls_mapping(objectives, controls) == [[[[1], [2]]], [[[1], [2]]]]
+    objectives = [
+        krotov_amd.Objective(initial_state=np.zeros(1), target=Y, H=H1),
+        krotov_amd.Objective(initial_state=np.ones(1), target=X, H=H2),
+        krotov_amd.Objective(initial_state=np.ones(1), target=X, H=H3),
+    ]
+    controls = extract_controls(objectives)
+    assert len(controls) == 4 and all(c in controls for c in (f, g, h, d))
+    maps = extract_controls_mapping(objectives, controls)
+    assert maps[0] == [[[1], [2], [], []]]
+    assert maps[1] == [[[1], [], [2], []]]
+    assert maps[2] == [[[], [], [], [1]]]
+
+
+def test_pulse_options_dict_to_list(caplog):
+    """reference tests/test_structural_conversions.py:221-254"""
+    u1, u2, u3 = np.array([]), np.array([]), np.array([])
+    controls = [u1, u2]
+    pulse_options = {id(u1): dict(lambda_a=1.0, update_shape=1), id(u2): dict(lambda_a=2.0, update_shape=1)}
+    as_list = pulse_options_dict_to_list(pulse_options, controls)
+    assert as_list == [pulse_options[id(u1)], pulse_options[id(u2)]]
+    with pytest.raises(ValueError) as exc_info:
+        pulse_options_dict_to_list({id(u1): dict(lambda_a=1.0, update_shape=1)}, controls)
+    assert 'does not have any associated pulse options' in str(exc_info.value)
+    pulse_options[id(u3)] = dict(lambda_a=1.0, update_shape=1)
+    with caplog.at_level(logging.WARNING):
+        pulse_options_dict_to_list(pulse_options, controls)
+    assert 'extra elements' in caplog.text
+
+
+def test_overlap_of_operators():
+    """reference tests/test_overlap.py:7-25: tr(Q^dagger rho) for a non-Hermitian Q (the magic basis)."""
+    Q = (1.0 / np.sqrt(2.0)) * np.array(
+        [[1, 0, 0, 1j], [0, 1j, 1, 0], [0, 1j, -1, 0], [1, 0, 0, -1j]], dtype=np.complex128)
+    ket01, ket10 = np.zeros(4, dtype=complex), np.zeros(4, dtype=complex)
+    ket01[1], ket10[2] = 1, 1
+    rho_2 = np.outer(ket01, ket10.conj())
+    expected = complex(np.trace(Q.conj().T @ rho_2))
+    assert abs(_overlap(Q, rho_2) - expected) < 1e-14
