@@ -186,3 +186,79 @@ def test_overlap_of_operators():
     rho_2 = np.outer(ket01, ket10.conj())
     expected = complex(np.trace(Q.conj().T @ rho_2))
     assert abs(_overlap(Q, rho_2) - expected) < 1e-14
+
+
+# ---- tests/test_functionals.py: known answers on two-qubit gates (NumPy kets) -------------------
+
+SQRT_SWAP = np.array([[1, 0, 0, 0], [0, 0.5 + 0.5j, 0.5 - 0.5j, 0], [0, 0.5 - 0.5j, 0.5 + 0.5j, 0], [0, 0, 0, 1]])
+CPHASE_PI = np.diag([1, 1, 1, -1]).astype(complex)
+SQRT_ISWAP = np.array([[1, 0, 0, 0], [0, 1 / np.sqrt(2), 1j / np.sqrt(2), 0], [0, 1j / np.sqrt(2), 1 / np.sqrt(2), 0],
+                       [0, 0, 0, 1]])
+
+
+def _canonical_basis():
+    return [np.eye(4, dtype=complex)[i] for i in range(4)]
+
+
+def _mapped(gate, basis):
+    """|phi_i> = sum_j O_ji |basis_j> (reference functionals.py `mapped_basis`)."""
+    return [sum(gate[j, i] * basis[j] for j in range(len(basis))) for i in range(len(basis))]
+
+
+def _with_weights(objectives):
+    import copy
+
+    out = copy.deepcopy(objectives)
+    out[1].weight, out[2].weight, out[3].weight = 2.0, 0.5, 0
+    return out
+
+
+def test_f_tau_and_functionals_known_answers():
+    """reference tests/test_functionals.py:91-145"""
+    from krotov_amd import functionals
+
+    basis = _canonical_basis()
+    states = _mapped(SQRT_SWAP, basis)
+    objectives = krotov_amd.gate_objectives(basis, CPHASE_PI, [np.zeros((4, 4), dtype=complex)])
+    tau = [np.vdot(obj.target, psi) for psi, obj in zip(states, objectives)]
+    for got, want in zip(tau, (1 + 0j, 0.5 + 0.5j, 0.5 + 0.5j, -1 + 0j)):
+        assert abs(got - want) < 1e-14
+    assert abs(functionals.f_tau(states, objectives) - (1 + 1j) / 4) < 1e-14
+    weighted = _with_weights(objectives)
+    assert abs(functionals.f_tau(states, weighted) - (2.25 + 1.25j) / 4) < 1e-14
+    assert all(not hasattr(obj, 'weight') for obj in objectives)  # the originals are untouched
+    assert abs(functionals.J_T_ss(states, objectives) - 0.25) < 1e-14
+    assert abs(functionals.J_T_sm(states, objectives) - 0.875) < 1e-14
+    assert abs(functionals.J_T_re(states, objectives) - 0.75) < 1e-14
+    assert abs(functionals.J_T_ss(states, weighted) - 1.75 / 4) < 1e-14
+
+
+def test_chi_constructors_known_answers():
+    """reference tests/test_functionals.py:206-302 (chis_ss, chis_sm, chis_re with and without weights)"""
+    from krotov_amd import functionals
+
+    basis = _canonical_basis()
+    objectives = krotov_amd.gate_objectives(basis, SQRT_ISWAP, [np.zeros((4, 4), dtype=complex)])
+    tau = [1, 0.5 * (1 + 1j), 0.5 * (1 + 1j), 1]
+
+    def check(chis, factors, objs):
+        for chi, fac, obj in zip(chis, factors, objs):
+            assert np.abs(chi - fac * obj.target).max() < 1e-14
+
+    check(functionals.chis_ss(fw_states_T=basis, objectives=objectives, tau_vals=tau),
+          [t / 4 for t in tau], objectives)
+    check(functionals.chis_sm(fw_states_T=basis, objectives=objectives, tau_vals=tau), [(3 + 1j) / 16] * 4, objectives)
+    check(functionals.chis_re(basis, objectives, None), [1 / 8] * 4, objectives)
+    weighted = _with_weights(objectives)
+    w = [1.0, 2.0, 0.5, 0.0]
+    check(functionals.chis_ss(fw_states_T=basis, objectives=weighted, tau_vals=tau),
+          [wk * t / 4 for wk, t in zip(w, tau)], weighted)
+    check(functionals.chis_sm(fw_states_T=basis, objectives=weighted, tau_vals=tau),
+          [(2.25 + 1.25j) / 16 * wk for wk in w], weighted)
+    check(functionals.chis_re(basis, weighted, None), [wk / 8 for wk in w], weighted)
+    # the scalars handed to the device-side construction (kh_chi_boundary) give the same co-states
+    for fn in (functionals.chis_ss, functionals.chis_sm, functionals.chis_re):
+        c, d = functionals.chi_coefficients(fn, np.array(w), tau, 4)
+        want = fn(basis, weighted, tau)
+        for k in range(4):
+            assert np.abs(c[k] * weighted[k].target + d[k] * basis[k] - want[k]).max() < 1e-14
