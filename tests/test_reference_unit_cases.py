@@ -262,3 +262,119 @@ def test_chi_constructors_known_answers():
         want = fn(basis, weighted, tau)
         for k in range(4):
             assert np.abs(c[k] * weighted[k].target + d[k] * basis[k] - want[k]).max() < 1e-14
+
+
+# ---- tests/test_objectives.py: gate_objectives, ensemble_objectives, liouvillian -----------------
+
+SX = np.array([[0, 1], [1, 0]], dtype=complex)
+SY = np.array([[0, -1j], [1j, 0]], dtype=complex)
+SZ = np.array([[1, 0], [0, -1]], dtype=complex)
+SM = np.array([[0, 0], [1, 0]], dtype=complex)  # qutip.sigmam(): |1><0| in QuTiP's basis order
+ID2 = np.eye(2, dtype=complex)
+CNOT = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=complex)
+
+
+def test_gate_objectives_single_qubit_gate():
+    """reference tests/test_objectives.py:307-316"""
+    basis = [np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)]
+    H = [SZ, [SX, lambda t, args: 1.0]]
+    objectives = krotov_amd.gate_objectives(basis, SY, H)  # sigma_y = -i|0><1| + i|1><0|
+    assert len(objectives) == 2
+    assert objectives[0].initial_state is basis[0] and np.array_equal(objectives[0].target, 1j * basis[1])
+    assert objectives[1].initial_state is basis[1] and np.array_equal(objectives[1].target, -1j * basis[0])
+    assert objectives[0].H[1][1] is H[1][1]  # the control object is shared
+
+
+def test_gate_objectives_shape_error():
+    """reference tests/test_objectives.py:319-330"""
+    basis = [np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)]
+    with pytest.raises(ValueError) as exc_info:
+        krotov_amd.gate_objectives(basis, np.kron(SY, ID2), [SZ, [SX, lambda t, args: 1.0]])
+    assert "same dimension as the number of basis" in str(exc_info.value)
+
+
+def test_ensemble_objectives():
+    """reference tests/test_objectives.py:333-347"""
+    rng = np.random.default_rng(1)
+    H0, H1 = rng.standard_normal((3, 3)) + 0j, rng.standard_normal((3, 3)) + 0j
+    eps = lambda t, args: 1.0  # noqa: E731
+    psi0, psi1 = np.array([1, 0, 0], dtype=complex), np.array([0, 1, 0], dtype=complex)
+    H = [H0, [H1, eps]]
+    objectives = [krotov_amd.Objective(initial_state=psi0, target=psi1, H=H),
+                  krotov_amd.Objective(initial_state=psi1, target=psi0, H=H)]
+    Hs = [[H0, [mu * H1, eps]] for mu in [0.95, 0.99, 1.01, 1.05]]
+    ens = krotov_amd.ensemble_objectives(objectives, Hs)
+    assert len(ens) == 10
+    assert ens[0] == objectives[0] and ens[1] == objectives[1]
+    assert np.abs(ens[2].H[1][0] - 0.95 * H1).max() < 1e-15
+    assert np.abs(ens[9].H[1][0] - 1.05 * H1).max() < 1e-15
+
+
+def _two_qubit_liouvillian():
+    H = [np.kron(SZ, ID2) + np.kron(ID2, SZ), [np.kron(SX, ID2), lambda t, args: 1.0],
+         [np.kron(ID2, SX), lambda t, args: 1.0]]
+    c_ops = [np.kron(SM, ID2), np.kron(ID2, SM)]
+    return H, c_ops, krotov_amd.objectives.liouvillian(H, c_ops)
+
+
+def test_liouvillian():
+    """reference tests/test_objectives.py:378-402: d/dt vec(rho) = L vec(rho), column-stacked vec."""
+    H, c_ops, L = _two_qubit_liouvillian()
+    assert isinstance(L, list) and len(L) == 3
+    assert L[1][1] is H[1][1] and L[2][1] is H[2][1]
+    rng = np.random.default_rng(2)
+    rho = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
+
+    def lindblad(Hm, cs):
+        out = -1j * (Hm @ rho - rho @ Hm)
+        for c in cs:
+            cd = c.conj().T
+            out = out + c @ rho @ cd - 0.5 * (cd @ c @ rho + rho @ cd @ c)
+        return out
+
+    vec = rho.ravel(order='F')
+    assert np.abs((L[0] @ vec).reshape(4, 4, order='F') - lindblad(H[0], c_ops)).max() < 1e-14
+    assert np.abs((L[1][0] @ vec).reshape(4, 4, order='F') - lindblad(H[1][0], [])).max() < 1e-14
+    assert np.abs(krotov_amd.objectives.liouvillian(H[0], c_ops) - L[0]).max() < 1e-15
+    with pytest.raises(ValueError):
+        krotov_amd.objectives.liouvillian(tuple(H), c_ops)
+
+
+def test_gate_objectives_liouville_state_sets():
+    """reference tests/test_objectives.py:416-540 ('3states', 'd+1', 'full' with a CNOT)"""
+    _, _, L = _two_qubit_liouvillian()
+    basis = [np.eye(4, dtype=complex)[i] for i in range(4)]
+
+    def conj_by_gate(rho):
+        return CNOT @ rho @ CNOT.conj().T
+
+    objs = krotov_amd.gate_objectives(basis, CNOT, L, liouville_states_set='3states')
+    rho_1 = np.diag([0.1 * (4 - i) for i in range(4)]).astype(complex)
+    rho_2 = np.full((4, 4), 1 / 4, dtype=complex)
+    rho_3 = np.diag([1 / 4] * 4).astype(complex)
+    assert len(objs) == 3
+    for obj, rho in zip(objs, (rho_1, rho_2, rho_3)):
+        assert np.abs(obj.initial_state - rho).max() < 1e-14
+        assert np.abs(obj.target - conj_by_gate(rho)).max() < 1e-14
+        assert not hasattr(obj, 'weight')
+    objs = krotov_amd.gate_objectives(basis, CNOT, L, liouville_states_set='3states', weights=[1, 0, 2])
+    assert len(objs) == 2
+    assert np.abs(objs[0].initial_state - rho_1).max() < 1e-14 and np.abs(objs[1].initial_state - rho_3).max() < 1e-14
+    assert all(isinstance(o.weight, float) for o in objs) and objs[0].weight == 1 and objs[1].weight == 2
+    for bad in ([1, 2], [1, 1, -1]):
+        with pytest.raises(ValueError):
+            krotov_amd.gate_objectives(basis, CNOT, L, liouville_states_set='3states', weights=bad)
+
+    objs = krotov_amd.gate_objectives(basis, CNOT, L, liouville_states_set='d+1')
+    assert len(objs) == 5
+    rhos = [np.outer(b, b.conj()) for b in basis] + [rho_2]
+    for obj, rho in zip(objs, rhos):
+        assert np.abs(obj.initial_state - rho).max() < 1e-14
+        assert np.abs(obj.target - conj_by_gate(rho)).max() < 1e-14
+
+    objs = krotov_amd.gate_objectives(basis, CNOT, L, liouville_states_set='full')
+    assert len(objs) == 16
+    rhos = [np.outer(basis[i], basis[j].conj()) for i in range(4) for j in range(4)]
+    for obj, rho in zip(objs, rhos):
+        assert np.abs(obj.initial_state - rho).max() < 1e-14
+        assert np.abs(obj.target - conj_by_gate(rho)).max() < 1e-14
