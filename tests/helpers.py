@@ -95,3 +95,61 @@ def numpy_plugins(is_super=False):
         return complex(np.vdot(a, b))
 
     return propagator, mu, overlap
+
+
+def check_infohook_chaining(**optimize_kwargs):
+    """The scenario of reference tests/test_infohooks.py:15-72 (5-level transmon, two
+    intervals, lambda_a halved after every iteration by modify_params_after_iter, two
+    chained info_hooks) through ``krotov_amd.optimize_pulses(**optimize_kwargs)``."""
+    import scipy.linalg
+
+    import krotov_amd
+
+    Ec, EjEc, nstates, T = 0.386, 45, 2, 10.0
+    Ej = EjEc * Ec
+    n = np.arange(-nstates, nstates + 1)
+    up = np.diag(np.ones(2 * nstates), k=-1)
+    H0 = (np.diag(4 * Ec * n**2) - Ej * (up + up.T) / 2.0).astype(complex)
+    H1 = (-2 * np.diag(n)).astype(complex)
+    eigenvals, eigenvecs = scipy.linalg.eig(H0)
+    ndx = np.argsort(eigenvals.real)
+    E, V = eigenvals[ndx].real, eigenvecs[:, ndx]
+    w01 = E[1] - E[0]
+    psi0, psi1 = V[:, 0].astype(complex), V[:, 1].astype(complex)
+    eps0 = lambda t, args: 0.5 * np.exp(-40.0 * (t / T - 0.5) ** 2) * np.cos(8 * np.pi * w01 * t)  # noqa: E731
+    H = [H0, [H1, eps0]]
+    obj = krotov_amd.Objective(initial_state=psi0, target=psi1, H=H)
+    tlist = np.array([0, 0.01, 0.02])
+    printed = []
+
+    def adjust_lambda_a(**args):
+        before = args['lambda_vals'][0]
+        args['lambda_vals'][0] *= 0.5
+        args['shared_data'].setdefault('messages', []).append('λₐ: %s → %s' % (before, args['lambda_vals'][0]))
+
+    def print_fidelity(**args):
+        F_re = np.average(np.array(args['tau_vals']).real)
+        printed.append("Iteration %d: \tF = %f" % (args['iteration'], F_re))
+        return F_re
+
+    def print_messages(**args):
+        if 'messages' in args['shared_data']:
+            message = "; ".join(args['shared_data']['messages'])
+            printed.append("\tmsg: " + message)
+            return message
+
+    res = krotov_amd.optimize_pulses(
+        [obj], pulse_options={H[1][1]: dict(lambda_a=1, update_shape=1)}, tlist=tlist,
+        chi_constructor=krotov_amd.functionals.chis_re,
+        info_hook=krotov_amd.info_hooks.chain(print_fidelity, print_messages),
+        modify_params_after_iter=adjust_lambda_a, iter_stop=2, **optimize_kwargs)
+    out = "\n".join(printed)
+    assert len(res.info_vals) == 3
+    assert isinstance(res.info_vals[1], tuple) and len(res.info_vals[1]) == 2
+    assert abs(res.info_vals[1][0] - 0.001978333994757067) < 1e-8
+    assert res.info_vals[1][1] == 'λₐ: 0.5 → 0.25'
+    assert 'Iteration 0: \tF = 0.000000' in out
+    assert 'msg: λₐ: 1.0 → 0.5' in out
+    assert 'Iteration 1: \tF = 0.001978' in out
+    assert 'msg: λₐ: 0.5 → 0.25' in out
+    return res

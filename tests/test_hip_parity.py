@@ -285,6 +285,14 @@ def test_density_matrix_ode_propagator_drop_in():
     assert np.asarray(res.states[0]).shape == np.asarray(objectives[0].initial_state).shape
 
 
+def test_infohook_chaining_on_device():
+    """reference tests/test_infohooks.py:15-72 with propagator=expm on the GPU: hooks that change
+    lambda_a between iterations, chained return values, known answer 0.001978333994757067."""
+    from helpers import check_infohook_chaining
+
+    check_infohook_chaining(propagator=krotov_amd.propagators.expm)
+
+
 @pytest.mark.parametrize('name', ['re', 'ss', 'sm', 'hs'])
 def test_boundary_costates_on_device(name):
     """kh_chi_boundary vs the host form of krotov.functionals.chis_* (reference

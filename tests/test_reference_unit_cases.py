@@ -378,3 +378,15 @@ def test_gate_objectives_liouville_state_sets():
     for obj, rho in zip(objs, rhos):
         assert np.abs(obj.initial_state - rho).max() < 1e-14
         assert np.abs(obj.target - conj_by_gate(rho)).max() < 1e-14
+
+
+# ---- tests/test_infohooks.py:15-72: chained hooks, modify_params_after_iter, shared_data ----------
+
+def test_infohook_chaining():
+    """Return values of several info_hooks combine into a tuple, None (from
+    modify_params_after_iter) is ignored, shared_data is passed along the chain and cleared
+    every iteration; known answer F_re = 0.001978333994757067 after one iteration."""
+    from helpers import check_infohook_chaining, numpy_plugins
+
+    prop, mu, overlap = numpy_plugins()
+    check_infohook_chaining(propagator=prop, mu=mu, overlap=overlap, norm=np.linalg.norm)
