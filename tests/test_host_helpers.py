@@ -181,3 +181,57 @@ def test_print_table_layout():
     with pytest.raises(ValueError, match="Invalid col_formats"):
         krotov_amd.info_hooks.print_table(J_T=None, col_formats=('%d', '%.2e', '%.2e', '%.2e %d', '%.2e', '%.2e',
                                                                  '%.2e', '%d'))
+
+
+@pytest.mark.parametrize('iter_stop', [0, -1])
+def test_zero_iterations(iter_stop):
+    """reference tests/test_krotov.py:166-199"""
+    objectives, pulse_options, tlist = _system()
+    prop, mu, vdot = numpy_plugins()
+    log = io.StringIO()
+    result = krotov_amd.optimize_pulses(
+        objectives, pulse_options=pulse_options, tlist=tlist, propagator=prop, mu=mu,
+        overlap=lambda a, b: None if a is None or b is None else vdot(a, b), norm=np.linalg.norm,
+        chi_constructor=krotov_amd.functionals.chis_re, store_all_pulses=True,
+        info_hook=krotov_amd.info_hooks.print_table(J_T=krotov_amd.functionals.J_T_re, out=log),
+        iter_stop=iter_stop, skip_initial_forward_propagation=True)
+    assert len(log.getvalue().splitlines()) == 2
+    assert result.message == 'Reached 0 iterations'
+    assert len(result.guess_controls) == len(result.optimized_controls) == 1
+    assert len(result.guess_controls[0]) == len(result.optimized_controls[0]) == len(result.tlist)
+    assert all(np.all(c1 == c2) for c1, c2 in zip(result.guess_controls, result.optimized_controls))
+    assert all(len(p) == len(result.tlist) - 1 for pulses in result.all_pulses for p in pulses)
+
+
+def test_broken_continuations():
+    """reference tests/test_krotov.py:433-540: every way `continue_from` can be inconsistent."""
+    from copy import deepcopy
+
+    objectives, pulse_options, tlist = _system()
+    prop, mu, overlap = numpy_plugins()
+    kw = dict(pulse_options=pulse_options, tlist=tlist, propagator=prop, mu=mu, overlap=overlap, norm=np.linalg.norm,
+              chi_constructor=krotov_amd.functionals.chis_re)
+    result = krotov_amd.optimize_pulses(objectives, iter_stop=1, store_all_pulses=True, **kw)
+
+    def broken(res, message, **extra):
+        with pytest.raises(ValueError) as exc_info:
+            krotov_amd.optimize_pulses(objectives, continue_from=res, **{**kw, **extra})
+        assert message in str(exc_info.value)
+
+    extra_obj = deepcopy(result)
+    extra_obj.objectives.append(deepcopy(result.objectives[0]))
+    broken(extra_obj, "number of objectives must be the same", store_all_pulses=True)
+    broken(result, "store_all_pulses parameter cannot be changed", store_all_pulses=False)
+    scaled = deepcopy(result)
+    scaled.objectives = result.objectives
+    scaled.tlist = scaled.tlist * 2
+    broken(scaled, "same time grid", store_all_pulses=True)
+    changed_nt = deepcopy(result)
+    changed_nt.objectives = result.objectives
+    changed_nt.tlist = np.linspace(0, 5, 1000)
+    broken(changed_nt, "same time grid", store_all_pulses=True)
+    incongruent = deepcopy(result)
+    incongruent.objectives = result.objectives
+    incongruent.optimized_controls[0] = np.stack([result.optimized_controls[0]] * 2).flatten()
+    broken(incongruent, "optimized_controls and tlist are incongruent", store_all_pulses=True)
+    broken(result.tlist, "only possible from a Result object", store_all_pulses=True)
