@@ -235,3 +235,42 @@ def test_broken_continuations():
     incongruent.optimized_controls[0] = np.stack([result.optimized_controls[0]] * 2).flatten()
     broken(incongruent, "optimized_controls and tlist are incongruent", store_all_pulses=True)
     broken(result.tlist, "only possible from a Result object", store_all_pulses=True)
+
+
+def test_numpy_array_controls_and_id_keyed_pulse_options():
+    """reference tests/test_numpy_controls.py (issue #79): the guess control given as a NumPy array,
+    pulse_options keyed by id(control); a few iterations reproduce the run with the callable control."""
+    tlist = np.linspace(0, 5, 500)
+    H0 = -0.5 * np.array([[1, 0], [0, -1]], dtype=complex)
+    H1 = np.array([[0, 1], [1, 0]], dtype=complex)
+
+    def guess_control(t, args):
+        return 0.2 * shapes.flattop(t, t_start=0, t_stop=5, t_rise=0.3, func="blackman")
+
+    def S(t):
+        return shapes.flattop(t, t_start=0, t_stop=5, t_rise=0.3, t_fall=0.3, func='blackman')
+
+    psi0, psi1 = np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)
+    guess_array = np.array([guess_control(t, []) for t in tlist])
+    H = [H0, [H1, guess_array]]
+    objectives = [krotov_amd.Objective(initial_state=psi0, target=psi1, H=H)]
+    prop, mu, vdot = numpy_plugins()
+    kw = dict(tlist=tlist, propagator=prop, mu=mu, norm=np.linalg.norm,
+              overlap=lambda a, b: None if a is None or b is None else vdot(a, b),
+              chi_constructor=krotov_amd.functionals.chis_ss)
+    res = krotov_amd.optimize_pulses(
+        objectives, pulse_options={id(H[1][1]): dict(lambda_a=5, update_shape=S)},
+        check_convergence=convergence.Or(convergence.value_below('1e-3', name='J_T'),
+                                         convergence.check_monotonic_error),
+        iter_stop=0, skip_initial_forward_propagation=True, **kw)
+    assert res.message == 'Reached 0 iterations'
+    # (beyond the reference's test) the array control optimises like the function it was sampled from:
+    # arrays skip the mid-point sampling (conversions.py:126-133), so compare with that array's own run
+    res_arr = krotov_amd.optimize_pulses(
+        objectives, pulse_options={id(H[1][1]): dict(lambda_a=5, update_shape=S)}, iter_stop=2, **kw)
+    g = np.load(os.path.join(GOLDEN, 'dump_tls_ss.npz'))
+    # the dump's run used the callable: same system, so J_T_ss decreases alike (3 s.f. of the first iteration)
+    J1 = 1 - abs(res_arr.tau_vals[1][0]) ** 2
+    J1_ref = 1 - abs(g['tau_vals'][1][0]) ** 2
+    assert abs(J1 - J1_ref) < 5e-3
+    assert res_arr.optimized_controls[0].shape == tlist.shape and res_arr.guess_controls[0] is not guess_array
