@@ -346,6 +346,11 @@ __device__ __forceinline__ bool kh_p2p_gather(const KhExchange &ex, int parity, 
 template <int MAXL>
 __device__ __forceinline__ bool kh_exchange(const KhExchange &ex, int n, int wg, int L, int lane,
                                             const double *part, double (&out)[MAXL]) {
+    if (ex.G == 1 && ex.world == 1) {  // a single workgroup on a single GPU: nothing to exchange
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) out[l] = l < L ? part[l] : 0.0;
+        return true;
+    }
     const int parity = n & 1;
     kh_publish(ex, parity, wg, L, lane, part, (unsigned)(n + 1));
     if (!kh_gather<MAXL>(ex, parity, L, (unsigned)(n + 1), lane, out)) return false;
