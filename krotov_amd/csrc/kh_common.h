@@ -222,7 +222,8 @@ __device__ __forceinline__ void kh_publish(const KhExchange &ex, int parity, int
     }
 }
 
-#define KH_GATHER_CHUNKS 4  // workgroups per lane: the exchange handles up to 256 workgroups
+#define KH_GATHER_CHUNKS 4  // workgroups per lane (default): the exchange handles up to 256 workgroups
+#define KH_GATHER_CHUNKS_WIDE 8  // two 256-thread workgroups per CU: up to 512
 
 // Called by ONE full wave.  Returns false on timeout/abort.  All granule loads
 // of a polling round are issued back to back (one memory round trip per round,
@@ -230,11 +231,11 @@ __device__ __forceinline__ void kh_publish(const KhExchange &ex, int parity, int
 // all workgroups, accumulated in a fixed order (per lane: workgroups lane,
 // lane+64, ...; then the sum64 tree) that is identical in every workgroup, so
 // every workgroup derives bit-identical pulse values.
-template <int MAXL>
+template <int MAXL, int CH = KH_GATHER_CHUNKS>
 __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int L, unsigned int epoch, int lane,
                                           double (&out)[MAXL]) {
     const kh_u64 *base = ex.slots + (size_t)parity * ex.G * L * 2;
-    kh_u64 a[MAXL][KH_GATHER_CHUNKS], b[MAXL][KH_GATHER_CHUNKS];
+    kh_u64 a[MAXL][CH], b[MAXL][CH];
     const long long t0 = wall_clock64();
     unsigned int spins = 0;
     // a poll issued before the slowest producer's store has reached the memory
@@ -245,7 +246,7 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
 #pragma unroll
         for (int l = 0; l < MAXL; ++l) {
 #pragma unroll
-            for (int c = 0; c < KH_GATHER_CHUNKS; ++c) {
+            for (int c = 0; c < CH; ++c) {
                 const int wg = lane + 64 * c;
                 if (l < L && wg < ex.G) {
                     const kh_u64 *g = base + ((size_t)wg * L + l) * 2;
@@ -259,7 +260,7 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
 #pragma unroll
         for (int l = 0; l < MAXL; ++l)
 #pragma unroll
-            for (int c = 0; c < KH_GATHER_CHUNKS; ++c)
+            for (int c = 0; c < CH; ++c)
                 ok = ok && ((unsigned int)(a[l][c] >> 32) == epoch) && ((unsigned int)(b[l][c] >> 32) == epoch);
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
@@ -277,7 +278,7 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
     for (int l = 0; l < MAXL; ++l) {
         double acc = 0.0;
 #pragma unroll
-        for (int c = 0; c < KH_GATHER_CHUNKS; ++c) {
+        for (int c = 0; c < CH; ++c) {
             const kh_u64 bits = ((a[l][c] & 0xffffffffull) << 32) | (b[l][c] & 0xffffffffull);
             acc += __longlong_as_double((long long)bits);
         }
@@ -343,7 +344,7 @@ __device__ __forceinline__ bool kh_p2p_gather(const KhExchange &ex, int parity, 
 // The whole per-interval exchange, called by ONE full wave of every workgroup:
 // publish this workgroup's partial sums, gather the GPU's total, and (sharded
 // runs) exchange the GPU totals across ranks.  `n` = interval index.
-template <int MAXL>
+template <int MAXL, int CH = KH_GATHER_CHUNKS>
 __device__ __forceinline__ bool kh_exchange(const KhExchange &ex, int n, int wg, int L, int lane,
                                             const double *part, double (&out)[MAXL]) {
     if (ex.G == 1 && ex.world == 1) {  // a single workgroup on a single GPU: nothing to exchange
@@ -353,7 +354,7 @@ __device__ __forceinline__ bool kh_exchange(const KhExchange &ex, int n, int wg,
     }
     const int parity = n & 1;
     kh_publish(ex, parity, wg, L, lane, part, (unsigned)(n + 1));
-    if (!kh_gather<MAXL>(ex, parity, L, (unsigned)(n + 1), lane, out)) return false;
+    if (!kh_gather<MAXL, CH>(ex, parity, L, (unsigned)(n + 1), lane, out)) return false;
     if (ex.world > 1) {
         const unsigned int epoch = ex.epoch_base + (unsigned)(n + 1);
         if (wg == 0) kh_p2p_publish(ex, parity, L, lane, out, epoch);

@@ -174,7 +174,7 @@ extern __shared__ __attribute__((aligned(16))) cplx kh_tile_dyn_lds[];
 // plain propagation with storage (backward sweep / iteration-0 forward sweep)
 // ---------------------------------------------------------------------------
 template <int RPT, int LT>
-__global__ void __launch_bounds__(512 / RPT)
+__global__ void __launch_bounds__(512 / RPT, 2)
 kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx *__restrict__ state_in,
                     cplx *__restrict__ store, cplx *__restrict__ state_out, int direction) {
     __shared__ __attribute__((aligned(16))) cplx buf[2][KH_TILE_N];
@@ -258,7 +258,7 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
 // Barriers per interval: 1 (partial sums) + 1 (broadcast of the reduced sums)
 // + one per Taylor term.
 template <int RPT, int LT, bool SO>  // SO: second-order update, compiled separately
-__global__ void __launch_bounds__(512 / RPT)
+__global__ void __launch_bounds__(512 / RPT, 2)
 kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     if (u.n_dev != nullptr) {  // graph-replayed stepwise mode: interval index from device memory
         u.n_begin = *u.n_dev;
@@ -398,7 +398,9 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
                 double part[LT];
                 partial_total(par, part);
                 double D[LT];
-                const bool ok = kh_exchange<LT>(ex, n, k, LT, lane, part, D);
+                // (256-thread workgroups can run two per CU: up to 512 of them take part)
+                const bool ok = kh_exchange<LT, RPT == 2 ? KH_GATHER_CHUNKS_WIDE : KH_GATHER_CHUNKS>(ex, n, k, LT, lane,
+                                                                                                   part, D);
                 if (lane == 0) {
 #pragma unroll
                     for (int l = 0; l < LT; ++l) D_sh[par][l] = D[l];

@@ -269,6 +269,15 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     if (const char *d = getenv("KH_COOP_DELAY")) e->coop_poll_delay = atoi(d);
     const char *force = getenv("KH_KERNEL");  // "generic" | "tile256" | "tile512" | "q2" | "coop" (testing)
     const bool tile_ok = csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && e->K <= max_wgs;
+    // More objectives than CUs, one control: 256-thread workgroups (one wave per SIMD, 256 VGPRs) fit two per
+    // CU, so up to 2 x #CUs objectives stay co-resident -- and the two workgroups of a CU hide each other's
+    // phase latency.
+    const int max_wgs2 = 2 * e->num_cus < 64 * KH_GATHER_CHUNKS_WIDE ? 2 * e->num_cus : 64 * KH_GATHER_CHUNKS_WIDE;
+    const bool tile2_ok = csr_fw == nullptr && e->N <= KH_TILE_N && e->L == 1 && e->K > max_wgs && e->K <= max_wgs2;
+    if (tile2_ok && !(force && strcmp(force, "generic") == 0)) {
+        e->kind = KIND_TILE_RPT2;
+        e->grid_update = e->K;
+    }
     if (tile_ok && !(force && strcmp(force, "generic") == 0)) {
         // two waves per SIMD are needed to keep the fp64 FMA pipe issuing back to back
         e->kind = KIND_TILE_RPT1;

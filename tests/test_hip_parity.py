@@ -36,6 +36,8 @@ SMALL = {
     'c5_n64_L2': lambda: configs.config_c5(K=4, N=64, nt=41, L=2, distinct=True),
     'c5_n80': lambda: configs.config_c5(K=3, N=80, nt=31, L=2),
     'c5_n33': lambda: configs.config_c5(K=5, N=33, nt=41),
+    # more objectives than CUs: two 256-thread workgroups per CU
+    'c5_k300': lambda: configs.config_c5(K=300, N=16, nt=21),
     # objectives sharing one operator list, N > 64: the cooperative matrix-core kernels
     'c4_d9': lambda: configs.config_c4(d=9, nt=41, n_logical=2),
     'c4_d10_k9': lambda: configs.config_c4(d=10, nt=21, n_logical=3),
@@ -86,6 +88,7 @@ def test_sweeps_match_oracle(name):
     assert np.abs(ga2.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
     assert np.abs((opt2 - opt).cpu().numpy()).max() < 1e-12 * scale
     assert eng.kernel.startswith('tile64') == (spec.N <= 64)
+    assert (eng.kernel == 'tile64/256') == (name == 'c5_k300')
     assert (eng.kernel == 'coop16/mfma') == (name.startswith('c4_d') and spec.N > 64 or name.startswith('shared'))
     eng.close()
 
@@ -432,31 +435,33 @@ def test_edge_cases():
     from krotov_amd.engine import HipKrotovEngine
 
     rng = np.random.default_rng(5)
-    # non-uniform dt, control absent from one objective, K > number of CUs (generic persistent loop)
-    K, N, nt = 300, 6, 21
-    tl = np.cumsum(np.concatenate([[0.0], rng.uniform(0.01, 0.05, nt - 1)]))
-    H0 = [configs.herm(rng, N, 3.0) for _ in range(K)]
-    H1 = configs.herm(rng, N, 1.0)
-    ops = [[H0[k], (None if k == 7 else H1)] for k in range(K)]
-    init = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
-    init /= np.linalg.norm(init, axis=1)[:, None]
-    target = np.roll(init, 1, axis=0)
-    prob = ko.OracleProblem(ops, init, target, tl)
-    gp = [0.3 * np.sin(np.arange(nt - 1))]
-    S = [np.ones(nt - 1)]
-    eng = HipKrotovEngine(ops, np.diff(tl))
-    assert eng.kernel == 'generic'
-    chi_T = target / np.linalg.norm(target, axis=1)[:, None]
-    norms = np.full(K, 1.0 / (2 * K))
-    chi = eng.backward(chi_T, np.array(gp))
-    ref_chi = ko.backward_sweep(prob, chi_T, gp)
-    assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-12
-    opt, psi_T, g_a = eng.forward_update(chi, norms, init, np.array(gp), np.array(S), np.array([2.0]))
-    eng.check()
-    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, [2.0])
-    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12
-    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
-    eng.close()
+    # non-uniform dt, control absent from one objective, more objectives than CUs: 300 -> two 256-thread
+    # workgroups per CU (register tiles), 600 -> the generic kernels' persistent loop over objectives
+    for K, kernel in ((300, 'tile64/256'), (600, 'generic')):
+        N, nt = 6, 21
+        tl = np.cumsum(np.concatenate([[0.0], rng.uniform(0.01, 0.05, nt - 1)]))
+        H0 = [configs.herm(rng, N, 3.0) for _ in range(K)]
+        H1 = configs.herm(rng, N, 1.0)
+        ops = [[H0[k], (None if k == 7 else H1)] for k in range(K)]
+        init = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
+        init /= np.linalg.norm(init, axis=1)[:, None]
+        target = np.roll(init, 1, axis=0)
+        prob = ko.OracleProblem(ops, init, target, tl)
+        gp = [0.3 * np.sin(np.arange(nt - 1))]
+        S = [np.ones(nt - 1)]
+        eng = HipKrotovEngine(ops, np.diff(tl))
+        assert eng.kernel == kernel
+        chi_T = target / np.linalg.norm(target, axis=1)[:, None]
+        norms = np.full(K, 1.0 / (2 * K))
+        chi = eng.backward(chi_T, np.array(gp))
+        ref_chi = ko.backward_sweep(prob, chi_T, gp)
+        assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-12
+        opt, psi_T, g_a = eng.forward_update(chi, norms, init, np.array(gp), np.array(S), np.array([2.0]))
+        eng.check()
+        ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, [2.0])
+        assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12
+        assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+        eng.close()
     # N = 1 and a large step norm (several Taylor sub-steps)
     ops1 = [[np.array([[2.5 + 0j]]), np.array([[40.0 + 0j]])]]
     eng = HipKrotovEngine(ops1, [0.5, 0.25])
