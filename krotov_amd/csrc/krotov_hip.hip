@@ -50,6 +50,7 @@ struct kh_engine {
     double tol, theta_max;
     int device, num_cus;
     KernelKind kind;
+    KernelKind kind_store;  // family of the plain sweeps (no cross-objective coupling: any K)
     int grid_update;  // workgroups of the single-launch update sweep
     // cooperative shared-operator kernels (kh_coop.h): row blocks, column groups, k-steps per wave
     int coop_G = 0, coop_Y = 0, coop_ks = 0, coop_cols = KH_COOP_COLS;
@@ -319,6 +320,12 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             if (!(pr->theta_max > 0.0)) e->theta_max = 4.0;
         }
     }
+    // The plain sweeps have no cross-objective coupling, so the register-tile kernel serves them for any
+    // number of objectives (workgroups simply run in turns) even when the update sweep needs the generic one.
+    e->kind_store = e->kind;
+    if (e->kind == KIND_GENERIC && csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 &&
+        !(force && strcmp(force, "generic") == 0))
+        e->kind_store = KIND_TILE_RPT1;
     if (e->kind == KIND_TILE_Q2) {
         // stage P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 once per distinct operator (pair)
         const size_t bytes = sizeof(cplx) * (size_t)e->N * e->N;
@@ -500,14 +507,14 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     const int direction = backward ? -1 : +1;
     KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
     int rc = KH_OK;
-    if (e->kind == KIND_TILE_Q2) {
+    if (e->kind_store == KIND_TILE_Q2) {
         kh_q2_sweep_store<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(
             p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
-    } else if (e->kind == KIND_TILE_RPT2) {
+    } else if (e->kind_store == KIND_TILE_RPT2) {
         rc = dispatch_tile_store<2>(e, p, pulses, in, store, out, direction, st);
-    } else if (e->kind == KIND_TILE_RPT1) {
+    } else if (e->kind_store == KIND_TILE_RPT1) {
         rc = dispatch_tile_store<1>(e, p, pulses, in, store, out, direction, st);
-    } else if (e->kind == KIND_COOP) {
+    } else if (e->kind_store == KIND_COOP) {
         if (e->coop_cols == 4)
             rc = e->coop_ks <= 8 ? launch_coop_store<8, 4>(e, p, pulses, in, store, out, direction, st)
                                  : launch_coop_store<16, 4>(e, p, pulses, in, store, out, direction, st);
