@@ -92,6 +92,7 @@ struct kh_engine {
     // tuning knobs (s_sleep units of 64 cycles), read from the environment once at creation
     int poll_delay = 16;       // KH_POLL_DELAY: head start of the update-sum stores, ~0.4 us: measured best
     int coop_poll_delay = 12;  // KH_COOP_DELAY: the same for the cooperative kernels' block exchange
+    long long timeout_ticks = 100000000LL;  // KH_TIMEOUT_MS: bound on any in-kernel wait (100 MHz ticks; 1 s)
 };
 
 // Kernels with more than 64 KiB of dynamic LDS need the limit raised once per device: remembered per
@@ -268,6 +269,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     e->grid_update = e->K < max_wgs ? e->K : max_wgs;
     if (const char *d = getenv("KH_POLL_DELAY")) e->poll_delay = atoi(d);
     if (const char *d = getenv("KH_COOP_DELAY")) e->coop_poll_delay = atoi(d);
+    if (const char *d = getenv("KH_TIMEOUT_MS"))  // e.g. under a profiler that slows the kernels down
+        if (atoll(d) > 0) e->timeout_ticks = atoll(d) * 100000LL;
     const char *force = getenv("KH_KERNEL");  // "generic" | "tile256" | "tile512" | "q2" | "coop" (testing)
     const bool tile_ok = csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && e->K <= max_wgs;
     // More objectives than CUs, one control: 256-thread workgroups (one wave per SIMD, 256 VGPRs) fit two per
@@ -569,7 +572,7 @@ static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
     ex.slots = e->d_slots;
     ex.abort_flag = e->d_abort;
     ex.G = (e->kind == KIND_COOP && internal_exchange) ? e->coop_G * e->coop_Y : e->grid_update;
-    ex.timeout_ticks = 100000000LL;  // 1 s of the 100 MHz wall clock
+    ex.timeout_ticks = e->timeout_ticks;
     ex.peer_windows = e->d_p2p_peers;
     ex.my_window = e->p2p_window;
     ex.world = (e->p2p_ready && internal_exchange) ? e->p2p_world : 1;
