@@ -65,6 +65,7 @@ __device__ __forceinline__ double dpp_move(double v) {
 #define KH_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
 #define KH_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i within each 8 lanes
 #define KH_DPP_MIRROR 0x140      // lane i <-> 15-i within each 16-lane row
+#define KH_DPP_ROR8 0x128        // lane i <- lane (i + 8) % 16 within each 16-lane row
 
 // all-reduce (sum) over groups of 4 / 8 / 16 adjacent lanes; every lane of the
 // group ends up with the same value, summed in the same order.
@@ -344,16 +345,22 @@ __device__ __forceinline__ bool kh_p2p_gather(const KhExchange &ex, int parity, 
 // The whole per-interval exchange, called by ONE full wave of every workgroup:
 // publish this workgroup's partial sums, gather the GPU's total, and (sharded
 // runs) exchange the GPU totals across ranks.  `n` = interval index.
+// It comes in two halves so that a kernel can put independent work between
+// the store and the first poll (the stores need ~1 us to become visible).
+__device__ __forceinline__ void kh_exchange_publish(const KhExchange &ex, int n, int wg, int L, int lane,
+                                                    const double *part) {
+    if (ex.G == 1 && ex.world == 1) return;  // a single workgroup on a single GPU: nothing to exchange
+    kh_publish(ex, n & 1, wg, L, lane, part, (unsigned)(n + 1));
+}
 template <int MAXL, int CH = KH_GATHER_CHUNKS>
-__device__ __forceinline__ bool kh_exchange(const KhExchange &ex, int n, int wg, int L, int lane,
-                                            const double *part, double (&out)[MAXL]) {
-    if (ex.G == 1 && ex.world == 1) {  // a single workgroup on a single GPU: nothing to exchange
+__device__ __forceinline__ bool kh_exchange_collect(const KhExchange &ex, int n, int wg, int L, int lane,
+                                                    const double *part, double (&out)[MAXL]) {
+    if (ex.G == 1 && ex.world == 1) {
 #pragma unroll
         for (int l = 0; l < MAXL; ++l) out[l] = l < L ? part[l] : 0.0;
         return true;
     }
     const int parity = n & 1;
-    kh_publish(ex, parity, wg, L, lane, part, (unsigned)(n + 1));
     if (!kh_gather<MAXL, CH>(ex, parity, L, (unsigned)(n + 1), lane, out)) return false;
     if (ex.world > 1) {
         const unsigned int epoch = ex.epoch_base + (unsigned)(n + 1);
@@ -361,4 +368,10 @@ __device__ __forceinline__ bool kh_exchange(const KhExchange &ex, int n, int wg,
         if (!kh_p2p_gather<MAXL>(ex, parity, L, epoch, lane, out)) return false;
     }
     return true;
+}
+template <int MAXL, int CH = KH_GATHER_CHUNKS>
+__device__ __forceinline__ bool kh_exchange(const KhExchange &ex, int n, int wg, int L, int lane,
+                                            const double *part, double (&out)[MAXL]) {
+    kh_exchange_publish(ex, n, wg, L, lane, part);
+    return kh_exchange_collect<MAXL, CH>(ex, n, wg, L, lane, part, out);
 }

@@ -221,6 +221,8 @@ struct KhUpdateArgs {
     const double *sigma;        // [nt-1] sigma at the interval mid-points
     const int *n_dev;           // stepwise mode under graph replay: the interval index lives in device memory
                                 // (read here, incremented by kh_reduce_partials), so every replay is identical
+    double adj_sign;            // +1 / -1 if every control operator equals +/- its own adjoint (exactly), else 0:
+                                // <chi|H phi> may then be taken as <(sign H) chi|phi> (kernels with ADJ = true)
 };
 
 // Im( mu * norm_k * <chi_k(t_n) | H_l phi_k> ) summed over this workgroup's
@@ -438,6 +440,24 @@ __global__ void kh_fro_norms(const cplx *const *ops, int count, int N, double *n
         double t = 0.0;
         for (unsigned w = 0; w < blockDim.x / 64; ++w) t += red[w];
         norms[idx] = sqrt(t);
+    }
+}
+
+// flags[0] (flags[1]) is raised when some control operator (index i with i % Lp1 != 0) differs from
+// plus (minus) its staged adjoint in any bit: decides KhUpdateArgs::adj_sign at engine creation
+__global__ void kh_adjoint_sign_kernel(const cplx *const *__restrict__ ops, const cplx *const *__restrict__ ops_adj,
+                                       int nops, int Lp1, int N, int *__restrict__ flags) {
+    for (int i = blockIdx.x; i < nops; i += gridDim.x) {
+        if (i % Lp1 == 0 || ops[i] == nullptr) continue;
+        const cplx *a = ops[i], *b = ops_adj[i];
+        bool plus_bad = false, minus_bad = false;
+        for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
+            const cplx x = a[idx], y = b[idx];
+            plus_bad = plus_bad || x.x != y.x || x.y != y.y;
+            minus_bad = minus_bad || x.x != -y.x || x.y != -y.y;
+        }
+        if (plus_bad) flags[0] = 1;
+        if (minus_bad) flags[1] = 1;
     }
 }
 

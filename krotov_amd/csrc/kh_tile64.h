@@ -20,22 +20,68 @@
 
 #define KH_TILE_N 64
 
+// Lane roles inside a wave (8 rows x 8 column groups), in two flavours:
+//   KhLanes<false>: the row's 8 column groups are 8 adjacent lanes; row sums are a three-step DPP butterfly
+//     (quad_perm, quad_perm, row_half_mirror: 18 VALU instructions for a complex value).
+//   KhLanes<true>: the matrix core adds them.  v_mfma_f64_4x4x4 with a constant B operand sums its A operand
+//     over the four lanes 16 k + i (k = 0..3), so the column group's low bits are lane >> 4; the result for
+//     i = 4 blk + r4 lands on lanes 16 r4 + 4 blk + (0..3), and ONE DPP half-mirror step adds the blk-parity
+//     partner: 2 MFMA + 6 VALU per complex value.  Pays in the two-terms-per-phase kernels (VALU-issue
+//     bound: -3 % on the backward sweep); the one-term-per-phase kernels are latency-bound and keep DPP
+//     (measured +1 % with the MFMA form).
+//   input side  (operator tiles, products):  column group cg(lane),  row row_in(lane)
+//   output side (row sums, state, co-state): row row_out(lane), replicated over 8 adjacent lanes; lane & 7 == 0
+//     writes
+template <bool MFMA>
+struct KhLanes;
+template <>
+struct KhLanes<true> {
+    static __device__ __forceinline__ int cg(int lane) { return (lane >> 4) + 4 * ((lane >> 2) & 1); }
+    static __device__ __forceinline__ int row_in(int lane) { return (lane & 3) + 4 * ((lane >> 3) & 1); }
+    static __device__ __forceinline__ int row_out(int lane) { return (lane >> 4) + 4 * ((lane >> 3) & 1); }
+    // scale * (sum of v over the 8 column groups of a row), on the row's output lanes
+    static __device__ __forceinline__ double rowsum(double v, double scale) {
+        const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(v, scale, 0.0, 0, 0, 0);
+        return d + dpp_move<KH_DPP_HALF_MIRROR>(d);
+    }
+    // sum over the wave of a value that is zero except on the 8 writer lanes (lane & 7 == 0); valid on lane 0.
+    // The same MFMA adds lanes {0,16,32,48} into lane 0 and {8,24,40,56} into lane 8; one row rotation joins
+    // them: 1 MFMA + 3 VALU instead of the ~30 dependent instructions of a full 64-lane butterfly.
+    static __device__ __forceinline__ double writers_sum(double v) {
+        const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(v, 1.0, 0.0, 0, 0, 0);
+        return d + dpp_move<KH_DPP_ROR8>(d);
+    }
+};
+template <>
+struct KhLanes<false> {
+    static __device__ __forceinline__ int cg(int lane) { return lane & 7; }
+    static __device__ __forceinline__ int row_in(int lane) { return lane >> 3; }
+    static __device__ __forceinline__ int row_out(int lane) { return lane >> 3; }
+    static __device__ __forceinline__ double rowsum(double v, double scale) { return scale * sum8(v); }
+    static __device__ __forceinline__ double writers_sum(double v) { return sum64(v); }
+};
+typedef KhLanes<false> KhTileLanes;
+
 template <int RPT>
 struct KhTile {
     static constexpr int THREADS = 512 / RPT;
     static constexpr int WAVES = THREADS / 64;
-    // row owned by (wave, lane) for r in [0, RPT)
-    static __device__ __forceinline__ int row(int wave, int lane, int r) {
-        return wave * (8 * RPT) + r * 8 + (lane >> 3);
+    // rows of (wave, lane) for r in [0, RPT): whose operator elements it holds / whose sums and state it holds
+    static __device__ __forceinline__ int row_in(int wave, int lane, int r) {
+        return wave * (8 * RPT) + r * 8 + KhTileLanes::row_in(lane);
     }
+    static __device__ __forceinline__ int row(int wave, int lane, int r) {
+        return wave * (8 * RPT) + r * 8 + KhTileLanes::row_out(lane);
+    }
+    static __device__ __forceinline__ bool writer(int lane) { return (lane & 7) == 0; }
 };
 
 template <int RPT>
 __device__ __forceinline__ void kh_tile_load_op(const cplx *op, int N, int wave, int lane, cplx (&a)[RPT][8]) {
-    const int cg = lane & 7;
+    const int cg = KhTileLanes::cg(lane);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-        const int row = KhTile<RPT>::row(wave, lane, r);
+        const int row = KhTile<RPT>::row_in(wave, lane, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int col = cg + 8 * j;
@@ -44,7 +90,7 @@ __device__ __forceinline__ void kh_tile_load_op(const cplx *op, int N, int wave,
     }
 }
 
-// y[r] = sum_c a[r][c] x[c], reduced over the row's 8 lanes (same value in all 8)
+// y[r] = sum_c a[r][c] x[c], summed over the row's 8 column groups (on the row's 8 output lanes)
 template <int RPT>
 __device__ __forceinline__ void kh_tile_matvec(const cplx (&a)[RPT][8], const cplx *x, int cg, cplx (&y)[RPT]) {
     cplx xv[8];
@@ -55,8 +101,8 @@ __device__ __forceinline__ void kh_tile_matvec(const cplx (&a)[RPT][8], const cp
         cplx acc = c_make(0.0, 0.0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) c_fma(acc, a[r][j], xv[j]);
-        y[r].x = sum8(acc.x);
-        y[r].y = sum8(acc.y);
+        y[r].x = KhTileLanes::rowsum(acc.x, 1.0);
+        y[r].y = KhTileLanes::rowsum(acc.y, 1.0);
     }
 }
 
@@ -71,7 +117,8 @@ __device__ __forceinline__ int kh_tile_expm_action(const cplx (&a)[RPT][8], cplx
                                                    cplx (*buf)[KH_TILE_N], const double *inv, int &cur, double fre,
                                                    double fim,
                                                    double dt, int nsub, int m, int wave, int lane) {
-    const int cg = lane & 7;
+    const int cg = KhTileLanes::cg(lane);
+    const bool writer = KhTile<RPT>::writer(lane);
     const double h = nsub == 1 ? dt : dt / nsub;
     for (int sub = 0; sub < nsub; ++sub) {
         for (int j = 1; j <= m; ++j) {
@@ -86,7 +133,7 @@ __device__ __forceinline__ int kh_tile_expm_action(const cplx (&a)[RPT][8], cplx
                 state[r].x += t.x;
                 state[r].y += t.y;
                 const double wx = last ? state[r].x : t.x, wy = last ? state[r].y : t.y;
-                if (cg == 0) buf[cur ^ 1][KhTile<RPT>::row(wave, lane, r)] = c_make(wx, wy);
+                if (writer) buf[cur ^ 1][KhTile<RPT>::row(wave, lane, r)] = c_make(wx, wy);
             }
             __syncthreads();
             cur ^= 1;
@@ -153,8 +200,8 @@ struct KhTileOps {
             cplx acc = c_make(0.0, 0.0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) c_fma(acc, at(o, r, j), xv[j]);
-            y[r].x = sum8(acc.x);
-            y[r].y = sum8(acc.y);
+            y[r].x = KhTileLanes::rowsum(acc.x, 1.0);
+            y[r].y = KhTileLanes::rowsum(acc.y, 1.0);
         }
     }
 };
@@ -180,7 +227,8 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
     __shared__ __attribute__((aligned(16))) cplx buf[2][KH_TILE_N];
     __shared__ __attribute__((aligned(16))) double inv_sh[KH_MAX_DEGREE + 2];
     __shared__ __attribute__((aligned(16))) double deg_sh[KH_MAX_DEGREE + 2];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool writer = KhTile<RPT>::writer(lane);
     if (tid <= KH_MAX_DEGREE) {
         inv_sh[tid] = tid ? 1.0 / tid : 0.0;
         deg_sh[tid] = p.deg_theta[tid];
@@ -204,7 +252,7 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
         }
         __syncthreads();  // previous objective's readers are done with buf
         int cur = 0;
-        if (cg == 0) {
+        if (writer) {
 #pragma unroll
             for (int r = 0; r < RPT; ++r) buf[0][KhTile<RPT>::row(wave, lane, r)] = state[r];
         }
@@ -271,7 +319,8 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     __shared__ __attribute__((aligned(16))) double D_sh[2][LT + 1];       // [LT] = ok flag
     __shared__ __attribute__((aligned(16))) double inv_sh[KH_MAX_DEGREE + 2];
     __shared__ __attribute__((aligned(16))) double deg_sh[KH_MAX_DEGREE + 2];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = KhTileLanes::cg(lane);
+    const bool writer = KhTile<RPT>::writer(lane);
     if (tid <= KH_MAX_DEGREE) {
         inv_sh[tid] = tid ? 1.0 / tid : 0.0;
         deg_sh[tid] = p.deg_theta[tid];
@@ -297,7 +346,7 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         state[r] = row < N ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     }
     int cur = 0;
-    if (cg == 0) {
+    if (writer) {
 #pragma unroll
         for (int r = 0; r < RPT; ++r) buf[0][KhTile<RPT>::row(wave, lane, r)] = state[r];
     }
@@ -330,7 +379,7 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
             cplx y[RPT];
             h.matvec(1 + l, buf[cur], cg, y);
             cplx ov = c_make(0.0, 0.0);
-            if (cg == 0) {
+            if (writer) {
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {
                     // second order: the bra is chi + hs (phi - phi_prev)

@@ -24,12 +24,18 @@
 #include "kh_tile64.h"
 
 #define KH_Q2_THREADS 512
+#ifdef KH_Q2_DPP_REDUCE  // all-VALU row sums, for A/B timing (scripts/ab_q2_reduce.sh)
+typedef KhLanes<false> KhQ2Lanes;
+#else
+typedef KhLanes<true> KhQ2Lanes;  // row sums on the matrix core (kh_tile64.h, "Lane roles")
+#endif
 #define KH_Q2_TILE_ELEMS (8 * KH_Q2_THREADS)  // complex elements of one 64x64 operator, lane-linear
 
 struct KhQ2Lds {
     cplx *h0;    // [8][512]
     cplx *p0;    // [8][512]
     cplx (*buf)[KH_TILE_N];  // [2][64]
+    cplx *chib;  // [64] chi(t_{n+1}) for the adjoint-side partial sums
     double *red; // [2][8 waves][2]
     double *D;   // [2][2]
     double2 *inv2;  // [KH_MAX_DEGREE/2] {1/(2p+1), 1/((2p+1)(2p+2))} (LDS: no SMEM loads in the phase loop)
@@ -37,7 +43,7 @@ struct KhQ2Lds {
 };
 
 __host__ __device__ inline size_t kh_q2_lds_bytes() {
-    return (size_t)2 * KH_Q2_TILE_ELEMS * sizeof(cplx) + 2 * KH_TILE_N * sizeof(cplx) + (2 * 8 * 2 + 4) * sizeof(double) +
+    return (size_t)2 * KH_Q2_TILE_ELEMS * sizeof(cplx) + 3 * KH_TILE_N * sizeof(cplx) + (2 * 8 * 2 + 4) * sizeof(double) +
            (KH_MAX_DEGREE / 2) * sizeof(double2) + (KH_MAX_DEGREE + 2) * sizeof(double);
 }
 
@@ -46,16 +52,17 @@ __device__ __forceinline__ KhQ2Lds kh_q2_carve(char *smem) {
     s.h0 = (cplx *)smem;
     s.p0 = s.h0 + KH_Q2_TILE_ELEMS;
     s.buf = (cplx(*)[KH_TILE_N])(s.p0 + KH_Q2_TILE_ELEMS);
-    s.red = (double *)(s.buf + 2);
+    s.chib = (cplx *)(s.buf + 2);
+    s.red = (double *)(s.chib + KH_TILE_N);
     s.D = s.red + 2 * 8 * 2;
     s.inv2 = (double2 *)(s.D + 4);
     s.deg = (double *)(s.inv2 + KH_MAX_DEGREE / 2);
     return s;
 }
 
-// this lane's 8 elements of an operator (row wave*8 + lane/8, columns cg + 8 j)
+// this lane's 8 elements of an operator (row wave*8 + row_in, columns cg + 8 j)
 __device__ __forceinline__ void kh_q2_load_tile(const cplx *op, int N, int wave, int lane, cplx (&t)[8]) {
-    const int row = wave * 8 + (lane >> 3), cg = lane & 7;
+    const int row = wave * 8 + KhQ2Lanes::row_in(lane), cg = KhQ2Lanes::cg(lane);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int col = cg + 8 * j;
@@ -95,12 +102,17 @@ __device__ __forceinline__ void kh_q2_build(const KhQ2Lds &s, int tid, double ep
 // its unreduced  sA = sum_p c1_p (A t_2p)|lane  and reduces it ONCE per
 // interval.  Order within a phase: B FMAs -> reduce -> write (what phase p+1
 // waits for), then the A FMAs under the LDS write latency, then the barrier.
+// `epilogue()` runs once, when the new state is complete in `state` and before the last barrier: work that
+// depends on the new state and must be visible after that barrier rides on it instead of a barrier of its own.
 // Returns the number of matrix-vector products issued.
+template <class Epilogue>
 __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx (&b)[8], cplx &state,
                                                  cplx (*buf)[KH_TILE_N], const double2 *inv2, int &cur,
                                                  cplx *store_in, int N, double fre, double fim,
-                                                 double dt, int nsub, int m, int wave, int lane) {
-    const int cg = lane & 7, row = wave * 8 + (lane >> 3);
+                                                 double dt, int nsub, int m, int wave, int lane,
+                                                 Epilogue epilogue) {
+    const int cg = KhQ2Lanes::cg(lane), row = wave * 8 + KhQ2Lanes::row_out(lane);
+    const bool writer = (lane & 7) == 0;
     const double h = nsub == 1 ? dt : dt / nsub;
     const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
     const int phases = (m + 1) >> 1;
@@ -123,22 +135,21 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
             cplx yb = c_make(0.0, 0.0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) c_fma(yb, b[j], xv[j]);
-            yb.x = sum8(yb.x);
-            yb.y = sum8(yb.y);
-            const double t2x = c2 * yb.x, t2y = c2 * yb.y;
+            const double t2x = KhQ2Lanes::rowsum(yb.x, c2), t2y = KhQ2Lanes::rowsum(yb.y, c2);
             state.x += t2x;
             state.y += t2y;
-            if (!last && cg == 0) buf[cur ^ 1][row] = c_make(t2x, t2y);
+            if (!last && writer) buf[cur ^ 1][row] = c_make(t2x, t2y);
             cplx ya = c_make(0.0, 0.0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) c_fma(ya, a[j], xv[j]);
             sA.x = fma(hj1, ya.x, sA.x);
             sA.y = fma(hj1, ya.y, sA.y);
             if (last) {
-                const cplx odd = c_mul(c_make(fre, fim), c_make(sum8(sA.x), sum8(sA.y)));
+                const cplx odd = c_mul(c_make(fre, fim), c_make(KhQ2Lanes::rowsum(sA.x, 1.0), KhQ2Lanes::rowsum(sA.y, 1.0)));
                 state.x += odd.x;
                 state.y += odd.y;
-                if (cg == 0) buf[cur ^ 1][row] = c_make(state.x, state.y);
+                if (writer) buf[cur ^ 1][row] = c_make(state.x, state.y);
+                if (sub + 1 == nsub) epilogue();
             }
             __syncthreads();
             cur ^= 1;
@@ -157,10 +168,11 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
                   int direction) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KhQ2Lds s = kh_q2_carve(smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / ((2.0 * tid + 1) * (2 * tid + 2)));
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
-    const int row = wave * 8 + (lane >> 3);
+    const int row = wave * 8 + KhQ2Lanes::row_out(lane);  // the row whose sums/state this lane holds
+    const bool writer = (lane & 7) == 0;
     const int N = p.N, nt = p.nt;
     double matvecs = 0.0;
     for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
@@ -177,7 +189,7 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
 
         cplx state = row < N ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
         int cur = 0;
-        if (cg == 0) s.buf[0][row] = state;
+        if (writer) s.buf[0][row] = state;
         __syncthreads();
         // the state entering interval `step` is stored from inside its first phase
         // (index n for the forward direction, n+1 for the backward one); the last
@@ -200,7 +212,7 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
             cplx *store_in =
                 store == nullptr ? nullptr : store + ((size_t)k * nt + (direction > 0 ? n : n + 1)) * N;
             matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, store_in, N, p.fre, p.fim, dt, nsub, m,
-                                         wave, lane);
+                                         wave, lane, [] {});
         }
         if (store != nullptr && wave == 0 && lane < N)
             store[((size_t)k * nt + (direction > 0 ? nt - 1 : 0)) * N + lane] = s.buf[cur][lane];
@@ -212,9 +224,17 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
 // ---------------------------------------------------------------------------
 // forward sweep with sequential pulse update (optimize.py:444-508), grid == K
 // ---------------------------------------------------------------------------
-template <bool SO>  // SO: second-order update (compiled separately so first order keeps its register budget)
+// SO: second-order update (compiled separately so first order keeps its register budget).
+// ADJ (first order, in-kernel exchange, control operator equal to +/- its adjoint): the partial sum of interval
+// n+1 is taken as <w|phi(t_{n+1})> with w = (sign H1) chi(t_{n+1}).  w does not depend on phi, so its
+// matrix-vector product runs in the shadow of the exchange of interval n (the other seven waves idle there, and
+// wave 0 has ~1 us between its store and the first useful poll), and what is left after the last Taylor phase
+// -- one complex multiply per row, the wave sum, one LDS write -- rides on that phase's barrier: the separate
+// "partial sums" step (8 LDS reads, 32 FMAs, row sums, a barrier: 0.46 us of 6 per interval) disappears.
+template <bool SO, bool ADJ>
 __global__ void __launch_bounds__(KH_Q2_THREADS)
 kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdateArgs u, KhExchange ex) {
+    static_assert(!(SO && ADJ), "the second-order bra depends on the new state");
     if (u.n_dev != nullptr) {  // graph-replayed stepwise mode: interval index from device memory
         u.n_begin = *u.n_dev;
         u.n_end = u.n_begin + 1;
@@ -224,10 +244,14 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     const KhQ2Lds s = kh_q2_carve(smem);
     double(*red)[8][2] = (double(*)[8][2])s.red;  // [parity][wave][re, im]
     double(*D_sh)[2] = (double(*)[2])s.D;         // [parity][value, ok]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = lane & 7;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = KhQ2Lanes::cg(lane);
     if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / ((2.0 * tid + 1) * (2 * tid + 2)));
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
-    const int row = wave * 8 + (lane >> 3);
+    const int row = wave * 8 + KhQ2Lanes::row_out(lane);  // the row whose sums/state/co-state this lane holds
+    // one wave of each SIMD's pair (wave 0, which runs the exchange, among them) issues first when both are
+    // ready: the pair's latency gaps interleave instead of coinciding (measured -1.7 % on the update sweep)
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+    const bool writer = (lane & 7) == 0;
     const int N = p.N, nt = p.nt;
     const int k = blockIdx.x;
     double matvecs = 0.0;
@@ -246,7 +270,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
 
     cplx state = row < N ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     int cur = 0;
-    if (cg == 0) s.buf[0][row] = state;
+    if (writer) s.buf[0][row] = state;
     __syncthreads();
 
     double g_a_loc = 0.0;
@@ -270,15 +294,15 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         cplx y = c_make(0.0, 0.0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) c_fma(y, h1[j], xv[j]);
-        y.x = sum8(y.x);
-        y.y = sum8(y.y);
+        y.x = KhQ2Lanes::rowsum(y.x, 1.0);
+        y.y = KhQ2Lanes::rowsum(y.y, 1.0);
         cplx ov = c_make(0.0, 0.0);
         // <chi + hs (phi - phi_prev) | H1 phi>: the second-order bra folded into the co-state
         cplx bra = chi;
         if constexpr (SO) bra = c_make(fma(hs, state.x - prev.x, chi.x), fma(hs, state.y - prev.y, chi.y));
-        if (cg == 0) c_fma_conj(ov, bra, y);
+        if (writer) c_fma_conj(ov, bra, y);
         // Im(mu <chi|H1 phi>) needs only one real combination: reduce that, not both parts
-        const double v = sum64(u.mu_re * ov.y + u.mu_im * ov.x);
+        const double v = KhQ2Lanes::writers_sum(u.mu_re * ov.y + u.mu_im * ov.x);
         if (lane == 0) red[par][wave][0] = v;
         matvecs += 1.0;
     };
@@ -289,10 +313,30 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         return chi_norm * acc;
     };
 
+    // ADJ: w = sign * H1 chi(t_{n+1}) (chi broadcast from LDS) on the row's output lanes
+    cplx w = c_make(0.0, 0.0);
+    auto adjoint_side = [&]() {
+        cplx xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = s.chib[cg + 8 * j];
+        cplx y = c_make(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c_fma(y, h1[j], xv[j]);
+        w.x = KhQ2Lanes::rowsum(y.x, u.adj_sign);
+        w.y = KhQ2Lanes::rowsum(y.y, u.adj_sign);
+        matvecs += 1.0;
+    };
+
     const bool emit_only = (!u.internal_exchange && u.n_begin == u.n_end);
     if ((u.internal_exchange || emit_only) && u.n_begin < nt - 1) {
         load_chi(u.n_begin);
         partial_pieces(u.n_begin & 1);
+    }
+    if constexpr (ADJ) {
+        if (u.n_begin + 1 < nt - 1) {
+            load_chi(u.n_begin + 1);
+            if (writer) s.chib[row] = chi;
+        }
     }
     __syncthreads();
     if (emit_only) {
@@ -312,16 +356,25 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
 #endif
     for (int n = u.n_begin; n < u.n_end; ++n) {
         const int par = n & 1;
-        if (n + 1 < nt - 1) load_chi(n + 1);
+        if constexpr (!ADJ) {
+            if (n + 1 < nt - 1) load_chi(n + 1);
+        }
 #ifdef KH_TIMING
         const long long tq0 = clock64();
 #endif
         // ---- cross-objective sum (optimize.py:470) ----
         if (u.internal_exchange) {
+            double part[1] = {0.0};
             if (wave == 0) {
-                double part[1] = {partial_total(par)};
+                part[0] = partial_total(par);
+                kh_exchange_publish(ex, n, k, 1, lane, part);
+            }
+            if constexpr (ADJ) {
+                if (n + 1 < nt - 1) adjoint_side();  // chib holds chi(t_{n+1})
+            }
+            if (wave == 0) {
                 double D[1];
-                const bool ok = kh_exchange<1>(ex, n, k, 1, lane, part, D);
+                const bool ok = kh_exchange_collect<1>(ex, n, k, 1, lane, part, D);
                 if (lane == 0) {
                     D_sh[par][0] = D[0];
                     D_sh[par][1] = ok ? 1.0 : 0.0;
@@ -360,15 +413,32 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
         cplx *fw_out = nullptr;
         if constexpr (SO) fw_out = u.fw_store + ((size_t)k * nt + n) * N;
-        matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
-                                     lane);
+        if constexpr (ADJ) {
+            if (n + 2 < nt - 1) load_chi(n + 2);  // lands during the phases; goes to LDS in the epilogue
+            matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
+                                         lane, [&] {
+                                             if (n + 1 < nt - 1) {
+                                                 cplx ov = c_make(0.0, 0.0);
+                                                 if (writer) c_fma_conj(ov, w, state);
+                                                 const double v =
+                                                     KhQ2Lanes::writers_sum(u.mu_re * ov.y + u.mu_im * ov.x);
+                                                 if (lane == 0) red[(n + 1) & 1][wave][0] = v;
+                                                 if (n + 2 < nt - 1 && writer) s.chib[row] = chi;
+                                             }
+                                         });
+        } else {
+            matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
+                                         lane, [] {});
+        }
 #ifdef KH_TIMING
         const long long tq2 = clock64();
         t_prop += tq2 - tq1;
 #endif
-        if (n + 1 < nt - 1) {
-            partial_pieces((n + 1) & 1);
-            __syncthreads();
+        if constexpr (!ADJ) {
+            if (n + 1 < nt - 1) {
+                partial_pieces((n + 1) & 1);
+                __syncthreads();
+            }
         }
 #ifdef KH_TIMING
         t_part += clock64() - tq2;

@@ -91,7 +91,9 @@ struct kh_engine {
     std::set<const void *> lds_raised;  // kernels whose dynamic-LDS limit was raised on this engine's device
     // tuning knobs (s_sleep units of 64 cycles), read from the environment once at creation
     int poll_delay = 16;       // KH_POLL_DELAY: head start of the update-sum stores, ~0.4 us: measured best
+    int adj_poll_delay = 0;    // KH_ADJ_DELAY: the same where a matrix-vector product already sits between store and poll
     int coop_poll_delay = 12;  // KH_COOP_DELAY: the same for the cooperative kernels' block exchange
+    double adj_sign = 0.0;  // +1 / -1: every control operator equals +/- its adjoint exactly (else 0)
     long long timeout_ticks = 100000000LL;  // KH_TIMEOUT_MS: bound on any in-kernel wait (100 MHz ticks; 1 s)
 };
 
@@ -240,6 +242,21 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     KH_HIP_E(hipMalloc((void **)&e->d_ops_bw, sizeof(cplx *) * nops));
     KH_HIP_E(hipMemcpy((void *)e->d_ops_fw, fw.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
     KH_HIP_E(hipMemcpy((void *)e->d_ops_bw, bw.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
+    if (csr_fw == nullptr && e->L >= 1) {  // is every control operator its own (negative) adjoint, bit for bit?
+        int *d_flags = nullptr, flags[2] = {1, 1};
+        KH_HIP_E(hipMalloc(&d_flags, sizeof(flags)));
+        hipError_t err = hipMemset(d_flags, 0, sizeof(flags));
+        if (err == hipSuccess) {
+            kh_adjoint_sign_kernel<<<(unsigned)(nops < 1024 ? nops : 1024), 256>>>(e->d_ops_fw, e->d_ops_bw, (int)nops,
+                                                                                   1 + e->L, e->N, d_flags);
+            err = hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(d_flags);
+        KH_HIP_E(err);
+        e->adj_sign = flags[0] == 0 ? 1.0 : (flags[1] == 0 ? -1.0 : 0.0);
+        if (const char *d = getenv("KH_NO_ADJ"))  // A/B switch: keep <chi|H phi> on the forward side
+            if (atoi(d) != 0) e->adj_sign = 0.0;
+    }
     KH_HIP_E(hipMalloc(&e->d_norms, sizeof(double) * nops));
     if (csr_fw != nullptr) {
         static_assert(sizeof(KhCsr) == sizeof(kh_csr), "kh_csr layout");
@@ -268,6 +285,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     const int max_wgs = e->num_cus < 64 * KH_GATHER_CHUNKS ? e->num_cus : 64 * KH_GATHER_CHUNKS;
     e->grid_update = e->K < max_wgs ? e->K : max_wgs;
     if (const char *d = getenv("KH_POLL_DELAY")) e->poll_delay = atoi(d);
+    if (const char *d = getenv("KH_ADJ_DELAY")) e->adj_poll_delay = atoi(d);
     if (const char *d = getenv("KH_COOP_DELAY")) e->coop_poll_delay = atoi(d);
     if (const char *d = getenv("KH_TIMEOUT_MS"))  // e.g. under a profiler that slows the kernels down
         if (atoll(d) > 0) e->timeout_ticks = atoll(d) * 100000LL;
@@ -376,9 +394,11 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         }
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kh_q2_lds_bytes()));
-        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false>,
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
-        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<true>,
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<true, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
 
     }
@@ -593,9 +613,14 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     int rc = KH_OK;
     if (e->kind == KIND_TILE_Q2 && !stepwise) {
         if (u.sigma != nullptr)
-            kh_q2_forward_update<true><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
+            kh_q2_forward_update<true, false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
+        else if (u.adj_sign != 0.0) {
+            KhExchange exa = ex;
+            exa.first_poll_delay = e->adj_poll_delay;
+            kh_q2_forward_update<false, true><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, exa);
+        }
         else
-            kh_q2_forward_update<false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
+            kh_q2_forward_update<false, false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_COOP && !stepwise) {
         if (e->coop_cols == 4)
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 4>(e, p, u, ex, st) : launch_coop_update<16, 4>(e, p, u, ex, st);
@@ -643,6 +668,7 @@ static KhUpdateArgs update_args(kh_engine *e, const kh_cdouble *chi_store, const
     u.n_begin = 0;
     u.n_end = e->nt - 1;
     u.internal_exchange = 1;
+    u.adj_sign = e->adj_sign;
     return u;
 }
 
