@@ -36,6 +36,7 @@ struct KhQ2Lds {
     cplx *p0;    // [8][512]
     cplx (*buf)[KH_TILE_N];  // [2][64]
     cplx *chib;  // [64] chi(t_{n+1}) for the adjoint-side partial sums
+    cplx *sbuf;  // [64] the vector s of kh_q2_expm_action
     double *red; // [2][8 waves][2]
     double *D;   // [2][2]
     double2 *inv2;  // [KH_MAX_DEGREE/2] {1/(2p+1), 1/((2p+1)(2p+2))} (LDS: no SMEM loads in the phase loop)
@@ -43,7 +44,7 @@ struct KhQ2Lds {
 };
 
 __host__ __device__ inline size_t kh_q2_lds_bytes() {
-    return (size_t)2 * KH_Q2_TILE_ELEMS * sizeof(cplx) + 3 * KH_TILE_N * sizeof(cplx) + (2 * 8 * 2 + 4) * sizeof(double) +
+    return (size_t)2 * KH_Q2_TILE_ELEMS * sizeof(cplx) + 4 * KH_TILE_N * sizeof(cplx) + (2 * 8 * 2 + 4) * sizeof(double) +
            (KH_MAX_DEGREE / 2) * sizeof(double2) + (KH_MAX_DEGREE + 2) * sizeof(double);
 }
 
@@ -53,7 +54,8 @@ __device__ __forceinline__ KhQ2Lds kh_q2_carve(char *smem) {
     s.p0 = s.h0 + KH_Q2_TILE_ELEMS;
     s.buf = (cplx(*)[KH_TILE_N])(s.p0 + KH_Q2_TILE_ELEMS);
     s.chib = (cplx *)(s.buf + 2);
-    s.red = (double *)(s.chib + KH_TILE_N);
+    s.sbuf = s.chib + KH_TILE_N;
+    s.red = (double *)(s.sbuf + KH_TILE_N);
     s.D = s.red + 2 * 8 * 2;
     s.inv2 = (double2 *)(s.D + 4);
     s.deg = (double *)(s.inv2 + KH_MAX_DEGREE / 2);
@@ -96,18 +98,20 @@ __device__ __forceinline__ void kh_q2_build(const KhQ2Lds &s, int tid, double ep
 // buf[cur] holds the state; on exit buf[cur] holds the new state.  f*f is real
 // (-1 in Hilbert space, +1 for Liouvillians): c2 = f^2 h^2 / (j1 j2).
 //
-// Only the B half (t_{2p+2}, the next phase's input) is reduced across lanes
-// every phase.  The odd terms t_{2p+1} = c1 A t_{2p} only enter the state sum,
-// and the sum over phases commutes with the sum over lanes: each lane keeps
-// its unreduced  sA = sum_p c1_p (A t_2p)|lane  and reduces it ONCE per
-// interval.  Order within a phase: B FMAs -> reduce -> write (what phase p+1
-// waits for), then the A FMAs under the LDS write latency, then the barrier.
+// The even terms are a chain of products with B = A^2:  t_{2p+2} = c2_p B t_{2p}.
+// The odd terms  t_{2p+1} = f h/(2p+1) A t_{2p}  only enter the state sum, and A is
+// linear:  sum_p t_{2p+1} = f A s  with  s = sum_p h/(2p+1) t_{2p}.  So each lane
+// accumulates its row of s while the even terms go by (two FMAs per phase), the
+// phase that produces the last input t_{2(P-1)} also writes s to LDS, and the
+// LAST phase does the one A product (on s) next to its B product: P + 1
+// matrix-vector products per step instead of 2 P, on the same critical path of
+// P phases.  (With m = 14: 8 products instead of 14.)
 // `epilogue()` runs once, when the new state is complete in `state` and before the last barrier: work that
 // depends on the new state and must be visible after that barrier rides on it instead of a barrier of its own.
 // Returns the number of matrix-vector products issued.
 template <class Epilogue>
 __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx (&b)[8], cplx &state,
-                                                 cplx (*buf)[KH_TILE_N], const double2 *inv2, int &cur,
+                                                 cplx (*buf)[KH_TILE_N], cplx *sbuf, const double2 *inv2, int &cur,
                                                  cplx *store_in, int N, double fre, double fim,
                                                  double dt, int nsub, int m, int wave, int lane,
                                                  Epilogue epilogue) {
@@ -122,12 +126,14 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
         store_in[lane] = buf[cur][lane];
     }
     for (int sub = 0; sub < nsub; ++sub) {
-        // this lane's share of sum_p h/(2p+1) A t_2p: the odd-term sum without its factor f
-        cplx sA = c_make(0.0, 0.0);
+        // this row of s = sum_p h/(2p+1) t_2p (t_0 = the incoming state)
+        cplx sacc = c_make(h * state.x, h * state.y);
+        if (phases == 1) {  // (degree <= 2) s = h t_0 is final already: one extra barrier in this rare case
+            if (writer) sbuf[row] = sacc;
+            __syncthreads();
+        }
         for (int ph = 0; ph < phases; ++ph) {
-            const double2 iv = inv2[ph];  // {1/(2p+1), 1/((2p+1)(2p+2))}
-            const double hj1 = h * iv.x;
-            const double c2 = f2h2 * iv.y;
+            const double c2 = f2h2 * inv2[ph].y;  // inv2[p] = {1/(2p+1), 1/((2p+1)(2p+2))}
             cplx xv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[j] = buf[cur][cg + 8 * j];
@@ -138,14 +144,24 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
             const double t2x = KhQ2Lanes::rowsum(yb.x, c2), t2y = KhQ2Lanes::rowsum(yb.y, c2);
             state.x += t2x;
             state.y += t2y;
-            if (!last && writer) buf[cur ^ 1][row] = c_make(t2x, t2y);
-            cplx ya = c_make(0.0, 0.0);
+            if (!last) {
+                const double hn = h * inv2[ph + 1].x;
+                sacc.x = fma(hn, t2x, sacc.x);
+                sacc.y = fma(hn, t2y, sacc.y);
+                if (writer) {
+                    buf[cur ^ 1][row] = c_make(t2x, t2y);
+                    if (ph + 2 == phases) sbuf[row] = sacc;  // s is complete: next phase multiplies it by A
+                }
+            } else {
+                // (the B product is finished before s is fetched: both vectors at once do not fit next to the tiles)
+                __builtin_amdgcn_sched_barrier(0);
+                cplx sv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) c_fma(ya, a[j], xv[j]);
-            sA.x = fma(hj1, ya.x, sA.x);
-            sA.y = fma(hj1, ya.y, sA.y);
-            if (last) {
-                const cplx odd = c_mul(c_make(fre, fim), c_make(KhQ2Lanes::rowsum(sA.x, 1.0), KhQ2Lanes::rowsum(sA.y, 1.0)));
+                for (int j = 0; j < 8; ++j) sv[j] = sbuf[cg + 8 * j];
+                cplx ya = c_make(0.0, 0.0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c_fma(ya, a[j], sv[j]);
+                const cplx odd = c_mul(c_make(fre, fim), c_make(KhQ2Lanes::rowsum(ya.x, 1.0), KhQ2Lanes::rowsum(ya.y, 1.0)));
                 state.x += odd.x;
                 state.y += odd.y;
                 if (writer) buf[cur ^ 1][row] = c_make(state.x, state.y);
@@ -155,7 +171,7 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
             cur ^= 1;
         }
     }
-    return nsub * phases * 2;
+    return nsub * (phases + 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -211,7 +227,7 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
             kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
             cplx *store_in =
                 store == nullptr ? nullptr : store + ((size_t)k * nt + (direction > 0 ? n : n + 1)) * N;
-            matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, store_in, N, p.fre, p.fim, dt, nsub, m,
+            matvecs += kh_q2_expm_action(a, b, state, s.buf, s.sbuf, s.inv2, cur, store_in, N, p.fre, p.fim, dt, nsub, m,
                                          wave, lane, [] {});
         }
         if (store != nullptr && wave == 0 && lane < N)
@@ -415,7 +431,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         if constexpr (SO) fw_out = u.fw_store + ((size_t)k * nt + n) * N;
         if constexpr (ADJ) {
             if (n + 2 < nt - 1) load_chi(n + 2);  // lands during the phases; goes to LDS in the epilogue
-            matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
+            matvecs += kh_q2_expm_action(a, b, state, s.buf, s.sbuf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
                                          lane, [&] {
                                              if (n + 1 < nt - 1) {
                                                  cplx ov = c_make(0.0, 0.0);
@@ -427,7 +443,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
                                              }
                                          });
         } else {
-            matvecs += kh_q2_expm_action(a, b, state, s.buf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
+            matvecs += kh_q2_expm_action(a, b, state, s.buf, s.sbuf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
                                          lane, [] {});
         }
 #ifdef KH_TIMING
