@@ -274,7 +274,10 @@ def main():
                          if eng.kernel == 'coop16/mfma' else
                          'fp64 vector-FMA bound (complex matrix-vector products cannot use MFMA tiles); the fp64 '
                          'vector peak equals the fp64 MFMA peak on MI355X (78.6 TFLOP/s). ') +
-                        'Algorithmic flops: K*(nt-1)*(8 N^2 * 14 [+ L*(8 N^2 + 8 N) for the update sweep]).',
+                        'Algorithmic (credited) flops: K*(nt-1)*(8 N^2 * 14 [+ L*(8 N^2 + 8 N) for the update sweep]), '
+                        'SURVEY.md 8d, whatever was issued: the q2 kernels evaluate the same degree-14 polynomial '
+                        'with 8 matrix-vector products per step (A^2 chain + one A product by linearity); see '
+                        'kernels.matvecs_issued_last_update_sweep for the executed count.',
                 'launch_ms': t_dom * 1e3,
             },
             'kernels': {
@@ -287,6 +290,7 @@ def main():
                 'hbm_frac_of_8TBs': max(b_bw / t_bw, b_up / t_up) / 1e9 / HBM_PEAK_GBS,
                 'matvecs_issued_last_update_sweep': stats['matvecs'],
                 'matvecs_credited_per_sweep': K_loc * (args.nt - 1) * (TAYLOR_DEGREE + args.L),
+                'update_executed_tflops': stats['matvecs'] * 8.0 * args.N * args.N / t_up / 1e12,
             },
             'final_J_T_re': float(1 - np.mean(np.array(res.tau_vals[-1]).real)),
         }
