@@ -46,6 +46,8 @@ struct KhCoopArgs {
                               // workgroups, each fetching a narrower block per term with fewer loads
     int ks;                   // k-steps (of 4 columns) per wave: 32 * ks >= N
     int first_poll_delay;     // s_sleep units (64 cycles) before a round's first fetch
+    const cplx *const *sq;    // one control only: P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 of this direction's
+                              // operators (A^2 = P0 + eps P1 + eps^2 P2), or NULL: term-by-term series
 };
 
 struct KhCoopLds {
@@ -339,6 +341,63 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
     return true;
 }
 
+// The same with the square of the generator as the chain operator (one control: A^2 = P0 + eps P1 +
+// eps^2 P2 with three fixed matrices staged by kh_engine_create).  The even terms are a chain of products
+// with B = A^2, t_{2p+2} = f^2 h^2 / ((2p+1)(2p+2)) B t_{2p}; the odd terms only enter the state sum and A is
+// linear, sum_p t_{2p+1} = f A s with s = sum_p h/(2p+1) t_{2p}: every owner accumulates its element of s
+// while the even terms go by, the last B round publishes s instead of a term, and ONE round with the A
+// fragment finishes the step.  ceil(m/2) + 1 rounds (each one cross-workgroup exchange) instead of m; the
+// fragment in LDS is rebuilt twice per step (B, then A) from L2.
+template <int MAXKS, int COLS>
+__device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, const KhExchange &ex,
+                                                       const cplx *const *ops, double eps, const KhCoopFrag &a,
+                                                       cplx &state, unsigned int &rid, KhCoopLds &s, int N, int y,
+                                                       int rowbase, int row, int col, bool owner_valid, double fre,
+                                                       double fim, double dt, int nsub, int m, int tid, int wave,
+                                                       int lane) {
+    const double h = nsub == 1 ? dt : dt / nsub;
+    const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
+    const int phases = (m + 1) >> 1;
+    const double eps1[1] = {eps};
+    for (int sub = 0; sub < nsub; ++sub) {
+        kh_coop_load_frag<MAXKS>(c.sq[0], N, rowbase, wave, lane, c.ks, a);
+        kh_coop_axpy_frag<MAXKS>(c.sq[1], eps, N, rowbase, wave, lane, c.ks, a);
+        kh_coop_axpy_frag<MAXKS>(c.sq[2], eps * eps, N, rowbase, wave, lane, c.ks, a);
+        cplx sacc = c_make(h * state.x, h * state.y);
+        for (int ph = 0; ph < phases; ++ph) {
+            cplx w;
+            kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+            if (s.abort) return false;
+            if (tid < 16 * COLS) {
+                const double c2 = f2h2 * kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2];
+                const cplx t2 = c_make(c2 * w.x, c2 * w.y);
+                state.x += t2.x;
+                state.y += t2.y;
+                const bool last = (ph + 1 == phases);
+                if (!last) {
+                    const double hn = h * kh_inv_table[2 * ph + 3];
+                    sacc.x = fma(hn, t2.x, sacc.x);
+                    sacc.y = fma(hn, t2.y, sacc.y);
+                }
+                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, last ? sacc : t2);
+            }
+            ++rid;
+        }
+        kh_coop_build<MAXKS>(ops, eps1, 1, N, rowbase, wave, lane, c.ks, a);
+        cplx w;
+        kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+        if (s.abort) return false;
+        if (tid < 16 * COLS) {
+            const cplx odd = c_mul(c_make(fre, fim), w);
+            state.x += odd.x;
+            state.y += odd.y;
+            if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, state);
+        }
+        ++rid;
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // plain propagation with storage (backward sweep / iteration-0 forward sweep)
 // ---------------------------------------------------------------------------
@@ -384,11 +443,18 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
         int nsub, m;
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
-        kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
-        if (!kh_coop_expm_action<MAXKS, COLS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt, nsub,
-                                        m, tid, wave, lane))
-            return;
-        rounds += (double)nsub * m;
+        if (c.sq != nullptr) {
+            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, p.ops, eps[0], a, state, rid, s, N, y, rowbase, row, col,
+                                                     owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
+                return;
+            rounds += (double)nsub * (((m + 1) >> 1) + 1);
+        } else {
+            kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
+            if (!kh_coop_expm_action<MAXKS, COLS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt,
+                                                  nsub, m, tid, wave, lane))
+                return;
+            rounds += (double)nsub * m;
+        }
         if (has_state && store != nullptr) store[((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N + row] = state;
     }
     if (has_state && state_out != nullptr) state_out[(size_t)k * N + row] = state;
@@ -492,11 +558,18 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
         int nsub, m;
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
-        kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
-        if (!kh_coop_expm_action<MAXKS, COLS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt, nsub,
-                                        m, tid, wave, lane))
-            return;
-        rounds += (double)nsub * m;
+        if (c.sq != nullptr) {
+            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, p.ops, eps[0], a, state, rid, s, N, y, rowbase, row, col,
+                                                     owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
+                return;
+            rounds += (double)nsub * (((m + 1) >> 1) + 1);
+        } else {
+            kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
+            if (!kh_coop_expm_action<MAXKS, COLS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt,
+                                                  nsub, m, tid, wave, lane))
+                return;
+            rounds += (double)nsub * m;
+        }
     }
     if (has_state) {
         u.phi[(size_t)k * N + row] = state;

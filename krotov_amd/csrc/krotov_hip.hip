@@ -347,8 +347,10 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     if (e->kind == KIND_GENERIC && csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 &&
         !(force && strcmp(force, "generic") == 0))
         e->kind_store = KIND_TILE_RPT1;
-    if (e->kind == KIND_TILE_Q2) {
+    const bool coop_sq = e->kind == KIND_COOP && e->L == 1 && !(getenv("KH_COOP_NOSQ") && atoi(getenv("KH_COOP_NOSQ")));
+    if (e->kind == KIND_TILE_Q2 || coop_sq) {
         // stage P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 once per distinct operator (pair)
+        const unsigned pgrid = (unsigned)(((size_t)e->N * e->N + 255) / 256 < 16 ? 16 : ((size_t)e->N * e->N + 255) / 256);
         const size_t bytes = sizeof(cplx) * (size_t)e->N * e->N;
         for (int dir = 0; dir < 2; ++dir) {
             const std::vector<const cplx *> &tab = dir == 0 ? fw : bw;
@@ -362,7 +364,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                     cplx *dst = nullptr;
                     KH_HIP_E(hipMalloc(&dst, bytes));
                     e->owned.push_back(dst);
-                    kh_q2_product<<<16, 256>>>(H0, H0, dst, e->N, 0);
+                    kh_q2_product<<<pgrid, 256>>>(H0, H0, dst, e->N, 0);
                     it0 = p0_of.emplace(H0, dst).first;
                 }
                 sq[(size_t)k * 3] = it0->second;
@@ -372,7 +374,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                     cplx *dst = nullptr;
                     KH_HIP_E(hipMalloc(&dst, bytes));
                     e->owned.push_back(dst);
-                    kh_q2_product<<<16, 256>>>(H1, H1, dst, e->N, 0);
+                    kh_q2_product<<<pgrid, 256>>>(H1, H1, dst, e->N, 0);
                     it2 = p2_of.emplace(H1, dst).first;
                 }
                 sq[(size_t)k * 3 + 2] = it2->second;
@@ -382,7 +384,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                     cplx *dst = nullptr;
                     KH_HIP_E(hipMalloc(&dst, bytes));
                     e->owned.push_back(dst);
-                    kh_q2_product<<<16, 256>>>(H0, H1, dst, e->N, 1);
+                    kh_q2_product<<<pgrid, 256>>>(H0, H1, dst, e->N, 1);
                     it1 = p1_of.emplace(key, dst).first;
                 }
                 sq[(size_t)k * 3 + 1] = it1->second;
@@ -392,6 +394,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             KH_HIP_E(hipMalloc((void **)slot, sizeof(cplx *) * sq.size()));
             KH_HIP_E(hipMemcpy((void *)*slot, sq.data(), sizeof(cplx *) * sq.size(), hipMemcpyHostToDevice));
         }
+    }
+    if (e->kind == KIND_TILE_Q2) {
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kh_q2_lds_bytes()));
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false, false>,
@@ -485,8 +489,9 @@ static int dispatch_tile_store(kh_engine *e, const KhSweepArgs &p, const double 
 
 static KhExchange exchange_args(const kh_engine *e, bool internal_exchange);
 
-static KhCoopArgs coop_args(const kh_engine *e) {
+static KhCoopArgs coop_args(const kh_engine *e, bool backward) {
     KhCoopArgs c;
+    c.sq = backward ? e->d_sq_bw : e->d_sq_fw;  // (NULL unless staged: one control)
     c.vbuf = e->d_coop_vbuf;
     c.epoch_base = 0;  // the buffer is cleared before every launch
     c.G = e->coop_G;
@@ -504,7 +509,7 @@ static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *p
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     kh_coop_sweep_store<MAXKS, COLS><<<dim3(e->coop_G, e->coop_Y), KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(
-        p, coop_args(e), exchange_args(e, true), pulses, in, store, out, direction);
+        p, coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
     return KH_OK;
 }
 
@@ -518,9 +523,9 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     const dim3 grid(e->coop_G, e->coop_Y);
     if (u.sigma != nullptr)
-        kh_coop_forward_update<MAXKS, COLS, true><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e), u, ex);
+        kh_coop_forward_update<MAXKS, COLS, true><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e, false), u, ex);
     else
-        kh_coop_forward_update<MAXKS, COLS, false><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e), u, ex);
+        kh_coop_forward_update<MAXKS, COLS, false><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e, false), u, ex);
     return KH_OK;
 }
 

@@ -118,6 +118,35 @@ def test_kernel_families_agree(name, kernel, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize('name', ['c1', 'c2l', 'c3', 'c5_n64', 'c5_n33'])
+def test_q2_update_forward_side_partial_sums(name, monkeypatch):
+    """The q2 update sweep normally takes <chi|H phi> on the adjoint side when the control operators are
+    +/- their own adjoints (Hermitian H_l: sign +1; commutator super-operators, c2l: sign -1).  KH_NO_ADJ=1
+    keeps the forward-side kernel (the one non-Hermitian controls get): same results."""
+    spec = SMALL[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.37)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    results = []
+    for no_adj in ('0', '1'):
+        monkeypatch.setenv('KH_NO_ADJ', no_adj)
+        eng = _engine(spec)
+        assert eng.kernel == 'tile64q2/512'
+        opt, psi_T, g_a = eng.forward_update(ref_chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+        eng.check()
+        assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * scale
+        assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+        assert np.abs(g_a.cpu().numpy() - ref_ga).max() < 1e-12 * max(1.0, np.abs(ref_ga).max())
+        results.append(opt.cpu().numpy())
+        eng.close()
+    assert np.abs(results[0] - results[1]).max() < 1e-13 * scale
+
+
 SECOND_ORDER_CASES = [
     ('c3', None), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
     ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c2l', None),
