@@ -46,8 +46,9 @@ struct KhCoopArgs {
                               // workgroups, each fetching a narrower block per term with fewer loads
     int ks;                   // k-steps (of 4 columns) per wave: 32 * ks >= N
     int first_poll_delay;     // s_sleep units (64 cycles) before a round's first fetch
+    const cplx *const *fops;  // [1 + L] this direction's (shared) operators in fragment order
     const cplx *const *sq;    // one control only: P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 of this direction's
-                              // operators (A^2 = P0 + eps P1 + eps^2 P2), or NULL: term-by-term series
+                              // operators (A^2 = P0 + eps P1 + eps^2 P2) in fragment order, or NULL: term-by-term series
 };
 
 struct KhCoopLds {
@@ -74,17 +75,35 @@ struct KhCoopFrag {
     __device__ __forceinline__ double &im(int q) const { return f[(size_t)(2 * q + 1) * KH_COOP_THREADS]; }
 };
 
-// rows rowbase + (lane & 15), columns (wave ks + q) 4 + (lane >> 4): the MFMA A-operand layout
+// Operators are re-laid out once, at engine creation, in "fragment order": the element that lane `lane` of
+// wave `wave` of row block g holds for k-step q -- row 16 g + (lane & 15), column (wave ks + q) 4 + (lane >> 4),
+// the MFMA A-operand layout -- sits at [((g WAVES + wave) ks + q) 64 + lane], zero beyond N.  A fragment
+// (re)build then reads 1 KiB per wave-level load, fully coalesced, without bounds checks; from the row-major
+// matrix the same load touched 16 half-used lines (measured: 4.2 -> see DESIGN.md us per table per interval).
+__global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, int N, int G, int ks) {
+    const size_t total = (size_t)G * KH_COOP_WAVES * ks * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const size_t t = idx >> 6;
+        const int q = (int)(t % ks), wave = (int)((t / ks) % KH_COOP_WAVES), g = (int)(t / ks / KH_COOP_WAVES);
+        const int row = g * 16 + (lane & 15), col = (wave * ks + q) * 4 + (lane >> 4);
+        out[idx] = (row < N && col < N) ? in[(size_t)row * N + col] : c_make(0.0, 0.0);
+    }
+}
+
+// this lane's elements of row block g of a fragment-ordered operator (NULL: zero operator)
+__device__ __forceinline__ const cplx *kh_coop_frag_src(const cplx *op, int g, int wave, int lane, int ks) {
+    return op == nullptr ? nullptr : op + ((size_t)(g * KH_COOP_WAVES + wave) * ks) * 64 + lane;
+}
+
 template <int MAXKS>
-__device__ __forceinline__ void kh_coop_load_frag(const cplx *op, int N, int rowbase, int wave, int lane, int ks,
+__device__ __forceinline__ void kh_coop_load_frag(const cplx *op, int g, int wave, int lane, int ks,
                                                   const KhCoopFrag &f) {
-    const int row = rowbase + (lane & 15);
+    const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
         if (q < ks) {
-            const int col = (wave * ks + q) * 4 + (lane >> 4);
-            cplx v = c_make(0.0, 0.0);
-            if (op != nullptr && row < N && col < N) v = op[(size_t)row * N + col];
+            const cplx v = src != nullptr ? src[(size_t)q * 64] : c_make(0.0, 0.0);
             f.re(q) = v.x;
             f.im(q) = v.y;
         }
@@ -93,14 +112,14 @@ __device__ __forceinline__ void kh_coop_load_frag(const cplx *op, int N, int row
 
 // a += eps * op  (same fragment layout)
 template <int MAXKS>
-__device__ __forceinline__ void kh_coop_axpy_frag(const cplx *op, double eps, int N, int rowbase, int wave, int lane,
-                                                  int ks, const KhCoopFrag &a) {
-    const int row = rowbase + (lane & 15);
+__device__ __forceinline__ void kh_coop_axpy_frag(const cplx *op, double eps, int g, int wave, int lane, int ks,
+                                                  const KhCoopFrag &a) {
+    const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
+    if (src == nullptr) return;
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
-        const int col = (wave * ks + q) * 4 + (lane >> 4);
-        if (q < ks && op != nullptr && row < N && col < N) {
-            const cplx v = op[(size_t)row * N + col];
+        if (q < ks) {
+            const cplx v = src[(size_t)q * 64];
             a.re(q) = fma(eps, v.x, a.re(q));
             a.im(q) = fma(eps, v.y, a.im(q));
         }
@@ -303,14 +322,14 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
     __syncthreads();  // part[] is free for the next round
 }
 
-// A = op_0 + sum_l eps_l op_l (fragments rebuilt from L2 once per interval: 2 (1+L) 16 N elements)
+// A = op_0 + sum_l eps_l op_l (fragments rebuilt from L2 once per interval; ops: fragment-ordered copies)
 template <int MAXKS>
-__device__ __forceinline__ void kh_coop_build(const cplx *const *ops, const double *eps, int L, int N, int rowbase,
-                                              int wave, int lane, int ks, const KhCoopFrag &a) {
-    kh_coop_load_frag<MAXKS>(ops[0], N, rowbase, wave, lane, ks, a);
+__device__ __forceinline__ void kh_coop_build(const cplx *const *ops, const double *eps, int L, int g, int wave,
+                                              int lane, int ks, const KhCoopFrag &a) {
+    kh_coop_load_frag<MAXKS>(ops[0], g, wave, lane, ks, a);
 #pragma unroll
     for (int l = 0; l < KH_COOP_MAX_L; ++l)
-        if (l < L) kh_coop_axpy_frag<MAXKS>(ops[1 + l], eps[l], N, rowbase, wave, lane, ks, a);
+        if (l < L) kh_coop_axpy_frag<MAXKS>(ops[1 + l], eps[l], g, wave, lane, ks, a);
 }
 
 // state <- exp(f A dt) state, term by term; round `rid` holds the state on entry and on exit.
@@ -350,9 +369,9 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
 // fragment in LDS is rebuilt twice per step (B, then A) from L2.
 template <int MAXKS, int COLS>
 __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, const KhExchange &ex,
-                                                       const cplx *const *ops, double eps, const KhCoopFrag &a,
+                                                       double eps, const KhCoopFrag &a,
                                                        cplx &state, unsigned int &rid, KhCoopLds &s, int N, int y,
-                                                       int rowbase, int row, int col, bool owner_valid, double fre,
+                                                       int g, int row, int col, bool owner_valid, double fre,
                                                        double fim, double dt, int nsub, int m, int tid, int wave,
                                                        int lane) {
     const double h = nsub == 1 ? dt : dt / nsub;
@@ -360,9 +379,9 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
     const int phases = (m + 1) >> 1;
     const double eps1[1] = {eps};
     for (int sub = 0; sub < nsub; ++sub) {
-        kh_coop_load_frag<MAXKS>(c.sq[0], N, rowbase, wave, lane, c.ks, a);
-        kh_coop_axpy_frag<MAXKS>(c.sq[1], eps, N, rowbase, wave, lane, c.ks, a);
-        kh_coop_axpy_frag<MAXKS>(c.sq[2], eps * eps, N, rowbase, wave, lane, c.ks, a);
+        kh_coop_load_frag<MAXKS>(c.sq[0], g, wave, lane, c.ks, a);
+        kh_coop_axpy_frag<MAXKS>(c.sq[1], eps, g, wave, lane, c.ks, a);
+        kh_coop_axpy_frag<MAXKS>(c.sq[2], eps * eps, g, wave, lane, c.ks, a);
         cplx sacc = c_make(h * state.x, h * state.y);
         for (int ph = 0; ph < phases; ++ph) {
             cplx w;
@@ -383,7 +402,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             }
             ++rid;
         }
-        kh_coop_build<MAXKS>(ops, eps1, 1, N, rowbase, wave, lane, c.ks, a);
+        kh_coop_build<MAXKS>(c.fops, eps1, 1, g, wave, lane, c.ks, a);
         cplx w;
         kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
         if (s.abort) return false;
@@ -444,12 +463,12 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         if (c.sq != nullptr) {
-            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, p.ops, eps[0], a, state, rid, s, N, y, rowbase, row, col,
+            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, eps[0], a, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
                 return;
             rounds += (double)nsub * (((m + 1) >> 1) + 1);
         } else {
-            kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
+            kh_coop_build<MAXKS>(c.fops, eps, L, g, wave, lane, c.ks, a);
             if (!kh_coop_expm_action<MAXKS, COLS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt,
                                                   nsub, m, tid, wave, lane))
                 return;
@@ -513,7 +532,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
 #pragma unroll
         for (int l = 0; l < KH_COOP_MAX_L; ++l) {
             if (l >= L) break;
-            kh_coop_load_frag<MAXKS>(p.ops[1 + l], N, rowbase, wave, lane, c.ks, a);
+            kh_coop_load_frag<MAXKS>(c.fops[1 + l], g, wave, lane, c.ks, a);
             cplx w;
             kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
             if (wave < 4) {  // (lanes that own no element contribute zeros: chi_norm, bra, w are 0 there)
@@ -559,12 +578,12 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         if (c.sq != nullptr) {
-            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, p.ops, eps[0], a, state, rid, s, N, y, rowbase, row, col,
+            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, eps[0], a, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
                 return;
             rounds += (double)nsub * (((m + 1) >> 1) + 1);
         } else {
-            kh_coop_build<MAXKS>(p.ops, eps, L, N, rowbase, wave, lane, c.ks, a);
+            kh_coop_build<MAXKS>(c.fops, eps, L, g, wave, lane, c.ks, a);
             if (!kh_coop_expm_action<MAXKS, COLS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt,
                                                   nsub, m, tid, wave, lane))
                 return;

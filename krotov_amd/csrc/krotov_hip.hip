@@ -64,6 +64,8 @@ struct kh_engine {
     double *d_deg_theta = nullptr;    // [KH_MAX_DEGREE+1] degree thresholds for tol
     KhCsr *d_csr_fw = nullptr;        // [K*(1+L)] sparse operators (kh_engine_create_csr), else NULL
     KhCsr *d_csr_bw = nullptr;        // [K*(1+L)] their conjugate transposes
+    const cplx **d_coop_fops_fw = nullptr, **d_coop_fops_bw = nullptr;  // [1+L] fragment-ordered operator copies
+    const cplx **d_coop_sq_fw = nullptr, **d_coop_sq_bw = nullptr;      // [3] the same for P0, P1, P2 (one control)
     const cplx **d_sq_fw = nullptr;   // [K*3] P0, P1, P2 of A^2 (q2 kernels), forward operators
     const cplx **d_sq_bw = nullptr;   // [K*3] the same for the adjoint operators
     std::vector<void *> owned;        // adjoint operator copies
@@ -157,6 +159,10 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_deg_theta);
     (void)hipFree(e->d_csr_fw);
     (void)hipFree(e->d_csr_bw);
+    (void)hipFree((void *)e->d_coop_fops_fw);
+    (void)hipFree((void *)e->d_coop_fops_bw);
+    (void)hipFree((void *)e->d_coop_sq_fw);
+    (void)hipFree((void *)e->d_coop_sq_bw);
     (void)hipFree((void *)e->d_sq_fw);
     (void)hipFree((void *)e->d_sq_bw);
     (void)hipFree(e->d_phi);
@@ -395,6 +401,43 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             KH_HIP_E(hipMemcpy((void *)*slot, sq.data(), sizeof(cplx *) * sq.size(), hipMemcpyHostToDevice));
         }
     }
+    if (e->kind == KIND_COOP) {
+        // fragment-ordered copies of the (shared) operators and, for one control, of P0, P1, P2 (kh_coop.h)
+        const size_t elems = (size_t)e->coop_G * KH_COOP_WAVES * e->coop_ks * 64;
+        std::map<const void *, const cplx *> perm_of;
+        auto permuted = [&](const cplx *src, const cplx **out) -> hipError_t {
+            *out = nullptr;
+            if (src == nullptr) return hipSuccess;
+            auto it = perm_of.find(src);
+            if (it == perm_of.end()) {
+                cplx *dst = nullptr;
+                const hipError_t err = hipMalloc(&dst, sizeof(cplx) * elems);
+                if (err != hipSuccess) return err;
+                e->owned.push_back(dst);
+                kh_coop_permute_kernel<<<(unsigned)((elems + 255) / 256), 256>>>(src, dst, e->N, e->coop_G, e->coop_ks);
+                it = perm_of.emplace(src, dst).first;
+            }
+            *out = it->second;
+            return hipSuccess;
+        };
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::vector<const cplx *> &tab = dir == 0 ? fw : bw;
+            std::vector<const cplx *> fops(1 + e->L, nullptr), sq3(3, nullptr);
+            for (int o = 0; o <= e->L; ++o) KH_HIP_E(permuted(tab[o], &fops[o]));
+            const cplx ***slot = dir == 0 ? &e->d_coop_fops_fw : &e->d_coop_fops_bw;
+            KH_HIP_E(hipMalloc((void **)slot, sizeof(cplx *) * fops.size()));
+            KH_HIP_E(hipMemcpy((void *)*slot, fops.data(), sizeof(cplx *) * fops.size(), hipMemcpyHostToDevice));
+            if (coop_sq) {
+                std::vector<const cplx *> nat(3, nullptr);
+                KH_HIP_E(hipMemcpy(nat.data(), dir == 0 ? e->d_sq_fw : e->d_sq_bw, sizeof(cplx *) * 3, hipMemcpyDeviceToHost));
+                for (int i = 0; i < 3; ++i) KH_HIP_E(permuted(nat[i], &sq3[i]));
+                const cplx ***sslot = dir == 0 ? &e->d_coop_sq_fw : &e->d_coop_sq_bw;
+                KH_HIP_E(hipMalloc((void **)sslot, sizeof(cplx *) * 3));
+                KH_HIP_E(hipMemcpy((void *)*sslot, sq3.data(), sizeof(cplx *) * 3, hipMemcpyHostToDevice));
+            }
+        }
+        KH_HIP_E(hipGetLastError());
+    }
     if (e->kind == KIND_TILE_Q2) {
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kh_q2_lds_bytes()));
@@ -491,7 +534,8 @@ static KhExchange exchange_args(const kh_engine *e, bool internal_exchange);
 
 static KhCoopArgs coop_args(const kh_engine *e, bool backward) {
     KhCoopArgs c;
-    c.sq = backward ? e->d_sq_bw : e->d_sq_fw;  // (NULL unless staged: one control)
+    c.fops = backward ? e->d_coop_fops_bw : e->d_coop_fops_fw;
+    c.sq = backward ? e->d_coop_sq_bw : e->d_coop_sq_fw;  // (NULL unless staged: one control)
     c.vbuf = e->d_coop_vbuf;
     c.epoch_base = 0;  // the buffer is cleared before every launch
     c.G = e->coop_G;
