@@ -132,6 +132,116 @@ __host__ inline void kh_build_degree_table(double tol, double *tab /*[KH_MAX_DEG
     }
 }
 
+// ---------------------------------------------------------------------------
+// Series coefficients for the two-terms-per-phase kernels (kh_tile64q2.h)
+// ---------------------------------------------------------------------------
+// Those kernels evaluate  sum_j c_j (f h A)^j v  with real c_j through the chain of even terms
+//   T_0 = c_0 v,  T_{2p+2} = r2_p f^2 h^2 A^2 T_{2p}   and   sum_odd = f A sum_p r1_p h T_{2p},
+// so all they need per degree m is c_0 and the rows {r1_p, r2_p}: r1_0 = c_1, r2_0 = c_2 (taken relative to v,
+// not to T_0), r1_p = c_{2p+1}/c_{2p}, r2_p = c_{2p+2}/c_{2p} for p >= 1.
+//   * Taylor (any generator): c_j = 1/j!, thresholds from kh_build_degree_table.
+//   * Generators with a REAL spectrum (every operator Hermitian bit for bit, f = -+i): the truncated Chebyshev
+//     series of exp(-+i theta x) on [-1, 1], rewritten in powers of (-+i theta x).  Its error 2 sum_{k>m}
+//     |J_k(theta)| ~ 2 (theta/2)^(m+1)/(m+1)! is 2^m times smaller than Taylor's remainder: theta = 0.5 needs
+//     degree 12 instead of 14 (6 phases instead of 7), theta = 1 needs 14 instead of 18.  The coefficients of
+//     degree m are computed for theta_b = tab[m], the largest theta the degree serves, and are valid for
+//     every spectrum inside [-theta_b, theta_b].  Only even degrees, theta_b <= 2 (beyond that the power
+//     basis loses digits; the kernels sub-step at theta_max <= 1 anyway).
+#define KH_Q2_ROWS (KH_MAX_DEGREE / 2)
+
+__host__ inline void kh_build_taylor_rows(double *c0 /*[KH_MAX_DEGREE+1]*/, double *rows /*[KH_MAX_DEGREE+1][KH_Q2_ROWS][2]*/) {
+    for (int m = 0; m <= KH_MAX_DEGREE; ++m) {
+        c0[m] = 1.0;
+        for (int p = 0; p < KH_Q2_ROWS; ++p) {
+            rows[((size_t)m * KH_Q2_ROWS + p) * 2 + 0] = 1.0 / (2 * p + 1);
+            rows[((size_t)m * KH_Q2_ROWS + p) * 2 + 1] = 1.0 / ((2.0 * p + 1) * (2 * p + 2));
+        }
+    }
+}
+
+// J_k(theta), k = 0..kmax, by Miller's downward recurrence J_{k-1} = (2k/theta) J_k - J_{k+1}, normalised
+// with J_0 + 2 sum_k J_{2k} = 1 (theta > 0; stable in this direction)
+__host__ inline void kh_bessel_j(double theta, int kmax, long double *J) {
+    const int start = kmax + 40 + (int)(2.0 * theta);
+    long double jp = 0.0L, jc = 1e-300L, norm = 0.0L;
+    for (int k = start; k >= 1; --k) {
+        const long double jm = (2.0L * k / (long double)theta) * jc - jp;  // J_{k-1}
+        jp = jc;
+        jc = jm;
+        if (k - 1 <= kmax) J[k - 1] = jc;
+        if (((k - 1) & 1) == 0) norm += (k - 1 == 0 ? 1.0L : 2.0L) * jc;
+        if (fabsl(jc) > 1e200L) {  // rescale (everything stored so far too)
+            jc *= 1e-200L;
+            jp *= 1e-200L;
+            norm *= 1e-200L;
+            for (int q = k - 1; q <= kmax; ++q) J[q] *= 1e-200L;
+        }
+    }
+    for (int k = 0; k <= kmax; ++k) J[k] /= norm;
+}
+
+// tab[m]: largest theta <= 2 the degree-m Chebyshev truncation serves at `tol` (even m; odd m repeat m-1 so
+// that the smallest-degree search never lands on them); c0, rows as above
+__host__ inline void kh_build_real_spectrum_rows(double tol, double *tab /*[KH_MAX_DEGREE+1]*/, double *c0, double *rows) {
+    const int TAIL = 40;
+    long double J[KH_MAX_DEGREE + TAIL + 2];
+    auto err = [&](double theta, int m) {
+        kh_bessel_j(theta, m + TAIL, J);
+        long double e = 0.0L;
+        for (int k = m + 1; k <= m + TAIL; ++k) e += fabsl(J[k]);
+        return (double)(2.0L * e);
+    };
+    kh_build_taylor_rows(c0, rows);  // (rows of the degrees that stay with Taylor)
+    double taylor_tab[KH_MAX_DEGREE + 1];
+    kh_build_degree_table(tol, taylor_tab);
+    tab[0] = 0.0;
+    for (int m = 1; m <= KH_MAX_DEGREE; ++m) {
+        if (m & 1) {
+            tab[m] = tab[m - 1];
+            continue;
+        }
+        if (taylor_tab[m] >= 2.0) {  // beyond the cap of the Chebyshev form: plain Taylor (rows already there)
+            tab[m] = taylor_tab[m] > tab[m - 1] ? taylor_tab[m] : tab[m - 1];
+            continue;
+        }
+        double lo = 0.0, hi = 2.0;
+        if (err(hi, m) <= tol) {
+            lo = hi;
+        } else {
+            for (int it = 0; it < 60; ++it) {
+                const double th = 0.5 * (lo + hi);
+                if (err(th, m) <= tol) lo = th; else hi = th;
+            }
+        }
+        if (lo < tab[m - 1]) lo = tab[m - 1];
+        tab[m] = lo;
+        const double theta = lo;
+        if (!(theta > 0.0)) continue;
+        // power coefficients of T_k by the recurrence T_{k+1} = 2 x T_k - T_{k-1}
+        static long double T[KH_MAX_DEGREE + 1][KH_MAX_DEGREE + 1];
+        for (int k = 0; k <= m; ++k)
+            for (int j = 0; j <= m; ++j) T[k][j] = 0.0L;
+        T[0][0] = 1.0L;
+        if (m >= 1) T[1][1] = 1.0L;
+        for (int k = 1; k < m; ++k)
+            for (int j = 0; j <= k + 1; ++j) T[k + 1][j] = (j > 0 ? 2.0L * T[k][j - 1] : 0.0L) - T[k - 1][j];
+        kh_bessel_j(theta, m, J);
+        long double c[KH_MAX_DEGREE + 1];
+        for (int j = 0; j <= m; ++j) {
+            long double acc = 0.0L;
+            for (int k = j; k <= m; k += 2)  // (+-i)^k x^j = (+-i)^j (-1)^((k-j)/2) x^j
+                acc += (k == 0 ? 1.0L : 2.0L) * J[k] * T[k][j] * (((k - j) / 2) % 2 ? -1.0L : 1.0L);
+            c[j] = acc / powl((long double)theta, j);
+        }
+        c0[m] = (double)c[0];
+        for (int p = 0; 2 * p + 2 <= m && p < KH_Q2_ROWS; ++p) {
+            const long double den = p == 0 ? 1.0L : c[2 * p];
+            rows[((size_t)m * KH_Q2_ROWS + p) * 2 + 0] = (double)(c[2 * p + 1] / den);
+            rows[((size_t)m * KH_Q2_ROWS + p) * 2 + 1] = (double)(c[2 * p + 2] / den);
+        }
+    }
+}
+
 // Per-thread cache of the bracket [tab[m-1], tab[m]] of the current degree: along
 // a smooth pulse the degree rarely changes, and the table reads (LDS, ~100
 // cycles each, dependent) would otherwise sit on every interval's critical path.

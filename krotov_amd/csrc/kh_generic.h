@@ -28,6 +28,10 @@ struct KhSweepArgs {
     double fre, fim;          // equation-of-motion factor f (propagators.py:94-99)
     double tol, theta_max, inv_theta_max;
     const double *deg_theta;  // [KH_MAX_DEGREE+1] largest theta per Taylor degree (kh_build_degree_table)
+    // q2 kernels only: their own degree thresholds and series coefficients (kh_common.h, "Series coefficients")
+    const double *q2_theta;   // [KH_MAX_DEGREE+1]
+    const double *q2_c0;      // [KH_MAX_DEGREE+1]
+    const double *q2_rows;    // [KH_MAX_DEGREE+1][KH_Q2_ROWS][2]
     double *stats;            // [0] += matvecs issued (per objective, summed)
 };
 
@@ -444,11 +448,14 @@ __global__ void kh_fro_norms(const cplx *const *ops, int count, int N, double *n
 }
 
 // flags[0] (flags[1]) is raised when some control operator (index i with i % Lp1 != 0) differs from
-// plus (minus) its staged adjoint in any bit: decides KhUpdateArgs::adj_sign at engine creation
+// plus (minus) its staged adjoint in any bit: decides KhUpdateArgs::adj_sign at engine creation;
+// flags[2] when some drift operator (i % Lp1 == 0) differs from its adjoint (flags[0] == flags[2] == 0: every
+// generator H0 + sum eps_l H_l is Hermitian, its spectrum real)
 __global__ void kh_adjoint_sign_kernel(const cplx *const *__restrict__ ops, const cplx *const *__restrict__ ops_adj,
                                        int nops, int Lp1, int N, int *__restrict__ flags) {
     for (int i = blockIdx.x; i < nops; i += gridDim.x) {
-        if (i % Lp1 == 0 || ops[i] == nullptr) continue;
+        if (ops[i] == nullptr) continue;
+        const bool drift = i % Lp1 == 0;
         const cplx *a = ops[i], *b = ops_adj[i];
         bool plus_bad = false, minus_bad = false;
         for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
@@ -456,8 +463,12 @@ __global__ void kh_adjoint_sign_kernel(const cplx *const *__restrict__ ops, cons
             plus_bad = plus_bad || x.x != y.x || x.y != y.y;
             minus_bad = minus_bad || x.x != -y.x || x.y != -y.y;
         }
-        if (plus_bad) flags[0] = 1;
-        if (minus_bad) flags[1] = 1;
+        if (drift) {
+            if (plus_bad) flags[2] = 1;
+        } else {
+            if (plus_bad) flags[0] = 1;
+            if (minus_bad) flags[1] = 1;
+        }
     }
 }
 

@@ -39,13 +39,14 @@ struct KhQ2Lds {
     cplx *sbuf;  // [64] the vector s of kh_q2_expm_action
     double *red; // [2][8 waves][2]
     double *D;   // [2][2]
-    double2 *inv2;  // [KH_MAX_DEGREE/2] {1/(2p+1), 1/((2p+1)(2p+2))} (LDS: no SMEM loads in the phase loop)
+    double2 *inv2;  // [KH_Q2_ROWS] the series' rows {r1_p, r2_p} of the current degree (Taylor: {1/(2p+1),
+                    // 1/((2p+1)(2p+2))}); LDS: no SMEM loads in the phase loop.  [KH_Q2_ROWS]: c_0 (in .x)
     double *deg;    // [KH_MAX_DEGREE+1] copy of the degree-threshold table
 };
 
 __host__ __device__ inline size_t kh_q2_lds_bytes() {
     return (size_t)2 * KH_Q2_TILE_ELEMS * sizeof(cplx) + 4 * KH_TILE_N * sizeof(cplx) + (2 * 8 * 2 + 4) * sizeof(double) +
-           (KH_MAX_DEGREE / 2) * sizeof(double2) + (KH_MAX_DEGREE + 2) * sizeof(double);
+           (KH_MAX_DEGREE / 2 + 1) * sizeof(double2) + (KH_MAX_DEGREE + 2) * sizeof(double);
 }
 
 __device__ __forceinline__ KhQ2Lds kh_q2_carve(char *smem) {
@@ -58,7 +59,7 @@ __device__ __forceinline__ KhQ2Lds kh_q2_carve(char *smem) {
     s.red = (double *)(s.sbuf + KH_TILE_N);
     s.D = s.red + 2 * 8 * 2;
     s.inv2 = (double2 *)(s.D + 4);
-    s.deg = (double *)(s.inv2 + KH_MAX_DEGREE / 2);
+    s.deg = (double *)(s.inv2 + KH_MAX_DEGREE / 2 + 1);
     return s;
 }
 
@@ -77,6 +78,17 @@ __device__ __forceinline__ void kh_q2_stage_tile(const cplx *op, int N, int wave
     kh_q2_load_tile(op, N, wave, lane, t);
 #pragma unroll
     for (int j = 0; j < 8; ++j) dst[j * KH_Q2_THREADS + tid] = t[j];
+}
+
+// the series' rows of degree m -> LDS (workgroup-uniform m; called between intervals, contains a barrier)
+__device__ __forceinline__ void kh_q2_load_rows(const KhSweepArgs &p, const KhQ2Lds &s, int m, int tid) {
+    __syncthreads();  // (no phase is still reading the previous rows)
+    if (tid < KH_Q2_ROWS) {
+        const double *r = p.q2_rows + ((size_t)m * KH_Q2_ROWS + tid) * 2;
+        s.inv2[tid] = make_double2(r[0], r[1]);
+    }
+    if (tid == KH_Q2_ROWS) s.inv2[KH_Q2_ROWS] = make_double2(p.q2_c0[m], 0.0);
+    __syncthreads();
 }
 
 // A = H0 + eps H1,  B = P0 + eps P1 + eps^2 P2  (H0, P0 from LDS)
@@ -126,14 +138,16 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
         store_in[lane] = buf[cur][lane];
     }
     for (int sub = 0; sub < nsub; ++sub) {
-        // this row of s = sum_p h/(2p+1) t_2p (t_0 = the incoming state)
-        cplx sacc = c_make(h * state.x, h * state.y);
+        // this row of s = sum_p r1_p h T_2p (T_0 = c_0 v, r1_0 relative to the incoming state v; Taylor: 1/(2p+1))
+        const double hr = h * inv2[0].x, c0 = inv2[KH_Q2_ROWS].x;
+        cplx sacc = c_make(hr * state.x, hr * state.y);
+        state = c_make(c0 * state.x, c0 * state.y);
         if (phases == 1) {  // (degree <= 2) s = h t_0 is final already: one extra barrier in this rare case
             if (writer) sbuf[row] = sacc;
             __syncthreads();
         }
         for (int ph = 0; ph < phases; ++ph) {
-            const double c2 = f2h2 * inv2[ph].y;  // inv2[p] = {1/(2p+1), 1/((2p+1)(2p+2))}
+            const double c2 = f2h2 * inv2[ph].y;  // inv2[p] = {r1_p, r2_p}
             cplx xv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[j] = buf[cur][cg + 8 * j];
@@ -185,8 +199,7 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KhQ2Lds s = kh_q2_carve(smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / ((2.0 * tid + 1) * (2 * tid + 2)));
-    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.q2_theta[tid];
     const int row = wave * 8 + KhQ2Lanes::row_out(lane);  // the row whose sums/state this lane holds
     const bool writer = (lane & 7) == 0;
     const int N = p.N, nt = p.nt;
@@ -213,6 +226,7 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
         const int n0 = direction > 0 ? 0 : nt - 2;
         double eps_next = pulses[n0], dt_next = p.dt[n0];
         KhDegreeCache dc = {12, 1.0, 0.0};
+        int m_rows = -1;
         for (int step = 0; step < nt - 1; ++step) {
             const int n = direction > 0 ? step : nt - 2 - step;
             const double eps = eps_next, dt = dt_next;
@@ -223,6 +237,10 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
             }
             int nsub, m;
             kh_degree_cached((nrm0 + fabs(eps) * nrm1) * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
+            if (m != m_rows) {  // (rare along a smooth pulse)
+                kh_q2_load_rows(p, s, m, tid);
+                m_rows = m;
+            }
             cplx a[8], b[8];
             kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
             cplx *store_in =
@@ -261,8 +279,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     double(*red)[8][2] = (double(*)[8][2])s.red;  // [parity][wave][re, im]
     double(*D_sh)[2] = (double(*)[2])s.D;         // [parity][value, ok]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = KhQ2Lanes::cg(lane);
-    if (tid < KH_MAX_DEGREE / 2) s.inv2[tid] = make_double2(1.0 / (2 * tid + 1), 1.0 / ((2.0 * tid + 1) * (2 * tid + 2)));
-    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.q2_theta[tid];
     const int row = wave * 8 + KhQ2Lanes::row_out(lane);  // the row whose sums/state/co-state this lane holds
     // one wave of each SIMD's pair (wave 0, which runs the exchange, among them) issues first when both are
     // ready: the pair's latency gaps interleave instead of coinciding (measured -1.7 % on the update sweep)
@@ -364,6 +381,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     double dt_next = kh_uniform(p.dt[u.n_begin]), guess_next = kh_uniform(u.guess[u.n_begin]),
            shape_next = kh_uniform(u.shape[u.n_begin]);
     const double lam = kh_uniform(u.lambda[0]);
+    int m_rows = -1;
     // S/lambda of the coming interval is formed one interval ahead: the fp64 division (~25 dependent
     // instructions) otherwise sits between the exchange and the rebuild of the tiles
     double stepw_next = kh_uniform(shape_next / lam);
@@ -428,6 +446,10 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         // ---- propagate over interval n with the updated pulse (optimize.py:479-491) ----
         int nsub, m;
         kh_degree_cached((nrm0 + fabs(eps) * nrm1) * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
+        if (m != m_rows) {  // (rare along a smooth pulse)
+            kh_q2_load_rows(p, s, m, tid);
+            m_rows = m;
+        }
         cplx a[8], b[8];
         kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
         stepw_next = kh_uniform(shape_next / lam);  // (under the LDS latency of the tile reads)

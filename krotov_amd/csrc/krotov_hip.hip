@@ -96,6 +96,8 @@ struct kh_engine {
     int adj_poll_delay = 0;    // KH_ADJ_DELAY: the same where a matrix-vector product already sits between store and poll
     int coop_poll_delay = 12;  // KH_COOP_DELAY: the same for the cooperative kernels' block exchange
     double adj_sign = 0.0;  // +1 / -1: every control operator equals +/- its adjoint exactly (else 0)
+    bool real_spectrum = false;  // every operator Hermitian (bit for bit) and f = -+i
+    double *d_q2_theta = nullptr, *d_q2_c0 = nullptr, *d_q2_rows = nullptr;  // series tables of the q2 kernels
     long long timeout_ticks = 100000000LL;  // KH_TIMEOUT_MS: bound on any in-kernel wait (100 MHz ticks; 1 s)
 };
 
@@ -145,6 +147,9 @@ static KhSweepArgs sweep_args(const kh_engine *e, bool backward) {
     p.theta_max = e->theta_max;
     p.inv_theta_max = 1.0 / e->theta_max;
     p.deg_theta = e->d_deg_theta;
+    p.q2_theta = e->d_q2_theta;
+    p.q2_c0 = e->d_q2_c0;
+    p.q2_rows = e->d_q2_rows;
     p.stats = e->d_stats;
     return p;
 }
@@ -157,6 +162,9 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_norms);
     (void)hipFree(e->d_dt);
     (void)hipFree(e->d_deg_theta);
+    (void)hipFree(e->d_q2_theta);
+    (void)hipFree(e->d_q2_c0);
+    (void)hipFree(e->d_q2_rows);
     (void)hipFree(e->d_csr_fw);
     (void)hipFree(e->d_csr_bw);
     (void)hipFree((void *)e->d_coop_fops_fw);
@@ -249,7 +257,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     KH_HIP_E(hipMemcpy((void *)e->d_ops_fw, fw.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
     KH_HIP_E(hipMemcpy((void *)e->d_ops_bw, bw.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
     if (csr_fw == nullptr && e->L >= 1) {  // is every control operator its own (negative) adjoint, bit for bit?
-        int *d_flags = nullptr, flags[2] = {1, 1};
+        int *d_flags = nullptr, flags[3] = {1, 1, 1};
         KH_HIP_E(hipMalloc(&d_flags, sizeof(flags)));
         hipError_t err = hipMemset(d_flags, 0, sizeof(flags));
         if (err == hipSuccess) {
@@ -260,6 +268,10 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         (void)hipFree(d_flags);
         KH_HIP_E(err);
         e->adj_sign = flags[0] == 0 ? 1.0 : (flags[1] == 0 ? -1.0 : 0.0);
+        // every generator Hermitian and f = -+i: real spectrum (the q2 kernels' shorter series, kh_common.h)
+        e->real_spectrum = flags[0] == 0 && flags[2] == 0 && !e->is_super;
+        if (const char *d = getenv("KH_TAYLOR"))  // A/B switch: plain Taylor coefficients everywhere
+            if (atoi(d) != 0) e->real_spectrum = false;
         if (const char *d = getenv("KH_NO_ADJ"))  // A/B switch: keep <chi|H phi> on the forward side
             if (atoi(d) != 0) e->adj_sign = 0.0;
     }
@@ -437,6 +449,21 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             }
         }
         KH_HIP_E(hipGetLastError());
+    }
+    if (e->kind == KIND_TILE_Q2 || e->kind_store == KIND_TILE_Q2) {
+        std::vector<double> tab(KH_MAX_DEGREE + 1), c0(KH_MAX_DEGREE + 1), rows((size_t)(KH_MAX_DEGREE + 1) * KH_Q2_ROWS * 2);
+        if (e->real_spectrum) {
+            kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data());
+        } else {
+            kh_build_degree_table(e->tol, tab.data());
+            kh_build_taylor_rows(c0.data(), rows.data());
+        }
+        KH_HIP_E(hipMalloc(&e->d_q2_theta, sizeof(double) * tab.size()));
+        KH_HIP_E(hipMalloc(&e->d_q2_c0, sizeof(double) * c0.size()));
+        KH_HIP_E(hipMalloc(&e->d_q2_rows, sizeof(double) * rows.size()));
+        KH_HIP_E(hipMemcpy(e->d_q2_theta, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+        KH_HIP_E(hipMemcpy(e->d_q2_c0, c0.data(), sizeof(double) * c0.size(), hipMemcpyHostToDevice));
+        KH_HIP_E(hipMemcpy(e->d_q2_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
     }
     if (e->kind == KIND_TILE_Q2) {
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -147,6 +147,38 @@ def test_q2_update_forward_side_partial_sums(name, monkeypatch):
     assert np.abs(results[0] - results[1]).max() < 1e-13 * scale
 
 
+@pytest.mark.parametrize('name', ['c1', 'c3', 'c5_n64', 'c5_n33'])
+def test_q2_real_spectrum_series_vs_taylor(name, monkeypatch):
+    """Hermitian generators (real spectrum) get the truncated-Chebyshev coefficients in the q2 kernels (two
+    degrees fewer at the same tolerance); KH_TAYLOR=1 keeps plain Taylor coefficients.  Both match the oracle
+    and each other; the shorter series issues fewer products."""
+    spec = SMALL[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.37)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    out, issued = [], []
+    for taylor in ('0', '1'):
+        monkeypatch.setenv('KH_TAYLOR', taylor)
+        eng = _engine(spec)
+        assert eng.kernel == 'tile64q2/512'
+        chi = eng.backward(chi_T, pulses)
+        assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-12
+        opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+        eng.check()
+        assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * scale
+        assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+        out.append(opt.cpu().numpy())
+        issued.append(eng.stats()['matvecs'])
+        eng.close()
+    assert np.abs(out[0] - out[1]).max() < 1e-13 * scale
+    assert issued[0] <= issued[1]
+
+
 SECOND_ORDER_CASES = [
     ('c3', None), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
     ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c2l', None),
