@@ -149,9 +149,16 @@ __host__ inline void kh_build_degree_table(double tol, double *tab /*[KH_MAX_DEG
 //     basis loses digits; the kernels sub-step at theta_max <= 1 anyway).
 #define KH_Q2_ROWS (KH_MAX_DEGREE / 2)
 
-__host__ inline void kh_build_taylor_rows(double *c0 /*[KH_MAX_DEGREE+1]*/, double *rows /*[KH_MAX_DEGREE+1][KH_Q2_ROWS][2]*/) {
+// The one-term-per-phase kernels (kh_tile64.h) use the same series term by term: T_j = ratio_j (f h A) T_{j-1},
+// ratios[m][0] = c_0, ratios[m][1] = c_1 (relative to v), ratios[m][j] = c_j / c_{j-1}  (Taylor: 1, 1, 1/j).
+#define KH_RATIO_STRIDE (KH_MAX_DEGREE + 1)
+
+__host__ inline void kh_build_taylor_rows(double *c0 /*[KH_MAX_DEGREE+1]*/, double *rows /*[KH_MAX_DEGREE+1][KH_Q2_ROWS][2]*/,
+                                          double *ratios /*[KH_MAX_DEGREE+1][KH_RATIO_STRIDE]*/) {
     for (int m = 0; m <= KH_MAX_DEGREE; ++m) {
         c0[m] = 1.0;
+        ratios[(size_t)m * KH_RATIO_STRIDE] = 1.0;
+        for (int j = 1; j <= KH_MAX_DEGREE; ++j) ratios[(size_t)m * KH_RATIO_STRIDE + j] = 1.0 / j;
         for (int p = 0; p < KH_Q2_ROWS; ++p) {
             rows[((size_t)m * KH_Q2_ROWS + p) * 2 + 0] = 1.0 / (2 * p + 1);
             rows[((size_t)m * KH_Q2_ROWS + p) * 2 + 1] = 1.0 / ((2.0 * p + 1) * (2 * p + 2));
@@ -182,7 +189,8 @@ __host__ inline void kh_bessel_j(double theta, int kmax, long double *J) {
 
 // tab[m]: largest theta <= 2 the degree-m Chebyshev truncation serves at `tol` (even m; odd m repeat m-1 so
 // that the smallest-degree search never lands on them); c0, rows as above
-__host__ inline void kh_build_real_spectrum_rows(double tol, double *tab /*[KH_MAX_DEGREE+1]*/, double *c0, double *rows) {
+__host__ inline void kh_build_real_spectrum_rows(double tol, double *tab /*[KH_MAX_DEGREE+1]*/, double *c0, double *rows,
+                                                 double *ratios) {
     const int TAIL = 40;
     long double J[KH_MAX_DEGREE + TAIL + 2];
     auto err = [&](double theta, int m) {
@@ -191,7 +199,7 @@ __host__ inline void kh_build_real_spectrum_rows(double tol, double *tab /*[KH_M
         for (int k = m + 1; k <= m + TAIL; ++k) e += fabsl(J[k]);
         return (double)(2.0L * e);
     };
-    kh_build_taylor_rows(c0, rows);  // (rows of the degrees that stay with Taylor)
+    kh_build_taylor_rows(c0, rows, ratios);  // (rows of the degrees that stay with Taylor)
     double taylor_tab[KH_MAX_DEGREE + 1];
     kh_build_degree_table(tol, taylor_tab);
     tab[0] = 0.0;
@@ -234,6 +242,8 @@ __host__ inline void kh_build_real_spectrum_rows(double tol, double *tab /*[KH_M
             c[j] = acc / powl((long double)theta, j);
         }
         c0[m] = (double)c[0];
+        ratios[(size_t)m * KH_RATIO_STRIDE] = (double)c[0];
+        for (int j = 1; j <= m; ++j) ratios[(size_t)m * KH_RATIO_STRIDE + j] = (double)(j == 1 ? c[1] : c[j] / c[j - 1]);
         for (int p = 0; 2 * p + 2 <= m && p < KH_Q2_ROWS; ++p) {
             const long double den = p == 0 ? 1.0L : c[2 * p];
             rows[((size_t)m * KH_Q2_ROWS + p) * 2 + 0] = (double)(c[2 * p + 1] / den);

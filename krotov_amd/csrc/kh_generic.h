@@ -28,10 +28,12 @@ struct KhSweepArgs {
     double fre, fim;          // equation-of-motion factor f (propagators.py:94-99)
     double tol, theta_max, inv_theta_max;
     const double *deg_theta;  // [KH_MAX_DEGREE+1] largest theta per Taylor degree (kh_build_degree_table)
-    // q2 kernels only: their own degree thresholds and series coefficients (kh_common.h, "Series coefficients")
+    // register-tile kernels only: their own degree thresholds and series coefficients (kh_common.h, "Series
+    // coefficients"): Taylor, or the shorter real-spectrum series when every operator is Hermitian
     const double *q2_theta;   // [KH_MAX_DEGREE+1]
     const double *q2_c0;      // [KH_MAX_DEGREE+1]
-    const double *q2_rows;    // [KH_MAX_DEGREE+1][KH_Q2_ROWS][2]
+    const double *q2_rows;    // [KH_MAX_DEGREE+1][KH_Q2_ROWS][2]   (two-terms-per-phase kernels)
+    const double *ratios;     // [KH_MAX_DEGREE+1][KH_RATIO_STRIDE]  (one-term-per-phase kernels)
     double *stats;            // [0] += matvecs issued (per objective, summed)
 };
 

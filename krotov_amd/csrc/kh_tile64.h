@@ -121,8 +121,11 @@ __device__ __forceinline__ int kh_tile_expm_action(const cplx (&a)[RPT][8], cplx
     const bool writer = KhTile<RPT>::writer(lane);
     const double h = nsub == 1 ? dt : dt / nsub;
     for (int sub = 0; sub < nsub; ++sub) {
+        const double c0 = inv[0];  // T_0 = c_0 v (1 for Taylor); ratio 1 is relative to v itself
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) state[r] = c_make(c0 * state[r].x, c0 * state[r].y);
         for (int j = 1; j <= m; ++j) {
-            const double hj = h * inv[j];  // LDS copy: an SMEM load here would drain lgkmcnt every term
+            const double hj = h * inv[j];  // series ratio of term j (Taylor: 1/j); LDS: no SMEM loads in the loop
             const cplx coef = c_make(fre * hj, fim * hj);
             cplx y[RPT];
             kh_tile_matvec<RPT>(a, buf[cur], cg, y);
@@ -217,6 +220,13 @@ struct KhTileLds {
 
 extern __shared__ __attribute__((aligned(16))) cplx kh_tile_dyn_lds[];
 
+// the series' ratios of degree m -> LDS (workgroup-uniform m; between intervals; contains barriers)
+__device__ __forceinline__ void kh_tile_load_ratios(const KhSweepArgs &p, double *inv_sh, int m, int tid) {
+    __syncthreads();  // (no phase is still reading the previous ratios)
+    if (tid <= KH_MAX_DEGREE) inv_sh[tid] = p.ratios[(size_t)m * KH_RATIO_STRIDE + tid];
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------
 // plain propagation with storage (backward sweep / iteration-0 forward sweep)
 // ---------------------------------------------------------------------------
@@ -230,8 +240,7 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool writer = KhTile<RPT>::writer(lane);
     if (tid <= KH_MAX_DEGREE) {
-        inv_sh[tid] = tid ? 1.0 / tid : 0.0;
-        deg_sh[tid] = p.deg_theta[tid];
+        deg_sh[tid] = p.q2_theta[tid];
     }
     const int N = p.N, nt = p.nt;
     double matvecs = 0.0;
@@ -285,6 +294,7 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
             }
             int nsub, m;
             kh_degree_lookup(theta * dt, deg_sh, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
+            if (m != m_hint || step == 0) kh_tile_load_ratios(p, inv_sh, m, tid);  // (workgroup-uniform, rare)
             m_hint = m;
             cplx a[RPT][8];
             h.build(eps, a);
@@ -322,8 +332,7 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cg = KhTileLanes::cg(lane);
     const bool writer = KhTile<RPT>::writer(lane);
     if (tid <= KH_MAX_DEGREE) {
-        inv_sh[tid] = tid ? 1.0 / tid : 0.0;
-        deg_sh[tid] = p.deg_theta[tid];
+        deg_sh[tid] = p.q2_theta[tid];
     }
     const int N = p.N, nt = p.nt;
     const int k = blockIdx.x;
@@ -497,6 +506,7 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         // ---- propagate over interval n with the updated pulse (optimize.py:479-491) ----
         int nsub, m;
         kh_degree_lookup(theta * dt, deg_sh, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
+        if (m != m_hint || n == u.n_begin) kh_tile_load_ratios(p, inv_sh, m, tid);  // (workgroup-uniform, rare)
         m_hint = m;
         cplx a[RPT][8];
         h.build(eps, a);

@@ -97,7 +97,7 @@ struct kh_engine {
     int coop_poll_delay = 12;  // KH_COOP_DELAY: the same for the cooperative kernels' block exchange
     double adj_sign = 0.0;  // +1 / -1: every control operator equals +/- its adjoint exactly (else 0)
     bool real_spectrum = false;  // every operator Hermitian (bit for bit) and f = -+i
-    double *d_q2_theta = nullptr, *d_q2_c0 = nullptr, *d_q2_rows = nullptr;  // series tables of the q2 kernels
+    double *d_q2_theta = nullptr, *d_q2_c0 = nullptr, *d_q2_rows = nullptr, *d_ratios = nullptr;  // series tables of the register-tile kernels
     long long timeout_ticks = 100000000LL;  // KH_TIMEOUT_MS: bound on any in-kernel wait (100 MHz ticks; 1 s)
 };
 
@@ -150,6 +150,7 @@ static KhSweepArgs sweep_args(const kh_engine *e, bool backward) {
     p.q2_theta = e->d_q2_theta;
     p.q2_c0 = e->d_q2_c0;
     p.q2_rows = e->d_q2_rows;
+    p.ratios = e->d_ratios;
     p.stats = e->d_stats;
     return p;
 }
@@ -165,6 +166,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_q2_theta);
     (void)hipFree(e->d_q2_c0);
     (void)hipFree(e->d_q2_rows);
+    (void)hipFree(e->d_ratios);
     (void)hipFree(e->d_csr_fw);
     (void)hipFree(e->d_csr_bw);
     (void)hipFree((void *)e->d_coop_fops_fw);
@@ -450,14 +452,18 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         }
         KH_HIP_E(hipGetLastError());
     }
-    if (e->kind == KIND_TILE_Q2 || e->kind_store == KIND_TILE_Q2) {
-        std::vector<double> tab(KH_MAX_DEGREE + 1), c0(KH_MAX_DEGREE + 1), rows((size_t)(KH_MAX_DEGREE + 1) * KH_Q2_ROWS * 2);
+    auto is_tile = [](int kind) { return kind == KIND_TILE_Q2 || kind == KIND_TILE_RPT1 || kind == KIND_TILE_RPT2; };
+    if (is_tile(e->kind) || is_tile(e->kind_store)) {
+        std::vector<double> tab(KH_MAX_DEGREE + 1), c0(KH_MAX_DEGREE + 1), rows((size_t)(KH_MAX_DEGREE + 1) * KH_Q2_ROWS * 2),
+            ratios((size_t)(KH_MAX_DEGREE + 1) * KH_RATIO_STRIDE);
         if (e->real_spectrum) {
-            kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data());
+            kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data());
         } else {
             kh_build_degree_table(e->tol, tab.data());
-            kh_build_taylor_rows(c0.data(), rows.data());
+            kh_build_taylor_rows(c0.data(), rows.data(), ratios.data());
         }
+        KH_HIP_E(hipMalloc(&e->d_ratios, sizeof(double) * ratios.size()));
+        KH_HIP_E(hipMemcpy(e->d_ratios, ratios.data(), sizeof(double) * ratios.size(), hipMemcpyHostToDevice));
         KH_HIP_E(hipMalloc(&e->d_q2_theta, sizeof(double) * tab.size()));
         KH_HIP_E(hipMalloc(&e->d_q2_c0, sizeof(double) * c0.size()));
         KH_HIP_E(hipMalloc(&e->d_q2_rows, sizeof(double) * rows.size()));
