@@ -227,7 +227,13 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
         double eps_next = pulses[n0], dt_next = p.dt[n0];
         KhDegreeCache dc = {12, 1.0, 0.0};
         int m_rows = -1;
+#ifdef KH_TIMING
+        long long t_build = 0, t_phases = 0;
+#endif
         for (int step = 0; step < nt - 1; ++step) {
+#ifdef KH_TIMING
+            const long long tq0 = clock64();
+#endif
             const int n = direction > 0 ? step : nt - 2 - step;
             const double eps = eps_next, dt = dt_next;
             if (step + 1 < nt - 1) {
@@ -245,9 +251,22 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
             kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
             cplx *store_in =
                 store == nullptr ? nullptr : store + ((size_t)k * nt + (direction > 0 ? n : n + 1)) * N;
+#ifdef KH_TIMING
+            const long long tq1 = clock64();
+            t_build += tq1 - tq0;
+#endif
             matvecs += kh_q2_expm_action(a, b, state, s.buf, s.sbuf, s.inv2, cur, store_in, N, p.fre, p.fim, dt, nsub, m,
                                          wave, lane, [] {});
+#ifdef KH_TIMING
+            t_phases += clock64() - tq1;
+#endif
         }
+#ifdef KH_TIMING
+        if (tid == 0 && k == 0 && p.stats != nullptr) {
+            p.stats[1] = (double)t_build;   // scalars, degree, tile rebuild issue
+            p.stats[2] = (double)t_phases;  // (the rebuild's LDS latency lands here)
+        }
+#endif
         if (store != nullptr && wave == 0 && lane < N)
             store[((size_t)k * nt + (direction > 0 ? nt - 1 : 0)) * N + lane] = s.buf[cur][lane];
         if (state_out != nullptr && wave == 0 && lane < N) state_out[(size_t)k * N + lane] = s.buf[cur][lane];
