@@ -89,7 +89,13 @@ const char *kh_version(void);
 
 /* Create an engine on the current HIP device.  Stages adjoint copies of every
  * distinct operator (the adjoint objectives of optimize.py:263,
- * objectives.py:240-258) and the exchange workspace. */
+ * objectives.py:240-258) and the exchange workspace, and reads the operators
+ * once more to pick its algorithms: operators that equal their own adjoint bit
+ * for bit (Hilbert space) get a shorter series for exp(-i H dt) than the Taylor
+ * series every other generator gets, and control operators that equal +/- their
+ * adjoint let the update sweep take <chi|dH/d eps|phi> on the co-state's side.
+ * Results agree with the general path to rounding; the operator arrays must not
+ * change while the engine lives. */
 int kh_engine_create(const kh_problem *problem, kh_engine **out);
 void kh_engine_destroy(kh_engine *engine);
 
