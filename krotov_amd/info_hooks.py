@@ -5,15 +5,18 @@ Mirrors ``krotov.info_hooks`` (reference src/krotov/info_hooks.py): ``chain``
 layout and text, so that logs of existing scripts look the same (compared
 against the reference's own ``tests/test_krotov/oct.log`` in
 tests/test_host_helpers.py).  An ``info_hook`` receives the keyword arguments
-listed in reference info_hooks.py:59-86.  Host bookkeeping (SURVEY.md 8f,
-rank 4); the reference's ``print_debug_information`` is not provided.
+listed in reference info_hooks.py:59-86; ``print_debug_information``
+(59-291) writes the same report as the reference's, with state sizes and norms
+taken from arrays instead of Qobj internals.  Host bookkeeping (SURVEY.md 8f,
+rank 4).
 """
 import sys
+import time
 import unicodedata
 
 import numpy as np
 
-__all__ = ['chain', 'print_table']
+__all__ = ['chain', 'print_table', 'print_debug_information']
 
 
 def chain(*hooks):
@@ -162,3 +165,74 @@ def print_table(*, J_T, show_g_a_int_per_pulse=False, J_T_prev=None, unicode=Tru
         return J_T_val
 
     return info_hook
+
+
+
+def _range_text(pulse):
+    """'[min, max]' of a pulse (reference info_hooks.py:624-641: real and imaginary ranges if complex)."""
+    pulse = np.asarray(pulse)
+    if np.iscomplexobj(pulse):
+        return '[(r:%.2f, i:%.2f), (r:%.2f, i:%.2f)]' % (
+            pulse.real.min(), pulse.imag.min(), pulse.real.max(), pulse.imag.max())
+    return '[%.2f, %.2f]' % (pulse.min(), pulse.max())
+
+
+def _state_nbytes(state):
+    """Memory of one state: the array's bytes (the reference estimates a Qobj's, info_hooks.py:12-21)."""
+    return np.asarray(state).nbytes
+
+
+def _storage_text(states, mb_per_slot):
+    if states is None:
+        return 'None'
+    first = states[0]
+    return '[%d * %s(%d)] (%.1f MB)' % (len(states), first.__class__.__name__, len(first), len(first) * mb_per_slot)
+
+
+def print_debug_information(*, objectives, adjoint_objectives, backward_states, forward_states, forward_states0,
+                            guess_pulses, optimized_pulses, g_a_integrals, lambda_vals, shape_arrays, fw_states_T,
+                            tlist, tau_vals, start_time, stop_time, iteration, info_vals, shared_data, propagator,
+                            chi_constructor, mu, sigma, iter_start, iter_stop, out=sys.stdout):
+    """``info_hook`` with the full keyword signature (reference info_hooks.py:59-86) that writes a report of the
+    iteration to ``out``: the set-up once (iteration 0), then duration, pulse ranges, the g_a integrals, lambda_a,
+    what is stored of the propagated states, the norms of the final states and the overlaps tau.  Same lines
+    and formats as the reference's (info_hooks.py:172-291); use :func:`functools.partial` to pass ``out``."""
+    w = out.write
+    w('Iteration %d\n' % iteration)
+    if iteration == 0:
+        w('    objectives:\n')
+        for i, obj in enumerate(objectives):
+            w('        %d:%s\n' % (i + 1, obj))
+        w('    adjoint objectives:\n')
+        for i, obj in enumerate(adjoint_objectives):
+            w('        %d:%s\n' % (i + 1, obj))
+        if isinstance(propagator, (list, tuple)):
+            names = [getattr(f, '__name__', f.__class__.__name__) for f in propagator]
+            w('    propagator: (%s)\n' % ', '.join(names))
+        elif hasattr(propagator, '__name__'):
+            w('    propagator: %s\n' % propagator.__name__)
+        for label, fn in (('chi_constructor', chi_constructor), ('mu', mu)):
+            if hasattr(fn, '__name__'):
+                w('    %s: %s\n' % (label, fn.__name__))
+        if sigma is not None:
+            w('    sigma: %s\n' % sigma.__class__.__name__)
+        w('    S(t) (ranges): %s\n' % ', '.join('[%f, %f]' % (np.min(S), np.max(S)) for S in shape_arrays))
+        w('    iter_start: %s\n' % iter_start)
+        w('    iter_stop: %s\n' % iter_stop)
+    w('    duration: %.1f secs (started at %s)\n' % (
+        stop_time - start_time, time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(start_time))))
+    w('    optimized pulses (ranges): %s\n' % ', '.join(_range_text(pulse) for pulse in optimized_pulses))
+    w('    \u222bg\u2090(t)dt: %s\n' % ', '.join('%.2e' % v for v in g_a_integrals))
+    w('    \u03bb\u2090: %s\n' % ', '.join('%.2e' % v for v in lambda_vals))
+    mb_per_slot = 0.0  # (no final states, e.g. skip_initial_forward_propagation)
+    if fw_states_T is not None:
+        mb_per_slot = sum(_state_nbytes(state) for state in fw_states_T) / 1024**2
+    w('    storage (bw, fw, fw0): %s, %s, %s\n' % (
+        _storage_text(backward_states, mb_per_slot), _storage_text(forward_states, mb_per_slot),
+        _storage_text(forward_states0, mb_per_slot)))
+    if fw_states_T is not None:
+        norms = [state.norm() if hasattr(state, 'norm') else np.linalg.norm(np.asarray(state)) for state in fw_states_T]
+        w('    fw_states_T norm: %s\n' % ', '.join('%f' % v for v in norms))
+    if tau_vals is not None and not any(z is None for z in tau_vals):
+        w('    \u03c4: %s\n' % ', '.join('(%.2e:%.2f\u03c0)' % (abs(z), np.angle(z) / np.pi) for z in tau_vals))
+    out.flush()

@@ -367,6 +367,54 @@ def make_print_table_cases():
     print(out.getvalue())
 
 
+def debug_information_cases():
+    """Keyword arguments of three synthetic iterations for ``print_debug_information`` (shared with
+    tests/test_host_helpers.py, which feeds them to krotov_amd's)."""
+    def expm():
+        pass
+
+    def chis_re():
+        pass
+
+    def derivative_wrt_pulse():
+        pass
+
+    base = dict(objectives=['<objective 1>', '<objective 2>'], adjoint_objectives=['<adjoint 1>', '<adjoint 2>'],
+                guess_pulses=[np.zeros(4), np.zeros(4)], lambda_vals=np.array([5.0, 0.25]),
+                shape_arrays=[np.array([0.0, 0.5, 1.0, 0.0]), np.ones(4)], tlist=np.linspace(0, 1, 5),
+                start_time=0.0, info_vals=[], shared_data={}, propagator=expm, chi_constructor=chis_re,
+                mu=derivative_wrt_pulse, sigma=None, iter_start=0, iter_stop=7, fw_states_T=[])
+    bw = [np.zeros((5, 3), dtype=complex), np.zeros((5, 3), dtype=complex)]
+    return [
+        dict(base, iteration=0, backward_states=None, forward_states=None, forward_states0=None,
+             optimized_pulses=[np.array([-1.0, 1.0, 5.0, 0.0]), np.array([0.0, 0.25, 0.5, 0.125])],
+             g_a_integrals=np.zeros(2), tau_vals=np.array([0.5 + 0.5j, -0.25j]), stop_time=1.25),
+        dict(base, iteration=1, backward_states=bw, forward_states=None, forward_states0=None,
+             optimized_pulses=[np.array([-1.5, 1.0, 5.5, 0.0]), np.array([0.0, 0.25 + 1j, 0.5, 0.125 - 2j])],
+             g_a_integrals=np.array([0.0123, 4.5e-6]), tau_vals=np.array([0.9, -0.8 + 0.1j]), stop_time=63.0),
+        dict(base, iteration=2, backward_states=bw, forward_states=bw, forward_states0=bw, propagator=[expm, expm],
+             optimized_pulses=[np.array([-1.5, 1.0, 5.5, 0.0]), np.array([0.0, 0.25, 0.5, 0.125])],
+             g_a_integrals=np.array([1.0, 2.0]), tau_vals=np.array([None, None]), stop_time=0.04),
+    ]
+
+
+def make_print_debug_cases():
+    """Text written by the reference's own ``krotov.info_hooks.print_debug_information`` for the synthetic
+    iterations above -> tests/golden/print_debug_cases.txt.  (Empty list of final states: the reference sizes them through
+    Qobj internals.  The iteration-0 block with a LIST of propagators is not exercised: the reference raises a
+    TypeError there, info_hooks.py:184-188.)"""
+    import io
+
+    krotov = import_reference_krotov()
+    out = io.StringIO()
+    for kw in debug_information_cases():
+        krotov.info_hooks.print_debug_information(out=out, **kw)
+        out.write("--\n")
+    with open(os.path.join(HERE, 'print_debug_cases.txt'), 'w', encoding='utf8') as fh:
+        fh.write(out.getvalue())
+    print(out.getvalue())
+
+
 def make_c5_full():
     """Headline configuration through the real reference loop: 1 iteration
     (~2.5 sweeps * 256 * 4000 props at ~0.8 ms each => ~35 min, one core)."""
@@ -390,6 +438,8 @@ if __name__ == '__main__':
         make_second_order()
     if 'print_table' in what:
         make_print_table_cases()
+    if 'print_debug' in what:
+        make_print_debug_cases()
     for w in what:
         if w in REF_CASES:
             make_ref_fixtures([w])

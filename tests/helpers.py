@@ -138,12 +138,21 @@ def check_infohook_chaining(**optimize_kwargs):
             printed.append("\tmsg: " + message)
             return message
 
+    import io
+
+    report = io.StringIO()
+
+    def debug_information(**args):  # the full-signature hook works on whatever state containers the path hands out
+        krotov_amd.info_hooks.print_debug_information(out=report, **args)
+
     res = krotov_amd.optimize_pulses(
         [obj], pulse_options={H[1][1]: dict(lambda_a=1, update_shape=1)}, tlist=tlist,
         chi_constructor=krotov_amd.functionals.chis_re,
-        info_hook=krotov_amd.info_hooks.chain(print_fidelity, print_messages),
+        info_hook=krotov_amd.info_hooks.chain(print_fidelity, print_messages, debug_information),
         modify_params_after_iter=adjust_lambda_a, iter_stop=2, **optimize_kwargs)
     out = "\n".join(printed)
+    assert report.getvalue().count('    storage (bw, fw, fw0): [1 * ') == 2  # iterations 1 and 2
+    assert '    fw_states_T norm: 1.000000\n' in report.getvalue()
     assert len(res.info_vals) == 3
     assert isinstance(res.info_vals[1], tuple) and len(res.info_vals[1]) == 2
     assert abs(res.info_vals[1][0] - 0.001978333994757067) < 1e-8

@@ -3,6 +3,7 @@
 integration test (tests/test_krotov.py:202-445, ``test_continue_optimization``)
 restated on the plugin path with NumPy plugins, against the reference's own
 log file tests/test_krotov/oct.log (kept as tests/golden/oct.log)."""
+import functools
 import io
 import logging
 import os
@@ -181,6 +182,42 @@ def test_print_table_layout():
     with pytest.raises(ValueError, match="Invalid col_formats"):
         krotov_amd.info_hooks.print_table(J_T=None, col_formats=('%d', '%.2e', '%.2e', '%.2e %d', '%.2e', '%.2e',
                                                                  '%.2e', '%d'))
+
+
+def test_print_debug_information_text():
+    """The full-signature info_hook writes what the reference's print_debug_information writes for the same
+    keyword arguments (tests/golden/print_debug_cases.txt, made by make_reference_goldens.py print_debug; the
+    wall-clock start is masked: it is printed in local time), and runs as info_hook of a real optimization."""
+    import re
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_goldens', os.path.join(GOLDEN, 'make_reference_goldens.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)  # (only defines functions; the reference is imported inside them)
+    out = io.StringIO()
+    for kw in mod.debug_information_cases():
+        krotov_amd.info_hooks.print_debug_information(out=out, **kw)
+        out.write("--\n")
+    mask = lambda text: re.sub(r'started at [0-9: -]+', 'started at X', text)  # noqa: E731
+    want = open(os.path.join(GOLDEN, 'print_debug_cases.txt'), encoding='utf8').read()
+    assert mask(out.getvalue()) == mask(want)
+    # final states given as arrays: sizes and norms come from the arrays
+    kw = dict(mod.debug_information_cases()[1], fw_states_T=[np.array([0.6, 0.8j]), np.array([1.0, 0.0])])
+    out = io.StringIO()
+    krotov_amd.info_hooks.print_debug_information(out=out, **kw)
+    assert '    fw_states_T norm: 1.000000, 1.000000\n' in out.getvalue()
+    assert '[2 * ndarray(5)] (0.0 MB), None, None' in out.getvalue()
+    # as the info_hook of an optimization
+    objectives, pulse_options, tlist = _system()
+    prop, mu, vdot = numpy_plugins()
+    log = io.StringIO()
+    krotov_amd.optimize_pulses(
+        objectives, pulse_options=pulse_options, tlist=tlist, propagator=prop, mu=mu,
+        overlap=lambda a, b: None if a is None or b is None else vdot(a, b), norm=np.linalg.norm,
+        chi_constructor=krotov_amd.functionals.chis_re,
+        info_hook=functools.partial(krotov_amd.info_hooks.print_debug_information, out=log), iter_stop=1)
+    text = log.getvalue()
+    assert text.startswith('Iteration 0\n    objectives:\n') and '\nIteration 1\n' in text
+    assert 'chi_constructor: chis_re' in text and 'storage (bw, fw, fw0): [1 * ' in text
 
 
 @pytest.mark.parametrize('iter_stop', [0, -1])
