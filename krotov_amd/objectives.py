@@ -5,14 +5,15 @@ API-compatible with ``krotov.objectives`` (reference src/krotov/objectives.py:
 ``ensemble_objectives``, 1097-1121 ``liouvillian``) for the parts on or next to
 the hot path.  Operators and states may be QuTiP-like objects (anything with
 ``.full()`` / ``.dag()``) or NumPy arrays; QuTiP itself is never imported, so
-there is no type checking, ``mesolve`` delegation or pretty printing here.
+there is no type checking, ``mesolve`` delegation or pretty printing here;
+``Objective.propagate`` (338-433) runs on the engine's forward sweep.
 """
 import copy
 import itertools
 
 import numpy as np
 
-__all__ = ['Objective', 'gate_objectives', 'ensemble_objectives', 'liouvillian']
+__all__ = ['Objective', 'PropagationResult', 'gate_objectives', 'ensemble_objectives', 'liouvillian']
 
 
 def _shallow_nested(l):
@@ -140,6 +141,58 @@ class Objective:
         adj.__dict__.update(self._extras())
         return adj
 
+    def propagate(self, tlist, *, propagator, rho0=None, H=None, c_ops=None, e_ops=None, args=None, expect=None):
+        """Propagate ``rho0`` (default: ``initial_state``) over the whole time grid with ``propagator`` -- the
+        same piecewise-constant-on-the-intervals convention, the same pulses (controls sampled by
+        :func:`~krotov_amd.conversions.discretize` and :func:`~krotov_amd.conversions.control_onto_interval`)
+        and the same propagator as :func:`~krotov_amd.optimize.optimize_pulses` uses (reference
+        objectives.py:338-433).  With ``krotov_amd.propagators.expm`` / ``HipExpm`` and no ``c_ops`` the whole
+        sweep is ONE launch of the engine's forward sweep with storage (include/krotov_hip.h:
+        ``kh_forward_store``); any other callable is stepped on the host as in the reference.
+
+        Returns a :class:`PropagationResult` (attributes of ``qutip.solver.Result``): ``states`` at every
+        grid point, or -- with ``e_ops`` -- ``expect[i]``, the expectation values of ``e_ops[i]``
+        (``expect(operator, state)``, default <psi|O|psi> for vectors, tr(O rho) for matrices).
+        """
+        from .conversions import (control_onto_interval, discretize, extract_controls, extract_controls_mapping,
+                                  plug_in_pulse_values)
+
+        H = self.H if H is None else H
+        c_ops = self.c_ops if c_ops is None else c_ops
+        e_ops = [] if e_ops is None else e_ops
+        args = {} if args is None else args
+        expect = _expectation_value if expect is None else expect
+        tlist = np.asarray(tlist, dtype=np.float64)
+        state = self.initial_state if rho0 is None else rho0
+        system = Objective(initial_state=state, H=H, target=self.target, c_ops=c_ops)
+        controls = extract_controls([system])
+        mapping = extract_controls_mapping([system], controls)
+        pulses = [control_onto_interval(discretize(control, tlist, args=(args,))) for control in controls]
+        result = PropagationResult()
+        result.solver = getattr(propagator, '__name__', propagator.__class__.__name__)
+        result.times = np.array(tlist)
+        result.num_expect, result.num_collapse = len(e_ops), len(c_ops)
+
+        from .optimize import _HipBackend, _use_device_path  # (imports this module)
+
+        if _use_device_path(propagator, None, None, None, 'array', [system]) and len(tlist) > 1:
+            backend = _HipBackend([system], mapping, tlist, len(controls), propagator)
+            _, trajectories = backend.initial_forward(pulses, store=True)
+            states = list(trajectories[0])
+            backend.engine.close()
+        else:
+            states = [state]
+            for n in range(len(tlist) - 1):
+                H_n = plug_in_pulse_values(H, pulses, mapping[0][0], n)
+                c_ops_n = [plug_in_pulse_values(c, pulses, mapping[0][1 + i], n) for i, c in enumerate(c_ops)]
+                state = propagator(H_n, state, tlist[n + 1] - tlist[n], c_ops_n, initialize=True)
+                states.append(state)
+        if len(e_ops) == 0:
+            result.states = states
+        else:
+            result.expect = [np.array([expect(oper, st) for st in states]) for oper in e_ops]
+        return result
+
     def __repr__(self):
         return "Objective(initial_state=%r, target=%r, H=<%d terms>, c_ops=<%d>)" % (
             type(self.initial_state).__name__,
@@ -147,6 +200,31 @@ class Objective:
             len(self.H) if isinstance(self.H, list) else 1,
             len(self.c_ops),
         )
+
+
+class PropagationResult:
+    """What :meth:`Objective.propagate` returns: the attributes of ``qutip.solver.Result`` that the reference
+    fills (objectives.py:384-433)."""
+
+    def __init__(self):
+        self.solver = 'n/a'
+        self.times = np.array([])
+        self.states = []
+        self.expect = []
+        self.num_expect = 0
+        self.num_collapse = 0
+
+
+def _expectation_value(oper, state):
+    """<psi|O|psi> for a state vector, tr(O rho) for a density matrix; real for Hermitian ``oper``."""
+    O = np.asarray(oper.full() if hasattr(oper, 'full') else oper, dtype=complex)
+    psi = np.asarray(state.full() if hasattr(state, 'full') else state, dtype=complex)
+    if psi.ndim == 2 and psi.shape[0] == psi.shape[1] and psi.shape[0] > 1:
+        val = np.trace(O @ psi)
+    else:
+        vec = psi.reshape(-1)
+        val = np.vdot(vec, O @ vec)
+    return val.real if np.array_equal(O, O.conj().T) else val
 
 
 # ---------------------------------------------------------------------------

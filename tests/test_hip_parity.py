@@ -179,6 +179,43 @@ def test_q2_real_spectrum_series_vs_taylor(name, monkeypatch):
     assert issued[0] <= issued[1]
 
 
+def test_objective_propagate_on_device():
+    """Objective.propagate with the GPU propagator = ONE forward sweep with storage; same states and expectation
+    values as the host loop over a NumPy propagator (Hilbert space and a Liouvillian acting on a density matrix)."""
+    import krotov_amd
+    from helpers import numpy_plugins
+    prop, _, _ = numpy_plugins()
+    rng = np.random.default_rng(5)
+    N = 6
+    G = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    H0 = (G + G.conj().T) / 4
+    G = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    H1 = (G + G.conj().T) / 8
+    eps = lambda t, args: 0.7 * np.sin(3 * t) + 0.2  # noqa: E731
+    psi0 = np.zeros(N, dtype=complex)
+    psi0[0] = 1.0
+    tlist = np.linspace(0, 4, 201)
+    obj = krotov_amd.Objective(initial_state=psi0, target=psi0, H=[H0, [H1, eps]])
+    host = obj.propagate(tlist, propagator=prop)
+    dev = obj.propagate(tlist, propagator=krotov_amd.propagators.expm)
+    assert dev.solver == 'expm' and len(dev.states) == len(tlist)
+    assert max(np.abs(np.asarray(a) - b).max() for a, b in zip(dev.states, host.states)) < 1e-12
+    P0 = np.zeros((N, N), dtype=complex)
+    P0[0, 0] = 1.0
+    dev_e = obj.propagate(tlist, propagator=krotov_amd.propagators.expm, e_ops=[P0, H0])
+    host_e = obj.propagate(tlist, propagator=prop, e_ops=[P0, H0])
+    assert len(dev_e.states) == 0
+    assert np.abs(dev_e.expect[0] - host_e.expect[0]).max() < 1e-12
+    assert np.abs(dev_e.expect[1] - host_e.expect[1]).max() < 1e-12
+    # Liouville space: the unitary Liouvillian of the same system on rho = |psi><psi| reproduces the populations
+    L0 = krotov_amd.objectives.liouvillian(H0, [])
+    L1 = krotov_amd.objectives.liouvillian(H1, [])
+    rho0 = np.outer(psi0, psi0.conj())
+    obj_l = krotov_amd.Objective(initial_state=rho0, target=rho0, H=[L0, [L1, eps]])
+    dev_l = obj_l.propagate(tlist, propagator=krotov_amd.propagators.HipExpm(liouville=True), e_ops=[P0])
+    assert np.abs(dev_l.expect[0] - host_e.expect[0]).max() < 1e-11
+
+
 SECOND_ORDER_CASES = [
     ('c3', None), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
     ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c2l', None),

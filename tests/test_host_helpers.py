@@ -220,6 +220,46 @@ def test_print_debug_information_text():
     assert 'chi_constructor: chis_re' in text and 'storage (bw, fw, fw0): [1 * ' in text
 
 
+def test_objective_propagate_host_loop():
+    """Objective.propagate (reference objectives.py:338-433; scenario of tests/test_objectives.py:233-270 without
+    the mesolve half): states on every grid point under the optimizer's own pulse discretization, expectation
+    values instead of states with e_ops, rho0 / H overrides, the attributes of the returned record."""
+    import scipy.linalg
+    H0 = np.diag([-0.5, 0.5]).astype(complex)
+    H1 = np.array([[0, 1], [1, 0]], dtype=complex)
+    eps = lambda t, args: 0.3 * np.sin(t) + args.get('offset', 0.0)  # noqa: E731
+    psi0, psi1 = np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)
+    obj = krotov_amd.Objective(initial_state=psi0, target=psi1, H=[H0, [H1, eps]])
+    tlist = np.linspace(0, 5, 51)
+    prop, _, _ = numpy_plugins()
+    res = obj.propagate(tlist, propagator=prop)
+    assert res.solver == prop.__name__ and res.num_expect == 0 and res.num_collapse == 0
+    assert np.array_equal(res.times, tlist) and len(res.states) == len(tlist) and res.expect == []
+    pulse = krotov_amd.conversions.control_onto_interval(krotov_amd.conversions.discretize(eps, tlist, args=({},)))
+    state = psi0
+    for n in range(len(tlist) - 1):
+        state = scipy.linalg.expm(-1j * (H0 + pulse[n] * H1) * (tlist[n + 1] - tlist[n])) @ state
+        assert np.abs(res.states[n + 1] - state).max() < 1e-13
+    P0, P1 = np.diag([1.0, 0.0]).astype(complex), np.diag([0.0, 1.0]).astype(complex)
+    res2 = obj.propagate(tlist, propagator=prop, e_ops=[P0, P1, H1 @ P0])
+    assert len(res2.states) == 0 and len(res2.expect) == 3 and res2.num_expect == 3
+    assert all(len(e) == len(tlist) for e in res2.expect)
+    assert res2.expect[0].dtype == np.float64 and np.iscomplexobj(res2.expect[2])  # Hermitian -> real
+    assert np.abs(res2.expect[0] - np.array([abs(s[0]) ** 2 for s in res.states])).max() < 1e-14
+    assert np.abs(res2.expect[0] + res2.expect[1] - 1.0).max() < 1e-13
+    # other initial state, other Hamiltonian, control arguments, a custom expect
+    res3 = obj.propagate(tlist, propagator=prop, rho0=psi1, H=[H0, [2 * H1, eps]], args={'offset': 0.1},
+                         e_ops=[P1], expect=lambda op, st: 7.0)
+    assert np.all(res3.expect[0] == 7.0)
+    res4 = obj.propagate(tlist, propagator=prop, rho0=psi1, H=[H0, [2 * H1, eps]], args={'offset': 0.1})
+    pulse4 = krotov_amd.conversions.control_onto_interval(
+        krotov_amd.conversions.discretize(eps, tlist, args=({'offset': 0.1},)))
+    state = psi1
+    for n in range(len(tlist) - 1):
+        state = scipy.linalg.expm(-1j * (H0 + pulse4[n] * 2 * H1) * (tlist[n + 1] - tlist[n])) @ state
+    assert np.abs(res4.states[-1] - state).max() < 1e-13
+
+
 @pytest.mark.parametrize('iter_stop', [0, -1])
 def test_zero_iterations(iter_stop):
     """reference tests/test_krotov.py:166-199"""
