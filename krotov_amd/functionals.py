@@ -30,6 +30,9 @@ __all__ = [
     'chis_re',
     'J_T_hs',
     'chis_hs',
+    'F_avg',
+    'gate',
+    'mapped_basis',
 ]
 
 
@@ -184,3 +187,71 @@ def chi_coefficients(chi_constructor, weights, tau, K):
             s += wk * t
         return ((1.0 / K**2) * w) * s, zero
     return None
+
+
+# ---------------------------------------------------------------------------
+# gate analysis (reference functionals.py:440-641); not on the optimisation path
+# ---------------------------------------------------------------------------
+def _arr(x):
+    return np.asarray(x.full() if hasattr(x, 'full') else x, dtype=np.complex128)
+
+
+def mapped_basis(O, basis_states):
+    """The states ``sum_i O[i, j] basis_states[i]`` for every column j of the gate ``O`` (reference
+    functionals.py:614-641); a tuple, each state of the basis states' type."""
+    O = _arr(O)
+    return tuple(
+        sum(complex(O[i, j]) * basis_states[i] for i in range(O.shape[0])) for j in range(O.shape[1])
+    )
+
+
+def gate(basis_states, fw_states_T):
+    """The N x N matrix ``U[i, j] = <basis_states[i]|fw_states_T[j]>`` that maps the basis states to the
+    propagated states (reference functionals.py:590-611; a NumPy array here, there is no Qobj to wrap it)."""
+    N = len(basis_states)
+    U = np.zeros((N, N), dtype=np.complex128)
+    for j in range(N):
+        for i in range(N):
+            U[i, j] = _overlap(basis_states[i], fw_states_T[j])
+    return U
+
+
+def F_avg(fw_states_T, basis_states, gate, mapped_basis_states=None, prec=1e-5):
+    """Average gate fidelity with respect to ``gate`` (N x N, in the logical subspace) from the propagated
+    logical basis (reference functionals.py:440-587): for N propagated state vectors
+    ``(|tr(O^+ U)|^2 + tr(O^+ U U^+ O)) / (N (N + 1))`` with U from :func:`gate`; for the N^2 propagated dyads
+    ``rho_ij = DynMap[|phi_i><phi_j|]`` (density matrices, ordered i N + j) the Liouville-space sum
+    ``sum_ij <O phi_i|rho_ij|O phi_j> + <O phi_i|rho_jj|O phi_i>`` over ``N (N + 1)``.  ``prec`` bounds the
+    imaginary part that errors in the states may leave."""
+    make_gate = globals()['gate']  # (the argument shadows the function of the same name, as in the reference)
+    N = len(basis_states)
+    O = _arr(gate)
+    if O.shape != (N, N):
+        raise ValueError("Shape of gate is incompatible with number of basis states")
+    first = _arr(fw_states_T[0])
+    is_operator = first.ndim == 2 and first.shape[0] == first.shape[1] and first.shape[0] > 1
+    if is_operator:
+        if len(fw_states_T) != N * N:
+            raise ValueError(
+                "Evaluating F_avg for density matrices requires %d states (forward-propagation of all dyadic "
+                "combinations of %d basis states), not %d" % (N * N, N, len(fw_states_T)))
+        if mapped_basis_states is None:
+            mapped_basis_states = mapped_basis(O, basis_states)
+        mapped = [_arr(v).reshape(-1) for v in mapped_basis_states]
+        F = 0.0
+        for j in range(N):
+            rho_jj = _arr(fw_states_T[j * N + j])
+            for i in range(N):
+                rho_ij = _arr(fw_states_T[i * N + j])
+                F += np.vdot(mapped[i], rho_ij @ mapped[j]) + np.vdot(mapped[i], rho_jj @ mapped[i])
+    else:
+        if len(fw_states_T) != N:
+            raise ValueError(
+                "Evaluating F_avg for hilbert space states requires %d states (forward-propagation of all basis "
+                "states), not %d" % (N, len(fw_states_T)))
+        U = make_gate(basis_states, fw_states_T)
+        OdU = O.conj().T @ U
+        F = abs(np.trace(OdU)) ** 2 + np.trace(OdU @ OdU.conj().T)
+    F = complex(F)
+    assert abs(F.imag) < prec, "%.2e > %.2e" % (F.imag, prec)
+    return F.real / (N * (N + 1))

@@ -274,6 +274,34 @@ ID2 = np.eye(2, dtype=complex)
 CNOT = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=complex)
 
 
+def test_gate_analysis_known_answers():
+    """F_avg, gate, mapped_basis (reference tests/test_functionals.py:79-89, 304-323 and the doctests of
+    functionals.py:590-641): sqrt(SWAP) against a controlled phase has F_avg = 0.3, in Hilbert space and from the
+    16 propagated dyads."""
+    from itertools import product
+    basis = [np.eye(4, dtype=complex)[:, i] for i in range(4)]
+    CNOT = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=complex)
+    states = krotov_amd.functionals.mapped_basis(CNOT, basis)
+    assert isinstance(states, tuple) and len(states) == 4
+    assert np.array_equal(states[2], basis[3]) and np.array_equal(states[3], basis[2])
+    assert np.abs(krotov_amd.functionals.gate(basis, states) - CNOT).max() < 1e-15
+    sqrt_swap = np.array([[1, 0, 0, 0], [0, 0.5 + 0.5j, 0.5 - 0.5j, 0], [0, 0.5 - 0.5j, 0.5 + 0.5j, 0], [0, 0, 0, 1]])
+    cphase = np.diag([1, 1, 1, -1]).astype(complex)
+    fw = krotov_amd.functionals.mapped_basis(sqrt_swap, basis)
+    assert abs(krotov_amd.functionals.F_avg(fw_states_T=fw, basis_states=basis, gate=cphase) - 0.3) < 1e-14
+    dyads = [np.outer(psi, phi.conj()) for psi, phi in product(fw, fw)]
+    assert abs(krotov_amd.functionals.F_avg(fw_states_T=dyads, basis_states=basis, gate=cphase) - 0.3) < 1e-14
+    assert abs(krotov_amd.functionals.F_avg(dyads, basis, cphase,
+                                            mapped_basis_states=krotov_amd.functionals.mapped_basis(cphase, basis)) - 0.3) < 1e-14
+    assert abs(krotov_amd.functionals.F_avg(krotov_amd.functionals.mapped_basis(cphase, basis), basis, cphase) - 1.0) < 1e-14
+    with pytest.raises(ValueError, match="Shape of gate"):
+        krotov_amd.functionals.F_avg(fw, basis, np.eye(2))
+    with pytest.raises(ValueError, match="requires 4 states"):
+        krotov_amd.functionals.F_avg(fw[:3], basis, cphase)
+    with pytest.raises(ValueError, match="requires 16 states"):
+        krotov_amd.functionals.F_avg(dyads[:5], basis, cphase)
+
+
 def test_gate_objectives_single_qubit_gate():
     """reference tests/test_objectives.py:307-316"""
     basis = [np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)]
