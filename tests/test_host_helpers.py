@@ -260,6 +260,28 @@ def test_objective_propagate_host_loop():
     assert np.abs(res4.states[-1] - state).max() < 1e-13
 
 
+def test_reference_parallel_map_names():
+    """Scripts that pass the reference's process-pool maps (tests/test_parallelization.py:113-140) or call
+    set_parallelization keep running: the names exist and map serially; |tau| after one iteration of the
+    transmon X gate is the reference's 0.9693 / 0.7743 (checked on the oracle in test_oracle_golden.py) --
+    here only that the three-map form goes through the plugin loop and gives the serial result."""
+    par = krotov_amd.parallelization
+    par.set_parallelization(use_loky=False, start_method='fork')
+    with pytest.raises(ValueError, match="start_method"):
+        par.set_parallelization(start_method='loky')
+    assert par.parallel_map(lambda v, a: v * a, [1, 2, 3], (2,), num_cpus=4) == [2, 4, 6]
+    assert par.parallel_map_fw_prop_step(lambda v, a: v + a, range(3), (1,)) == [1, 2, 3]
+    objectives, pulse_options, tlist = _system()
+    prop, mu, vdot = numpy_plugins()
+    kw = dict(pulse_options=pulse_options, tlist=tlist, propagator=prop, mu=mu, norm=np.linalg.norm,
+              overlap=lambda a, b: None if a is None or b is None else vdot(a, b),
+              chi_constructor=krotov_amd.functionals.chis_re, iter_stop=1)
+    serial = krotov_amd.optimize_pulses(objectives, **kw)
+    mapped = krotov_amd.optimize_pulses(
+        objectives, parallel_map=(par.parallel_map, par.parallel_map, par.parallel_map_fw_prop_step), **kw)
+    assert np.array_equal(serial.optimized_controls[0], mapped.optimized_controls[0])
+
+
 @pytest.mark.parametrize('iter_stop', [0, -1])
 def test_zero_iterations(iter_stop):
     """reference tests/test_krotov.py:166-199"""
