@@ -43,8 +43,7 @@ def serial_map(task, values, task_args=(), task_kwargs=None, **kwargs):
     return [task(v, *task_args, **task_kwargs) for v in values]
 
 
-def parallel_map(task, values, task_args=(), task_kwargs=None, num_cpus=None, progress_bar=None,
-                 progress_bar_args=None):
+def parallel_map(task, values, task_args=(), task_kwargs=None, num_cpus=None, progress_bar=None):
     """Signature of the reference's process-pool map (parallelization.py:233-299); evaluated serially."""
     return serial_map(task, values, task_args, task_kwargs)
 
