@@ -675,6 +675,9 @@ static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
     ex.abort_flag = e->d_abort;
     ex.G = (e->kind == KIND_COOP && internal_exchange) ? e->coop_G * e->coop_Y : e->grid_update;
     ex.timeout_ticks = e->timeout_ticks;
+    // across GPUs the ranks are separate processes: a host-side hiccup of one of them (garbage collection, page
+    // faults) must not look like a lost peer and demote the whole run to the per-interval path
+    if (e->p2p_ready && internal_exchange && ex.timeout_ticks < 1000000000LL) ex.timeout_ticks = 1000000000LL;  // 10 s
     ex.peer_windows = e->d_p2p_peers;
     ex.my_window = e->p2p_window;
     ex.world = (e->p2p_ready && internal_exchange) ? e->p2p_world : 1;
