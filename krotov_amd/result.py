@@ -3,11 +3,22 @@
 iter_seconds, info_vals, tau_vals, guess_controls, optimized_controls,
 controls_mapping, all_pulses, states, message, start_local_time,
 end_local_time``.  Host bookkeeping only.
+
+:meth:`Result.load` also reads dumps written by the reference itself
+(``krotov.result.Result.dump`` under QuTiP 4): the pickled QuTiP objects are
+rebuilt as NumPy arrays (state vectors 1-D, operators dense 2-D) by an
+unpickler that maps the handful of reference / QuTiP classes such a dump
+contains to stand-ins -- neither ``krotov`` nor ``qutip`` is imported -- so an
+optimisation started with the reference can be continued here
+(``continue_from=Result.load(path, objectives=...)``).
 """
 import copy
+import importlib
 import logging
 import pickle
 import time
+
+import numpy as np
 
 __all__ = ['Result', 'ControlPlaceholder']
 
@@ -121,7 +132,11 @@ class Result:
 
         logger = logging.getLogger('krotov')
         with open(filename, 'rb') as fh:
-            res = pickle.load(fh)
+            res = _Unpickler(fh).load()
+        if not isinstance(res, cls):
+            raise pickle.UnpicklingError("%s does not contain a Result" % filename)
+        for name, value in list(res.__dict__.items()):
+            setattr(res, name, _without_qobj(value))
         if objectives is None:
             if any(_has_placeholder(obj.H) or any(_has_placeholder(c) for c in obj.c_ops) for obj in res.objectives):
                 logger.warning(
@@ -165,3 +180,92 @@ def _has_placeholder(lst):
     if isinstance(lst, list):
         return any(_has_placeholder(v) for v in lst)
     return isinstance(lst, ControlPlaceholder)
+
+
+# ---------------------------------------------------------------------------
+# dumps written by the reference (krotov.result.Result.dump, result.py:247-262, under QuTiP 4)
+# ---------------------------------------------------------------------------
+class _RefState:
+    """Receives the pickled attribute dict of a qutip.Qobj / qutip.fastsparse.fast_csr_matrix."""
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+
+class _RefQobj(_RefState):
+    def to_array(self):
+        m = self._data
+        rows, cols = m._shape
+        dense = np.zeros((rows, cols), dtype=np.complex128)
+        indptr, indices, data = np.asarray(m.indptr), np.asarray(m.indices), np.asarray(m.data)
+        for r in range(rows):
+            lo, hi = indptr[r], indptr[r + 1]
+            dense[r, indices[lo:hi]] += data[lo:hi]
+        kind = getattr(self, '_type', None)
+        if kind == 'ket' or (kind is None and cols == 1):
+            return dense[:, 0].copy()
+        if kind == 'bra':
+            return dense[0, :].copy()
+        return dense
+
+
+class _RefCsr(_RefState):
+    pass
+
+
+def _ref_objective(initial_state, H, target, c_ops):
+    """krotov.objectives._Objective_reduce_init (reference objectives.py:581-585)"""
+    from .objectives import Objective
+
+    return Objective(initial_state=initial_state, H=H, target=target, c_ops=c_ops)
+
+
+class _Unpickler(pickle.Unpickler):
+    """The classes of a reference dump are mapped to their stand-ins above (whether or not ``krotov`` / ``qutip``
+    happen to be installed); everything else resolves as in :func:`pickle.load`."""
+
+    _REFERENCE = {
+        ('krotov.result', 'Result'): lambda: Result,
+        ('krotov.objectives', 'Objective'): lambda: importlib.import_module('krotov_amd.objectives').Objective,
+        ('krotov.objectives', '_Objective_reduce_init'): lambda: _ref_objective,
+        ('krotov.objectives', '_ControlPlaceholder'): lambda: ControlPlaceholder,
+        ('qutip.qobj', 'Qobj'): lambda: _RefQobj,
+        ('qutip.fastsparse', 'fast_csr_matrix'): lambda: _RefCsr,
+    }
+    _PLAIN = {
+        ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+        ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+        ('numpy', 'ndarray'), ('numpy', 'dtype'), ('time', 'struct_time'), ('builtins', 'complex'),
+        ('builtins', 'set'), ('builtins', 'frozenset'), ('collections', 'OrderedDict'),
+    }
+
+    def find_class(self, module, name):
+        if (module, name) in self._REFERENCE:
+            return self._REFERENCE[(module, name)]()
+        if (module, name) in self._PLAIN or module == 'krotov_amd' or module.startswith('krotov_amd.'):
+            if module.startswith('numpy.core.'):  # NumPy 2 moved numpy.core to numpy._core
+                try:
+                    return getattr(importlib.import_module(module), name)
+                except (ImportError, AttributeError):
+                    module = module.replace('numpy.core.', 'numpy._core.', 1)
+            return getattr(importlib.import_module(module), name)
+        return super().find_class(module, name)  # user classes (custom attributes of objectives, info_vals)
+
+
+def _without_qobj(value):
+    """``value`` with every rebuilt QuTiP object replaced by its array (lists, tuples, dicts and objectives
+    are walked)."""
+    from .objectives import Objective
+
+    if isinstance(value, _RefQobj):
+        return value.to_array()
+    if isinstance(value, list):
+        return [_without_qobj(v) for v in value]
+    if isinstance(value, tuple):
+        return tuple(_without_qobj(v) for v in value)
+    if isinstance(value, dict):
+        return {k: _without_qobj(v) for k, v in value.items()}
+    if isinstance(value, Objective):
+        for k, v in list(value.__dict__.items()):
+            setattr(value, k, _without_qobj(v))
+    return value

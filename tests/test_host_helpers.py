@@ -282,6 +282,44 @@ def test_reference_parallel_map_names():
     assert np.array_equal(serial.optimized_controls[0], mapped.optimized_controls[0])
 
 
+def test_load_reference_dump_and_continue(caplog):
+    """Result.load reads a dump written by the reference itself (tests/golden/reference_tls_oct_result.dump is
+    the reference's tests/test_result_serialization/oct_result.dump: QuTiP 4 objects inside) without krotov or
+    qutip: fields as extracted independently into dump_tls_ss.npz, QuTiP objects as arrays; and the
+    optimisation continues from it exactly as if it had run here from the start."""
+    from krotov_amd import configs
+    path = os.path.join(GOLDEN, 'reference_tls_oct_result.dump')
+    g = np.load(os.path.join(GOLDEN, 'dump_tls_ss.npz'))
+    with caplog.at_level('WARNING', logger='krotov'):
+        res = krotov_amd.result.Result.load(path)
+    assert 'control placeholders' in caplog.text
+    assert isinstance(res, krotov_amd.result.Result) and res.message.startswith('Reached convergence')
+    assert np.array_equal(res.tlist, g['tlist']) and list(res.iters) == list(g['iters'])
+    assert np.array_equal(np.array(res.tau_vals), g['tau_vals'])
+    assert np.array_equal(np.array(res.optimized_controls), g['optimized_controls'])
+    assert np.array_equal(np.array(res.all_pulses)[:, 0, :], g['all_pulses'][:, 0, :])
+    obj = res.objectives[0]
+    spec = configs.config_c1()
+    assert isinstance(obj, krotov_amd.Objective)
+    assert np.array_equal(obj.H[0], spec.H0[0]) and np.array_equal(obj.H[1][0], spec.Hc[0][0])
+    assert isinstance(obj.H[1][1], krotov_amd.result.ControlPlaceholder)
+    assert np.array_equal(obj.initial_state, spec.init[0]) and np.array_equal(obj.target, spec.target[0])
+    assert all(isinstance(st, np.ndarray) and st.shape == (2,) for st in res.states)
+    # continue two iterations from the reference's result vs 20 iterations from scratch
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd, column_states=False)
+    prop, mu, vdot = numpy_plugins()
+    kw = dict(pulse_options=pulse_options, tlist=spec.tlist, propagator=prop, mu=mu, norm=np.linalg.norm,
+              overlap=lambda a, b: None if a is None or b is None else vdot(a, b),
+              chi_constructor=krotov_amd.functionals.chis_ss, store_all_pulses=True)
+    loaded = krotov_amd.result.Result.load(path, objectives=objectives)
+    cont = krotov_amd.optimize_pulses(objectives, continue_from=loaded, iter_stop=20, **kw)
+    scratch = krotov_amd.optimize_pulses(objectives, iter_stop=20, **kw)
+    assert list(cont.iters) == list(range(21)) and len(cont.all_pulses) == 21
+    assert np.abs(np.array(cont.all_pulses[19:]) - np.array(scratch.all_pulses[19:])).max() < 1e-9
+    assert np.abs(np.array(cont.tau_vals[19:]) - np.array(scratch.tau_vals[19:])).max() < 1e-9
+    assert np.abs(np.array(cont.optimized_controls) - np.array(scratch.optimized_controls)).max() < 1e-9
+
+
 @pytest.mark.parametrize('iter_stop', [0, -1])
 def test_zero_iterations(iter_stop):
     """reference tests/test_krotov.py:166-199"""
