@@ -485,6 +485,23 @@ def test_tls_dump_18_iterations_on_device():
     assert np.abs(got - g['all_pulses']).max() < 1e-11  # measured ~1e-13
 
 
+def test_continue_from_reference_dump_on_device():
+    """An optimisation the reference ran and dumped (QuTiP objects inside; read by Result.load without QuTiP) is
+    continued on the GPU: iterations 19 and 20 as if all 20 had run here."""
+    import os
+    spec = configs.config_c1()
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'reference_tls_oct_result.dump')
+    loaded = krotov_amd.result.Result.load(path, objectives=objectives)
+    kw = dict(propagator=krotov_amd.propagators.expm, chi_constructor=krotov_amd.functionals.chis_ss,
+              store_all_pulses=True, iter_stop=20)
+    cont = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, continue_from=loaded, **kw)
+    scratch = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, **kw)
+    assert list(cont.iters) == list(range(21))
+    assert np.abs(np.array(cont.all_pulses[19:]) - np.array(scratch.all_pulses[19:])).max() < 1e-9
+    assert np.abs(np.array(cont.tau_vals[19:]) - np.array(scratch.tau_vals[19:])).max() < 1e-9
+
+
 def test_transmon17_dump_on_device():
     """reference docs/notebooks/transmonxgate_opt_result.dump, iterations 5 -> 8."""
     g = golden('dump_transmon17')
