@@ -28,6 +28,12 @@ def _real_scalar(v):
     return float(v)
 
 
+def _tlist_midpoints(tlist):
+    """Mid-points of the intervals of ``tlist`` (reference conversions.py:35-40)."""
+    tlist = np.asarray(tlist, dtype=np.float64)
+    return 0.5 * (tlist[1:] + tlist[:-1])
+
+
 def pulse_onto_tlist(pulse):
     """Interval values -> grid-point values: end points are kept, interior
     points are the mean of the two neighbouring intervals

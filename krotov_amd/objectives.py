@@ -78,14 +78,30 @@ class Objective:
     should reach ``target``; ``c_ops`` are Lindblad operators.
 
     Custom attributes (e.g. ``weight``) survive copies and ``adjoint()``.
-    ``type_checking`` exists for source compatibility with scripts that set it
-    (reference objectives.py:154-158); no type checks are ever performed here.
+    With ``type_checking`` (class attribute, default True as in the reference,
+    objectives.py:154-183) the constructor rejects what cannot be a state or a
+    (nested list of) operator(s): ``ValueError("Invalid initial_state ...")`` /
+    ``"Invalid H ..."`` / ``"Invalid c_ops ..."``.  Without QuTiP the test is
+    structural (array-likes and objects with ``.full()`` pass; None, callables,
+    tuples, strings do not).
     """
 
-    type_checking = False
+    type_checking = True
     _default_attribs = ['initial_state', 'H', 'target', 'c_ops']
 
     def __init__(self, *, initial_state, H, target, c_ops=None):
+        if self.type_checking:
+            if not _operator_like(initial_state):
+                raise ValueError("Invalid initial_state: must be a state (an array or an object with .full()), "
+                                 "not %s" % type(initial_state).__name__)
+            if not (_operator_like(H) or _nested_operator_list(H)):
+                raise ValueError("Invalid H, must be an operator or a nested list [H0, [H1, control], ...], not %s"
+                                 % type(H).__name__)
+            if c_ops is not None and not (isinstance(c_ops, list) and all(
+                    _operator_like(c) or _nested_operator_list(c)
+                    or (isinstance(c, list) and len(c) == 2 and _operator_like(c[0]))  # [operator, control]
+                    for c in c_ops)):
+                raise ValueError("Invalid c_ops, must be a list of operators or nested lists")
         self.H = H
         self.initial_state = initial_state
         self.target = target
@@ -200,6 +216,52 @@ class Objective:
             len(self.H) if isinstance(self.H, list) else 1,
             len(self.c_ops),
         )
+
+
+def _operator_like(x):
+    if x is None or callable(x) and not hasattr(x, 'full') or isinstance(x, (str, bytes, tuple, list, dict)):
+        return False
+    return hasattr(x, 'full') or hasattr(x, 'shape') or isinstance(x, (int, float, complex))
+
+
+def _nested_operator_list(lst):
+    if not isinstance(lst, list) or len(lst) == 0:
+        return False
+    return all(_operator_like(t) or (isinstance(t, list) and len(t) == 2 and _operator_like(t[0])) for t in lst)
+
+
+def _remove_functions_from_nested_list(lst):
+    """Copy of a nested list with every callable control replaced by a placeholder numbered in order of first
+    appearance (reference objectives.py:629-636)."""
+    from .result import ControlPlaceholder
+
+    ids = {}
+
+    def walk(v):
+        if isinstance(v, list):
+            return [walk(x) for x in v]
+        if callable(v) and not hasattr(v, 'full'):
+            return ControlPlaceholder(ids.setdefault(id(v), len(ids)))
+        return v
+
+    return walk(lst)
+
+
+def _Objective_reduce_init(initial_state, H, target, c_ops):
+    return Objective(initial_state=initial_state, H=H, target=target, c_ops=c_ops)
+
+
+def _Objective_reduce(obj):
+    """Reduction function for pickling an :class:`Objective` whose controls are functions, for a pickler's
+    ``dispatch_table`` / :func:`copyreg.pickle` (reference objectives.py:588-610): the functions -- which the
+    standard pickle cannot store -- become :class:`~krotov_amd.result.ControlPlaceholder` s."""
+    extras = {k: v for k, v in obj.__dict__.items() if k not in obj._default_attribs}
+    return (
+        _Objective_reduce_init,
+        (obj.initial_state, _remove_functions_from_nested_list(obj.H), obj.target,
+         _remove_functions_from_nested_list(obj.c_ops)),
+        extras,
+    )
 
 
 class PropagationResult:

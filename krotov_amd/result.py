@@ -217,7 +217,9 @@ def _ref_objective(initial_state, H, target, c_ops):
     """krotov.objectives._Objective_reduce_init (reference objectives.py:581-585)"""
     from .objectives import Objective
 
-    return Objective(initial_state=initial_state, H=H, target=target, c_ops=c_ops)
+    obj = Objective.__new__(Objective)  # (the components are still stand-ins: no validation here)
+    obj.initial_state, obj.H, obj.target, obj.c_ops = initial_state, H, target, ([] if c_ops is None else c_ops)
+    return obj
 
 
 class _Unpickler(pickle.Unpickler):

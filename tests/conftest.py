@@ -28,3 +28,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+
+@pytest.fixture
+def dummy_objectives(monkeypatch):
+    """Objectives built from placeholders (None, strings) for structural tests: switch the constructor's
+    validation off, as scripts do with ``krotov.Objective.type_checking = False``."""
+    import krotov_amd
+
+    monkeypatch.setattr(krotov_amd.Objective, 'type_checking', False)

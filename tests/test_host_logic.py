@@ -56,7 +56,7 @@ def test_shapes_match_oracle_bitwise():
     assert cb(2.5, None) == 1.0 and cb(2.5, {'func': 'sinsq'}) == 1.0
 
 
-def test_mapping_and_plug_in():
+def test_mapping_and_plug_in(dummy_objectives):
     X, Y, Z = np.eye(2), 2 * np.eye(2), 3 * np.eye(2)
     u1, u2 = np.zeros(3), np.ones(3)
     o1 = krotov_amd.Objective(initial_state=None, target=None, H=[X, [Y, u1], [Z, u1]])
@@ -103,7 +103,7 @@ def test_functionals_known_answers():
     assert np.abs(listed - c[:, None] * np.array([o.target for o in objs])).max() < 1e-15 and not d.any()
 
 
-def test_overlap_and_mu():
+def test_overlap_and_mu(dummy_objectives):
     from krotov_amd.mu import derivative_wrt_pulse
     from krotov_amd.second_order import _overlap
 

@@ -44,7 +44,7 @@ def _dummy_objective(control):
     return [krotov_amd.Objective(initial_state=np.zeros(2, dtype=complex), target=None, H=H)], H[1][1]
 
 
-def test_shape_validation():
+def test_shape_validation(dummy_objectives):
     """reference tests/test_pulse_options.py:9-73"""
     objectives, u = _dummy_objective(lambda t, args: 0)
     tlist = np.linspace(0, 10, 100)
@@ -93,7 +93,7 @@ def test_discretize():
     assert np.max(np.abs(discretize(sampled, tlist) - control_array)) < 1e-15
 
 
-def test_discretization_as_float():
+def test_discretization_as_float(dummy_objectives):
     """reference tests/test_structural_conversions.py:63-82 (an int-valued control is discretised as float)"""
     objectives, u = _dummy_objective(lambda t, args: 0)
     tlist = np.linspace(0, 10, 100)
@@ -101,7 +101,7 @@ def test_discretization_as_float():
     assert res[0][0].dtype == np.float64 and res[1][0].dtype == np.float64 and res[4][0].dtype == np.float64
 
 
-def test_initialize_krotov_controls_boundary_conditions():
+def test_initialize_krotov_controls_boundary_conditions(dummy_objectives):
     """reference tests/test_structural_conversions.py:85-141"""
     T = 10
     blackman = qutip_callback(shapes.blackman, t_start=0, t_stop=T)
@@ -120,7 +120,7 @@ def test_initialize_krotov_controls_boundary_conditions():
     assert len(shape_arrays) == 1 and isinstance(shape_arrays[0], np.ndarray) and len(shape_arrays[0]) == len(tlist) - 1
 
 
-def test_extract_controls_with_arrays():
+def test_extract_controls_with_arrays(dummy_objectives):
     """reference tests/test_structural_conversions.py:144-167"""
     X, Y, Z = Op(), Op(), Op()
     u1, u2 = np.array([]), np.array([])
@@ -136,7 +136,7 @@ def test_extract_controls_with_arrays():
     assert control_map[1] == [[[], [1]]]
 
 
-def test_extract_controls():
+def test_extract_controls(dummy_objectives):
     """reference tests/test_structural_conversions.py:170-218"""
     X, Y = Op(), Op()
     f, g, h, d = (lambda t: 0), (lambda t: 0), (lambda t: 0), (lambda t: 0)
@@ -300,6 +300,86 @@ def test_gate_analysis_known_answers():
         krotov_amd.functionals.F_avg(fw[:3], basis, cphase)
     with pytest.raises(ValueError, match="requires 16 states"):
         krotov_amd.functionals.F_avg(dyads[:5], basis, cphase)
+
+
+def test_invalid_objective_and_adjoint_of_invalid_list():
+    """reference tests/test_objectives.py:193-215: what cannot be a state / Hamiltonian is rejected at
+    construction (type_checking is on by default); _adjoint of a malformed nested list raises unless told to
+    ignore errors."""
+    H0 = np.diag([1.0, -1.0]).astype(complex)
+    H = [H0, [np.array([[0, 1], [1, 0]], dtype=complex), lambda t, args: 1.0]]
+    psi0, psi1 = np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)
+    krotov_amd.Objective(initial_state=psi0, target=psi1, H=H)
+    krotov_amd.Objective(initial_state=psi0, target='PE', H=H0, c_ops=[[H0, lambda t, args: 1.0]])
+    for bad in (psi0.conj, None):  # a bound method (psi0.full in the reference's test), nothing
+        with pytest.raises(ValueError, match="Invalid initial_state"):
+            krotov_amd.Objective(initial_state=bad, target=psi1, H=H)
+    for bad in (tuple(H), None):
+        with pytest.raises(ValueError, match="Invalid H"):
+            krotov_amd.Objective(initial_state=psi0, target=psi1, H=bad)
+    with pytest.raises(ValueError, match="Invalid c_ops"):
+        krotov_amd.Objective(initial_state=psi0, target=psi1, H=H, c_ops=(H0,))
+    nested = ['H0', ['H1', lambda t, args: 1], ['H2', 'H3', lambda t, args: 1]]
+    with pytest.raises(ValueError, match="expected format"):
+        krotov_amd.objectives._adjoint(nested, ignore_errors=False)
+    assert krotov_amd.objectives._adjoint(nested, ignore_errors=True) == nested
+
+
+def test_gate_objectives_pe_and_midpoints():
+    """reference tests/test_objectives.py:350-375 (Bell-basis objectives with target 'PE' under the three
+    spellings) and tests/test_structural_conversions.py:257-264 (_tlist_midpoints)."""
+    sz, sx, one = np.diag([1.0, -1.0]).astype(complex), np.array([[0, 1], [1, 0]], dtype=complex), np.eye(2, dtype=complex)
+    basis = [np.eye(4, dtype=complex)[:, i] for i in range(4)]
+    H = [np.kron(sz, one) + np.kron(one, sz), [np.kron(sx, one), lambda t, args: 1.0],
+         [np.kron(one, sx), lambda t, args: 1.0]]
+    objectives = krotov_amd.gate_objectives(basis, 'PE', H)
+    assert len(objectives) == 4 and all(obj.target == 'PE' for obj in objectives)
+    b00, b01, b10, b11 = basis
+    bell = [(b00 + b11) / np.sqrt(2), (1j * b01 + 1j * b10) / np.sqrt(2), (b01 - b10) / np.sqrt(2),
+            (1j * b00 - 1j * b11) / np.sqrt(2)]  # weylchamber.bell_basis
+    for obj, state in zip(objectives, bell):
+        assert np.abs(obj.initial_state - state).max() < 1e-15
+        assert obj == krotov_amd.Objective(initial_state=obj.initial_state, target='PE', H=H)
+    for spelling in ('perfect_entangler', 'perfect entangler', 'Perfect Entangler'):
+        assert krotov_amd.gate_objectives(basis, spelling, H) == objectives
+    with pytest.raises(ValueError):
+        krotov_amd.gate_objectives(basis, 'prefect(!) entanglers', H)
+    mid = krotov_amd.conversions._tlist_midpoints(np.array([0, 1.0, 2.0, 2.2]))
+    assert len(mid) == 3 and mid[0] == 0.5 and mid[1] == 1.5 and mid[2] == 2.1
+
+
+def test_objective_pickle_with_reduction_function():
+    """reference tests/test_objectives.py:698-741: pickled through the reduction function, an objective comes
+    back like a deep copy except that its control functions have become placeholders."""
+    import copyreg
+    import io
+    import pickle
+    H0 = np.diag([1.0, -1.0]).astype(complex)
+    H1 = np.array([[0, 1], [1, 0]], dtype=complex)
+    u1, u2 = (lambda t, args: 1.0), (lambda t, args: 2.0)
+    C = np.array([[0, 1], [0, 0]], dtype=complex)
+    obj1 = krotov_amd.Objective(initial_state=np.array([1, 0], dtype=complex), target=np.array([0, 1], dtype=complex),
+                                H=[H0, [H1, u1], [H0, u2]], c_ops=[[C, u1]])
+    obj1.weight = 0.5
+    with io.BytesIO() as buffer:
+        pickler = pickle.Pickler(buffer)
+        pickler.dispatch_table = copyreg.dispatch_table.copy()
+        pickler.dispatch_table[krotov_amd.Objective] = krotov_amd.objectives._Objective_reduce
+        pickler.dump(obj1)
+        buffer.seek(0)
+        obj2 = pickle.load(buffer)
+    assert obj2 is not obj1 and obj2 != obj1
+    assert obj2.initial_state is not obj1.initial_state and np.array_equal(obj2.initial_state, obj1.initial_state)
+    assert obj2.target is not obj1.target and np.array_equal(obj2.target, obj1.target)
+    assert obj2.H[0] is not obj1.H[0] and np.array_equal(obj2.H[0], obj1.H[0])
+    assert np.array_equal(obj2.H[1][0], H1) and np.array_equal(obj2.c_ops[0][0], C)
+    placeholder = krotov_amd.result.ControlPlaceholder
+    assert isinstance(obj2.H[1][1], placeholder) and isinstance(obj2.H[2][1], placeholder)
+    assert obj2.H[1][1] != obj2.H[2][1]
+    assert isinstance(obj2.c_ops[0][1], placeholder)
+    assert obj2.weight == 0.5
+    with pytest.raises(Exception):  # lambdas are not picklable without the reduction function
+        pickle.dumps(obj1)
 
 
 def test_gate_objectives_single_qubit_gate():
