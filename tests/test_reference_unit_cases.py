@@ -382,6 +382,38 @@ def test_objective_pickle_with_reduction_function():
         pickle.dumps(obj1)
 
 
+def test_derivative_wrt_pulse_cases():
+    """reference tests/test_mu.py:54-139: a control appearing in several terms gives the sum of their operators
+    (0.5 (s+ + s-) ... here s+ + s- = sigma_x); a control that is not in the objective gives the zero map;
+    collapse operators depending on the differentiated control are not implemented, on another control they
+    are fine."""
+    from krotov_amd.mu import derivative_wrt_pulse
+    sp = np.array([[0, 1], [0, 0]], dtype=complex)
+    sm, sz, sx = sp.T.copy(), np.diag([1.0, -1.0]).astype(complex), np.array([[0, 1], [1, 0]], dtype=complex)
+    eps1, eps2 = (lambda t, args: 0.5), (lambda t, args: 1)
+    H1, H2 = [0.5 * sz, [sp, eps1], [sm, eps1]], [0.5 * sz, [sz, eps2]]
+    k0, k1 = np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)
+    controls = [eps1, eps2]
+
+    def system(c_ops):
+        objs = [krotov_amd.Objective(initial_state=k0, target=k1, H=H, c_ops=c_ops) for H in (H1, H2)]
+        return objs, krotov_amd.conversions.extract_controls_mapping(objs, controls)
+
+    objs, mapping = system([0.1 * sp])
+    mu = derivative_wrt_pulse(objs, 0, controls, mapping, i_pulse=0, time_index=0)
+    for state in (k0, k1):
+        assert np.abs(mu(state) - sx @ state).max() == 0 and mu(state).shape == state.shape
+    for i_objective, i_pulse in ((0, 1), (1, 0)):
+        zero = derivative_wrt_pulse(objs, i_objective, controls, mapping, i_pulse=i_pulse, time_index=0)
+        for state in (k0, k1):
+            assert np.abs(zero(state)).max() == 0 and zero(state).shape == state.shape
+    objs, mapping = system([[[0.1 * sp, eps1]]])
+    with pytest.raises(NotImplementedError):
+        derivative_wrt_pulse(objs, 0, controls, mapping, i_pulse=0, time_index=0)
+    mu = derivative_wrt_pulse(objs, 1, controls, mapping, i_pulse=1, time_index=0)
+    assert np.abs(mu(k1) - sz @ k1).max() == 0
+
+
 def test_gate_objectives_single_qubit_gate():
     """reference tests/test_objectives.py:307-316"""
     basis = [np.array([1, 0], dtype=complex), np.array([0, 1], dtype=complex)]
