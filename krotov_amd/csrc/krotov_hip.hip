@@ -22,6 +22,7 @@
 #include "kh_tile64.h"
 #include "kh_tile64q2.h"
 #include "kh_coop.h"
+#include "kh_mini.h"
 
 static thread_local std::string g_last_error;
 
@@ -97,6 +98,7 @@ struct kh_engine {
     int coop_poll_delay = 12;  // KH_COOP_DELAY: the same for the cooperative kernels' block exchange
     double adj_sign = 0.0;  // +1 / -1: every control operator equals +/- its adjoint exactly (else 0)
     bool real_spectrum = false;  // every operator Hermitian (bit for bit) and f = -+i
+    bool mini = false;           // kind q2, N <= 16, K <= 8: the one-wave-per-objective kernels (kh_mini.h)
     double *d_q2_theta = nullptr, *d_q2_c0 = nullptr, *d_q2_rows = nullptr, *d_ratios = nullptr;  // series tables of the register-tile kernels
     long long timeout_ticks = 100000000LL;  // KH_TIMEOUT_MS: bound on any in-kernel wait (100 MHz ticks; 1 s)
 };
@@ -112,14 +114,14 @@ static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
 
 extern "C" const char *kh_last_error(void) { return g_last_error.c_str(); }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.2 (gfx950; tile64q2, tile64, coop16/mfma, generic, generic/csr kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.3 (gfx950; tile64q2, tile64, mini16, coop16/mfma, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
     switch (e->kind) {
         case KIND_TILE_RPT2: return "tile64/256";
         case KIND_TILE_RPT1: return "tile64/512";
-        case KIND_TILE_Q2: return "tile64q2/512";
+        case KIND_TILE_Q2: return e->mini ? "mini16/wave" : "tile64q2/512";
         case KIND_COOP: return "coop16/mfma";
         default: return e->d_csr_fw != nullptr ? "generic/csr" : "generic";
     }
@@ -327,6 +329,14 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         if (force && strcmp(force, "tile512") == 0) e->kind = KIND_TILE_RPT1;
         if (force && strcmp(force, "tile256") == 0 && e->L <= 2) e->kind = KIND_TILE_RPT2;
         e->grid_update = e->K;
+        // small problems: one wave per objective, the objectives of the GPU in one workgroup (kh_mini.h);
+        // KH_KERNEL=q2 keeps the workgroup-per-objective kernels, KH_KERNEL=mini is accepted for symmetry
+        e->mini = e->kind == KIND_TILE_Q2 && e->N <= KH_MINI_N && e->K <= KH_MINI_MAXK && force == nullptr;
+    }
+    if (force && strcmp(force, "mini") == 0 && tile_ok && e->L == 1 && e->N <= KH_MINI_N && e->K <= KH_MINI_MAXK) {
+        e->kind = KIND_TILE_Q2;
+        e->grid_update = e->K;
+        e->mini = true;
     }
     // objectives sharing ONE operator list with a state too large for a register tile: one Taylor
     // term of all objectives is a dense (N x N)(N x K) product -> fp64 matrix cores (kh_coop.h)
@@ -612,7 +622,9 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     const int direction = backward ? -1 : +1;
     KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
     int rc = KH_OK;
-    if (e->kind_store == KIND_TILE_Q2) {
+    if (e->kind_store == KIND_TILE_Q2 && e->mini) {
+        kh_mini_sweep_store<<<e->K, 64, 0, st>>>(p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
+    } else if (e->kind_store == KIND_TILE_Q2) {
         kh_q2_sweep_store<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(
             p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
     } else if (e->kind_store == KIND_TILE_RPT2) {
@@ -696,7 +708,12 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     // plain tile kernel (2 tiles) there -- measured 39 vs ~20 us per interval.
     const bool stepwise = !u.internal_exchange;
     int rc = KH_OK;
-    if (e->kind == KIND_TILE_Q2 && !stepwise) {
+    if (e->kind == KIND_TILE_Q2 && e->mini && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
+        if (u.sigma != nullptr)
+            kh_mini_forward_update<true><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
+        else
+            kh_mini_forward_update<false><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
+    } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
         if (u.sigma != nullptr)
             kh_q2_forward_update<true, false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
         else if (u.adj_sign != 0.0) {

@@ -9,7 +9,6 @@ The three sweeps map onto the reference's three ``parallel_map`` dispatches
 """
 import ctypes
 import os
-import weakref
 
 import numpy as np
 import torch
@@ -27,9 +26,10 @@ def _is_sparse(op):
 
 
 def LAST_ENGINE():
-    """The most recently created engine that is still alive (for benchmarks
-    that need the per-launch timings of an engine built inside optimize_pulses)."""
-    return None if _last_engine is None else _last_engine()
+    """The most recently created engine (for benchmarks and tests that need the per-launch timings or the
+    kernel family of an engine built inside optimize_pulses).  Held strongly until the next engine is created:
+    nothing in a :class:`~krotov_amd.result.Result` is guaranteed to keep it alive."""
+    return _last_engine
 
 
 def _require_gpu():
@@ -82,7 +82,7 @@ class HipKrotovEngine:
         self.profile = os.environ.get('KH_PROFILE', '0') == '1'
         self._events = {'forward': [], 'backward': [], 'update': []}
         global _last_engine
-        _last_engine = weakref.ref(self)
+        _last_engine = self
 
     def _check_dim(self, shape):
         if len(shape) != 2 or shape[0] != shape[1]:

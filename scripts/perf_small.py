@@ -23,11 +23,15 @@ for name, spec in (('c1 TLS', configs.config_c1()), ('c2 X gate (Hilbert)', conf
         torch.cuda.synchronize()
         stamps.append(time.perf_counter())
 
+    os.environ['KH_PROFILE'] = '1'  # per-sweep HIP-event timing
     krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, propagator=prop,
                                chi_constructor=getattr(krotov_amd.functionals, 'chis_' + spec.chi),
                                info_hook=hook, iter_stop=8)
     per = sorted(b - a for a, b in zip(stamps[2:], stamps[3:]))
     eng = LAST_ENGINE()
-    print('%-34s K=%d N=%d nt=%d  kernel %-13s  %.2f ms per iteration (%.2f us per interval and sweep)' % (
-        name, spec.K, spec.N, len(spec.tlist), eng.kernel, 1e3 * per[len(per) // 2],
-        1e6 * per[len(per) // 2] / (2 * (len(spec.tlist) - 1))))
+    t = eng.kernel_times_ms()
+    print('%-34s K=%d N=%d nt=%d  kernel %-13s  %.2f ms per iteration (kernels: backward %.2f + update %.2f ms = '
+          '%.2f + %.2f us per interval)' % (
+              name, spec.K, spec.N, len(spec.tlist), eng.kernel, 1e3 * per[len(per) // 2], min(t['backward']),
+              min(t['update']), 1e3 * min(t['backward']) / (len(spec.tlist) - 1),
+              1e3 * min(t['update']) / (len(spec.tlist) - 1)))

@@ -87,7 +87,8 @@ def test_sweeps_match_oracle(name):
     assert np.abs(psi2.cpu().numpy() - ref_psi).max() < tol
     assert np.abs(ga2.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
     assert np.abs((opt2 - opt).cpu().numpy()).max() < 1e-12 * scale
-    assert eng.kernel.startswith('tile64') == (spec.N <= 64)
+    assert eng.kernel.startswith(('tile64', 'mini16')) == (spec.N <= 64)
+    assert (eng.kernel == 'mini16/wave') == (spec.N <= 16 and spec.K <= 8 and spec.L == 1)
     assert (eng.kernel == 'tile64/256') == (name == 'c5_k300')
     assert (eng.kernel == 'coop16/mfma') == (name.startswith('c4_d') and spec.N > 64 or name.startswith('shared'))
     eng.close()
@@ -133,6 +134,7 @@ def test_q2_update_forward_side_partial_sums(name, monkeypatch):
     ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
     scale = max(1.0, np.abs(np.array(ref_opt)).max())
     results = []
+    monkeypatch.setenv('KH_KERNEL', 'q2')  # (the small cases would otherwise run the one-wave kernels)
     for no_adj in ('0', '1'):
         monkeypatch.setenv('KH_NO_ADJ', no_adj)
         eng = _engine(spec)
@@ -162,6 +164,7 @@ def test_q2_real_spectrum_series_vs_taylor(name, monkeypatch):
     ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
     scale = max(1.0, np.abs(np.array(ref_opt)).max())
     out, issued = [], []
+    monkeypatch.setenv('KH_KERNEL', 'q2')  # (the small cases would otherwise run the one-wave kernels)
     for taylor in ('0', '1'):
         monkeypatch.setenv('KH_TAYLOR', taylor)
         eng = _engine(spec)
@@ -668,6 +671,8 @@ def _two_rank_spec(case):
         spec = configs.config_c5(K=6, N=64, nt=61, L=1)
         spec.chi = 'sm'
         return spec
+    if case == 'c3':  # small problem: the one-wave-per-objective kernels, 2 + 2 objectives
+        return configs.config_c3(nt=301)
     return configs.config_c4(d=9, nt=41, n_logical=3)  # N = 81, K = 9 -> 5 + 4 objectives
 
 
@@ -714,7 +719,7 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['c5', 'c4', 'c4so'])
+@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so'])
 def test_two_ranks_sharded_on_one_gpu(case):
     import socket
 
@@ -740,11 +745,11 @@ def test_two_ranks_sharded_on_one_gpu(case):
         ref = oracle_optimize(spec, 2, sigma=SigmaA(0.0, 2e-3))
     else:
         ref = oracle_optimize(spec, 2)
-    tol = 1e-12 if case == 'c5' else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
+    tol = 1e-12 if case in ('c5', 'c3') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
     for _, pulses, tau, used_p2p, kernel in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
-        assert kernel == ('tile64q2/512' if case == 'c5' else 'coop16/mfma')
+        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini16/wave'}.get(case, 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
     print("cross-GPU exchange through peer windows used:", [o[3] for o in out])
 
