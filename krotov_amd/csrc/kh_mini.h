@@ -5,8 +5,8 @@
 // whatever N is, and the update sweep another ~1.7 us per interval on the cross-workgroup exchange through the
 // memory side.  Below N = 16 neither is needed:
 //   * a 16 x 16 complex tile is 4 elements per lane of ONE wave (lane = row * 4 + column quarter); a product
-//     is 4 broadcast LDS reads, 16 FMAs and a DPP quad reduction, and the vector goes back through LDS inside
-//     the wave -- LDS operations of a wave execute in order, so there is no barrier at all in the series;
+//     is 16 FMAs and a DPP quad reduction, and the vector never leaves the registers: the next product fetches
+//     its four elements from the lanes that hold them with ds_bpermute -- no LDS memory, no barrier in the series;
 //   * the objectives are the waves of ONE workgroup: the update sums cross through LDS with one
 //     __syncthreads per interval instead of a global exchange (objectives sharded over GPUs: the peer-window
 //     stage of kh_common.h on top, by wave 0).
@@ -26,8 +26,6 @@ struct KhMiniLds {
     double2 rows[KH_MAX_DEGREE + 1][KH_Q2_ROWS];  // {r1_p, r2_p} of every degree (kh_common.h, "Series coefficients")
     double c0[KH_MAX_DEGREE + 1];
     double deg[KH_MAX_DEGREE + 1];
-    cplx x[KH_MINI_MAXK][2][KH_MINI_N];  // per-wave ping-pong term vectors
-    cplx s[KH_MINI_MAXK][KH_MINI_N];     // per-wave vector s of the odd terms
     double part[2][KH_MINI_MAXK];        // the objectives' partial sums, by interval parity
     double D[2][2];                      // cross-GPU total + ok flag, by interval parity
 };
@@ -53,65 +51,93 @@ __device__ __forceinline__ void kh_mini_load_tile(const cplx *op, int N, int lan
     }
 }
 
-// (tile x vector)[r] on the four lanes of row r
-__device__ __forceinline__ cplx kh_mini_matvec(const cplx (&t)[4], const cplx *x, int lane) {
+// (tile x vector)[r] on the four lanes of row r.  The vector lives in registers, element c on the four lanes
+// 4 c .. 4 c + 3 (where the previous product left it): each lane fetches its four elements with ds_bpermute
+// (the LDS crossbar, no LDS memory) -- no write -> wait -> read round trip between the terms of the series.
+__device__ __forceinline__ cplx kh_mini_matvec(const cplx (&t)[4], cplx v, int lane) {
     const int cq = lane & 3;
     cplx y = c_make(0.0, 0.0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c_fma(y, t[j], x[4 * cq + j]);
+    for (int j = 0; j < 4; ++j) {
+        const int src = 4 * (4 * cq + j);
+        c_fma(y, t[j], c_make(__shfl(v.x, src), __shfl(v.y, src)));
+    }
     return c_make(sum4(y.x), sum4(y.y));
 }
 
-// LDS written by some lanes of this wave is read by others next: keep the compiler from moving the accesses
-// across this point (the hardware runs a wave's LDS operations in order)
-__device__ __forceinline__ void kh_mini_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// The step's coefficients in registers.  A single wave exposes every LDS latency (~100 cycles per dependent
+// read), so nothing is read from the tables while the degree, the step and the sub-step count stay what they
+// were in the previous interval -- the usual case along a smooth pulse on a uniform grid.
+#define KH_MINI_PHASES 8  // phase counts up to this run from registers; beyond: from the LDS tables
+struct KhMiniCoef {
+    int m, nsub;
+    double dt;
+    double c0, hr;                 // T_0 = c_0 v;  s starts as h r1_0 v
+    double c2[KH_MINI_PHASES];     // f^2 h^2 r2_p
+    double hn[KH_MINI_PHASES];     // h r1_{p+1}
+};
 
-// state <- series(f A dt) state for this wave's objective; x[cur] holds the state on entry and on exit
-__device__ __forceinline__ int kh_mini_expm_action(const cplx (&a)[4], const cplx (&b)[4], cplx &state, KhMiniLds &s,
-                                                   int w, int &cur, double fre, double fim, double dt, int nsub, int m,
-                                                   int lane) {
-    const int r = lane >> 2;
-    const bool writer = (lane & 3) == 0;
+__device__ __forceinline__ void kh_mini_coefficients(KhMiniCoef &c, const KhMiniLds &s, int m, int nsub, double dt,
+                                                     double fre, double fim) {
+    if (c.m == m && c.nsub == nsub && c.dt == dt) return;
+    c.m = m;
+    c.nsub = nsub;
+    c.dt = dt;
     const double h = nsub == 1 ? dt : dt / nsub;
     const double f2h2 = (fre * fre - fim * fim) * h * h;
-    const int phases = (m + 1) >> 1;
     const double2 *rows = s.rows[m];
+    c.c0 = s.c0[m];
+    c.hr = h * rows[0].x;
+#pragma unroll
+    for (int q = 0; q < KH_MINI_PHASES; ++q) {
+        c.c2[q] = f2h2 * rows[q].y;
+        c.hn[q] = h * rows[q + 1].x;
+    }
+}
+
+// state <- series(f A dt) state for this wave's objective (`state`: this lane's row of the vector)
+__device__ __forceinline__ int kh_mini_expm_action(const cplx (&a)[4], const cplx (&b)[4], cplx &state,
+                                                   const KhMiniLds &s, const KhMiniCoef &c, double fre, double fim,
+                                                   double dt, int nsub, int m, int lane) {
+    const int phases = (m + 1) >> 1;
     for (int sub = 0; sub < nsub; ++sub) {
-        const double hr = h * rows[0].x, c0 = s.c0[m];
-        cplx sacc = c_make(hr * state.x, hr * state.y);
-        state = c_make(c0 * state.x, c0 * state.y);
-        if (phases == 1) {
-            if (writer) s.s[w][r] = sacc;
-            kh_mini_wave_sync();
-        }
-        for (int ph = 0; ph < phases; ++ph) {
-            const double c2 = f2h2 * rows[ph].y;
-            const cplx yb = kh_mini_matvec(b, s.x[w][cur], lane);
-            const cplx t2 = c_make(c2 * yb.x, c2 * yb.y);
-            state.x += t2.x;
-            state.y += t2.y;
-            if (ph + 1 < phases) {
-                const double hn = h * rows[ph + 1].x;
-                sacc.x = fma(hn, t2.x, sacc.x);
-                sacc.y = fma(hn, t2.y, sacc.y);
-                if (writer) {
-                    s.x[w][cur ^ 1][r] = t2;
-                    if (ph + 2 == phases) s.s[w][r] = sacc;
+        cplx term = state;                                   // T_2p, the chain's current vector
+        cplx sacc = c_make(c.hr * state.x, c.hr * state.y);  // s = sum_p r1_p h T_2p
+        state = c_make(c.c0 * state.x, c.c0 * state.y);
+        if (phases <= KH_MINI_PHASES) {
+#pragma unroll
+            for (int ph = 0; ph < KH_MINI_PHASES; ++ph) {
+                if (ph < phases) {
+                    const cplx yb = kh_mini_matvec(b, term, lane);
+                    term = c_make(c.c2[ph] * yb.x, c.c2[ph] * yb.y);
+                    state.x += term.x;
+                    state.y += term.y;
+                    if (ph + 1 < phases) {
+                        sacc.x = fma(c.hn[ph], term.x, sacc.x);
+                        sacc.y = fma(c.hn[ph], term.y, sacc.y);
+                    }
                 }
-            } else {
-                const cplx ya = kh_mini_matvec(a, s.s[w], lane);
-                const cplx odd = c_mul(c_make(fre, fim), ya);
-                state.x += odd.x;
-                state.y += odd.y;
-                if (writer) s.x[w][cur ^ 1][r] = state;
             }
-            kh_mini_wave_sync();
-            cur ^= 1;
+        } else {
+            const double h = nsub == 1 ? dt : dt / nsub;
+            const double f2h2 = (fre * fre - fim * fim) * h * h;
+            const double2 *rows = s.rows[m];
+            for (int ph = 0; ph < phases; ++ph) {
+                const double c2 = f2h2 * rows[ph].y;
+                const cplx yb = kh_mini_matvec(b, term, lane);
+                term = c_make(c2 * yb.x, c2 * yb.y);
+                state.x += term.x;
+                state.y += term.y;
+                if (ph + 1 < phases) {
+                    const double hn = h * rows[ph + 1].x;
+                    sacc.x = fma(hn, term.x, sacc.x);
+                    sacc.y = fma(hn, term.y, sacc.y);
+                }
+            }
         }
+        const cplx odd = c_mul(c_make(fre, fim), kh_mini_matvec(a, sacc, lane));
+        state.x += odd.x;
+        state.y += odd.y;
     }
     return nsub * (phases + 1);
 }
@@ -146,30 +172,35 @@ kh_mini_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const dou
     kh_mini_load_tile(sq[(size_t)k * 3 + 2], N, lane, p2);
     const double nrm0 = p.op_norms[(size_t)k * 2], nrm1 = p.op_norms[(size_t)k * 2 + 1];
     cplx state = r < N ? state_in[(size_t)k * N + r] : c_make(0.0, 0.0);
-    int cur = 0;
-    if (writer) s.x[0][0][r] = state;
-    __syncthreads();
+    __syncthreads();  // (the tables)
     const bool stores = store != nullptr && writer && r < N;
     if (stores) store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + r] = state;
     double matvecs = 0.0;
-    int m_hint = 12;
-    // per-interval scalars are fetched one interval ahead (a global load is most of a step here)
+    KhDegreeCache dc = {12, 1.0, 0.0};
+    KhMiniCoef coef;
+    coef.m = -1;
+    // Per-interval scalars are fetched one interval ahead, and CONSUMED (moved to scalar registers) before the
+    // interval's state is stored: loads and stores share one in-order counter on gfx9, so a wait for a load
+    // issued after a store also waits for the store's acknowledgement (~1 us) -- most of a step here.
     const int n0 = direction > 0 ? 0 : nt - 2;
-    double eps_next = pulses[n0], dt_next = p.dt[n0];
+    double eps_next = kh_uniform(pulses[n0]), dt_next = kh_uniform(p.dt[n0]);
     for (int step = 0; step < nt - 1; ++step) {
         const int n = direction > 0 ? step : nt - 2 - step;
         const double eps = eps_next, dt = dt_next;
+        double eps_ld = 0.0, dt_ld = 0.0;
         if (step + 1 < nt - 1) {
             const int nn = direction > 0 ? n + 1 : n - 1;
-            eps_next = pulses[nn];
-            dt_next = p.dt[nn];
+            eps_ld = pulses[nn];
+            dt_ld = p.dt[nn];
         }
         int nsub, m;
-        kh_degree_lookup((nrm0 + fabs(eps) * nrm1) * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
-        m_hint = m;
+        kh_degree_cached((nrm0 + fabs(eps) * nrm1) * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
+        kh_mini_coefficients(coef, s, m, nsub, dt, p.fre, p.fim);
         cplx a[4], b[4];
         kh_mini_build(eps, h0, h1, p0, p1, p2, a, b);
-        matvecs += kh_mini_expm_action(a, b, state, s, 0, cur, p.fre, p.fim, dt, nsub, m, lane);
+        matvecs += kh_mini_expm_action(a, b, state, s, coef, p.fre, p.fim, dt, nsub, m, lane);
+        eps_next = kh_uniform(eps_ld);
+        dt_next = kh_uniform(dt_ld);
         if (stores) store[((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N + r] = state;
     }
     if (state_out != nullptr && writer && r < N) state_out[(size_t)k * N + r] = state;
@@ -196,12 +227,10 @@ kh_mini_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpda
     const double nrm0 = p.op_norms[(size_t)k * 2], nrm1 = p.op_norms[(size_t)k * 2 + 1];
     const double chi_norm = u.chi_norms[k];
     cplx state = r < N ? u.phi[(size_t)k * N + r] : c_make(0.0, 0.0);
-    int cur = 0;
-    if (writer) s.x[w][0][r] = state;
-    __syncthreads();
+    __syncthreads();  // (the tables)
     double matvecs = 0.0;
 
-    // this objective's  ||chi|| Im(mu <bra(t_n)|H1 phi>)  -> part[n & 1][k]; phi in x[cur], its row in `state`
+    // this objective's  ||chi|| Im(mu <bra(t_n)|H1 phi>)  -> part[n & 1][k]; phi's row of this lane in `state`
     // chi(t_n) (and, second order, phi_prev(t_n), sigma_n) of this lane's row, fetched one interval ahead
     cplx chi = c_make(0.0, 0.0), prev = c_make(0.0, 0.0);
     double sig = 0.0;
@@ -213,7 +242,7 @@ kh_mini_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpda
         if constexpr (SO) sig = u.sigma[n];
     };
     auto partial = [&](int n) {
-        const cplx y = kh_mini_matvec(h1, s.x[w][cur], lane);
+        const cplx y = kh_mini_matvec(h1, state, lane);
         cplx bra = chi;
         if constexpr (SO) {  // bra = chi + sigma / (2 ||chi||) (phi - phi_prev)  (optimize.py:468-469)
             if (writer && r < N) {
@@ -235,7 +264,9 @@ kh_mini_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpda
     __syncthreads();
     double g_a_loc = 0.0;
     const double lam = u.lambda[0];
-    int m_hint = 12;
+    KhDegreeCache dc = {12, 1.0, 0.0};
+    KhMiniCoef coef;
+    coef.m = -1;
     double dt_next = p.dt[u.n_begin], guess_next = u.guess[u.n_begin], shape_next = u.shape[u.n_begin];
     for (int n = u.n_begin; n < u.n_end; ++n) {
         const int par = n & 1;
@@ -274,11 +305,11 @@ kh_mini_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpda
         }
         // ---- propagate over interval n with the updated pulse (optimize.py:479-491) ----
         int nsub, m;
-        kh_degree_lookup((nrm0 + fabs(eps) * nrm1) * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
-        m_hint = m;
+        kh_degree_cached((nrm0 + fabs(eps) * nrm1) * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
+        kh_mini_coefficients(coef, s, m, nsub, dt, p.fre, p.fim);
         cplx a[4], b[4];
         kh_mini_build(eps, h0, h1, p0, p1, p2, a, b);
-        matvecs += kh_mini_expm_action(a, b, state, s, w, cur, p.fre, p.fim, dt, nsub, m, lane);
+        matvecs += kh_mini_expm_action(a, b, state, s, coef, p.fre, p.fim, dt, nsub, m, lane);
         if (n + 1 < nt - 1) partial(n + 1);
         __syncthreads();  // everybody's partial sum of the next interval is in LDS
     }
