@@ -211,6 +211,7 @@ def main():
     kernel_names = {
         'tile64q2/512': ('kh_q2_forward_update', 'kh_q2_sweep_store'),
         'mini16/wave': ('kh_mini_forward_update', 'kh_mini_sweep_store'),
+        'mini4/wave': ('kh_quad_forward_update', 'kh_quad_sweep_store'),
         'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
         'coop16/mfma': ('kh_coop_forward_update', 'kh_coop_sweep_store'),
     }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))

@@ -320,3 +320,238 @@ kh_mini_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpda
     if (tid == 0) u.g_a[0] = g_a_loc;
     if (lane == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }
+
+// ===========================================================================
+// N <= 4, at most 4 objectives: the whole problem in ONE wave
+// ===========================================================================
+// One matrix element per lane: lane = 16 o + 4 r + c holds element [r][c] of objective o's tiles; vector element
+// e of objective o sits on lanes 16 o + 4 e .. + 3.  A product is one complex multiply, a DPP quad sum and one
+// ds_bpermute fetch per lane; the update sum over rows AND objectives is a single wavefront reduction (no LDS,
+// no barrier anywhere; objectives sharded over GPUs: the peer-window stage by the same wave).  The series'
+// degree is the largest any of the wave's objectives needs (a higher degree also serves a smaller norm).
+#define KH_QUAD_N 4
+#define KH_QUAD_MAXK 4
+
+__device__ __forceinline__ cplx kh_quad_load(const cplx *op, int N, int r, int c, bool valid) {
+    return (valid && op != nullptr && r < N && c < N) ? op[(size_t)r * N + c] : c_make(0.0, 0.0);
+}
+
+// (tile x vector)[r] on the four lanes of row r of every objective
+__device__ __forceinline__ cplx kh_quad_matvec(cplx t, cplx v, int lane) {
+    const int src = (lane & 48) | ((lane & 3) << 2);  // the lanes holding element c of this lane's objective
+    const cplx x = c_make(__shfl(v.x, src), __shfl(v.y, src));
+    const cplx y = c_mul(t, x);
+    return c_make(sum4(y.x), sum4(y.y));
+}
+
+__device__ __forceinline__ int kh_quad_expm_action(cplx a, cplx b, cplx &state, const KhMiniLds &s, const KhMiniCoef &c,
+                                                   double fre, double fim, double dt, int nsub, int m, int lane) {
+    const int phases = (m + 1) >> 1;
+    for (int sub = 0; sub < nsub; ++sub) {
+        cplx term = state;
+        cplx sacc = c_make(c.hr * state.x, c.hr * state.y);
+        state = c_make(c.c0 * state.x, c.c0 * state.y);
+        if (phases <= KH_MINI_PHASES) {
+#pragma unroll
+            for (int ph = 0; ph < KH_MINI_PHASES; ++ph) {
+                if (ph < phases) {
+                    const cplx yb = kh_quad_matvec(b, term, lane);
+                    term = c_make(c.c2[ph] * yb.x, c.c2[ph] * yb.y);
+                    state.x += term.x;
+                    state.y += term.y;
+                    if (ph + 1 < phases) {
+                        sacc.x = fma(c.hn[ph], term.x, sacc.x);
+                        sacc.y = fma(c.hn[ph], term.y, sacc.y);
+                    }
+                }
+            }
+        } else {
+            const double h = nsub == 1 ? dt : dt / nsub;
+            const double f2h2 = (fre * fre - fim * fim) * h * h;
+            const double2 *rows = s.rows[m];
+            for (int ph = 0; ph < phases; ++ph) {
+                const double c2 = f2h2 * rows[ph].y;
+                const cplx yb = kh_quad_matvec(b, term, lane);
+                term = c_make(c2 * yb.x, c2 * yb.y);
+                state.x += term.x;
+                state.y += term.y;
+                if (ph + 1 < phases) {
+                    const double hn = h * rows[ph + 1].x;
+                    sacc.x = fma(hn, term.x, sacc.x);
+                    sacc.y = fma(hn, term.y, sacc.y);
+                }
+            }
+        }
+        const cplx odd = c_mul(c_make(fre, fim), kh_quad_matvec(a, sacc, lane));
+        state.x += odd.x;
+        state.y += odd.y;
+    }
+    return nsub * (phases + 1);
+}
+
+// largest value of a lane-varying non-negative double over the wave (same value in every lane)
+__device__ __forceinline__ double kh_wave_max(double v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+struct KhQuadTiles {
+    cplx h0, h1, p0, p1, p2;
+    double nrm0, nrm1;
+};
+
+__device__ __forceinline__ KhQuadTiles kh_quad_load_tiles(const KhSweepArgs &p, const cplx *const *sq, int k, int r, int c,
+                                                          bool valid) {
+    KhQuadTiles t;
+    const size_t kk = valid ? (size_t)k : 0;
+    t.h0 = kh_quad_load(p.ops[kk * 2], p.N, r, c, valid);
+    t.h1 = kh_quad_load(p.ops[kk * 2 + 1], p.N, r, c, valid);
+    t.p0 = kh_quad_load(sq[kk * 3], p.N, r, c, valid);
+    t.p1 = kh_quad_load(sq[kk * 3 + 1], p.N, r, c, valid);
+    t.p2 = kh_quad_load(sq[kk * 3 + 2], p.N, r, c, valid);
+    t.nrm0 = valid ? p.op_norms[kk * 2] : 0.0;
+    t.nrm1 = valid ? p.op_norms[kk * 2 + 1] : 0.0;
+    return t;
+}
+
+__device__ __forceinline__ void kh_quad_build(const KhQuadTiles &t, double eps, cplx &a, cplx &b) {
+    const double eps2 = eps * eps;
+    a = c_make(fma(eps, t.h1.x, t.h0.x), fma(eps, t.h1.y, t.h0.y));
+    b = c_make(fma(eps2, t.p2.x, fma(eps, t.p1.x, t.p0.x)), fma(eps2, t.p2.y, fma(eps, t.p1.y, t.p0.y)));
+}
+
+__global__ void __launch_bounds__(64)
+kh_quad_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const double *__restrict__ pulses,
+                    const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out,
+                    int direction) {
+    __shared__ KhMiniLds s;
+    const int lane = threadIdx.x, k = lane >> 4, r = (lane >> 2) & 3, c = lane & 3;
+    const int N = p.N, nt = p.nt;
+    const bool valid = k < p.K, owner = valid && c == 0 && r < N;
+    kh_mini_stage_tables(p, s, lane, 64);
+    const KhQuadTiles t = kh_quad_load_tiles(p, sq, k, r, c, valid);
+    cplx state = (valid && r < N) ? state_in[(size_t)k * N + r] : c_make(0.0, 0.0);
+    __syncthreads();  // (the tables)
+    const bool stores = store != nullptr && owner;
+    if (stores) store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + r] = state;
+    double matvecs = 0.0;
+    KhDegreeCache dc = {12, 1.0, 0.0};
+    KhMiniCoef coef;
+    coef.m = -1;
+    const int n0 = direction > 0 ? 0 : nt - 2;
+    double eps_next = kh_uniform(pulses[n0]), dt_next = kh_uniform(p.dt[n0]);
+    for (int step = 0; step < nt - 1; ++step) {
+        const int n = direction > 0 ? step : nt - 2 - step;
+        const double eps = eps_next, dt = dt_next;
+        double eps_ld = 0.0, dt_ld = 0.0;
+        if (step + 1 < nt - 1) {
+            const int nn = direction > 0 ? n + 1 : n - 1;
+            eps_ld = pulses[nn];
+            dt_ld = p.dt[nn];
+        }
+        int nsub, m;
+        const double theta = kh_uniform(kh_wave_max((t.nrm0 + fabs(eps) * t.nrm1) * dt));
+        kh_degree_cached(theta, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
+        kh_mini_coefficients(coef, s, m, nsub, dt, p.fre, p.fim);
+        cplx a, b;
+        kh_quad_build(t, eps, a, b);
+        matvecs += kh_quad_expm_action(a, b, state, s, coef, p.fre, p.fim, dt, nsub, m, lane);
+        eps_next = kh_uniform(eps_ld);
+        dt_next = kh_uniform(dt_ld);
+        if (stores) store[((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N + r] = state;
+    }
+    if (state_out != nullptr && owner) state_out[(size_t)k * N + r] = state;
+    if (lane == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs * p.K);
+}
+
+template <bool SO>
+__global__ void __launch_bounds__(64)
+kh_quad_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdateArgs u, KhExchange ex) {
+    __shared__ KhMiniLds s;
+    const int lane = threadIdx.x, k = lane >> 4, r = (lane >> 2) & 3, c = lane & 3;
+    const int N = p.N, nt = p.nt;
+    const bool valid = k < p.K, owner = valid && c == 0 && r < N;
+    kh_mini_stage_tables(p, s, lane, 64);
+    const KhQuadTiles t = kh_quad_load_tiles(p, sq, k, r, c, valid);
+    const double chi_norm = valid ? u.chi_norms[k] : 0.0;
+    cplx state = (valid && r < N) ? u.phi[(size_t)k * N + r] : c_make(0.0, 0.0);
+    __syncthreads();  // (the tables)
+    double matvecs = 0.0;
+
+    cplx chi = c_make(0.0, 0.0), prev = c_make(0.0, 0.0);
+    double sig = 0.0;
+    auto load_bra = [&](int n) {
+        if (owner) {
+            chi = u.chi_store[((size_t)k * nt + n) * N + r];
+            if constexpr (SO) prev = u.fw_prev[((size_t)k * nt + n) * N + r];
+        }
+        if constexpr (SO) sig = u.sigma[n];
+    };
+    // sum over rows and objectives of ||chi_k|| Im(mu <bra_k|H1 phi_k>): one wavefront reduction
+    auto update_sum = [&]() {
+        const cplx y = kh_quad_matvec(t.h1, state, lane);
+        cplx bra = chi;
+        if constexpr (SO) {
+            if (owner) {
+                const double hs = 0.5 * sig / chi_norm;
+                bra = c_make(fma(hs, state.x - prev.x, chi.x), fma(hs, state.y - prev.y, chi.y));
+            }
+        }
+        cplx ov = c_make(0.0, 0.0);
+        if (owner) c_fma_conj(ov, bra, y);
+        matvecs += 1.0;
+        return sum64(chi_norm * (u.mu_re * ov.y + u.mu_im * ov.x));
+    };
+
+    double d_next = 0.0;
+    if (u.n_begin < nt - 1) {
+        load_bra(u.n_begin);
+        d_next = update_sum();
+    }
+    double g_a_loc = 0.0;
+    const double lam = u.lambda[0];
+    KhDegreeCache dc = {12, 1.0, 0.0};
+    KhMiniCoef coef;
+    coef.m = -1;
+    double dt_next = p.dt[u.n_begin], guess_next = u.guess[u.n_begin], shape_next = u.shape[u.n_begin];
+    for (int n = u.n_begin; n < u.n_end; ++n) {
+        const int par = n & 1;
+        const double dt = dt_next, guess = guess_next, shape = shape_next;
+        if (n + 1 < nt - 1) {
+            dt_next = p.dt[n + 1];
+            guess_next = u.guess[n + 1];
+            shape_next = u.shape[n + 1];
+            load_bra(n + 1);
+        }
+        double d1 = d_next;
+        if (ex.world > 1) {  // objectives sharded over GPUs: second stage through the peer windows
+            const unsigned int epoch = ex.epoch_base + (unsigned)(n + 1);
+            double D[1] = {d1};
+            kh_p2p_publish(ex, par, 1, lane, D, epoch);
+            if (!kh_p2p_gather<1>(ex, par, 1, epoch, lane, D)) return;
+            d1 = D[0];
+        }
+        const double stepw = shape / lam;
+        const double eps = kh_uniform(guess + stepw * d1);
+        g_a_loc += stepw * (d1 * d1) * dt;
+        if (lane == 0) u.opt[n] = eps;
+        if constexpr (SO) {
+            if (owner) u.fw_store[((size_t)k * nt + n) * N + r] = state;
+        }
+        int nsub, m;
+        const double theta = kh_uniform(kh_wave_max((t.nrm0 + fabs(eps) * t.nrm1) * dt));
+        kh_degree_cached(theta, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
+        kh_mini_coefficients(coef, s, m, nsub, dt, p.fre, p.fim);
+        cplx a, b;
+        kh_quad_build(t, eps, a, b);
+        matvecs += kh_quad_expm_action(a, b, state, s, coef, p.fre, p.fim, dt, nsub, m, lane);
+        if (n + 1 < nt - 1) d_next = update_sum();
+    }
+    if (owner) {
+        u.phi[(size_t)k * N + r] = state;
+        if constexpr (SO) u.fw_store[((size_t)k * nt + u.n_end) * N + r] = state;
+    }
+    if (lane == 0) u.g_a[0] = g_a_loc;
+    if (lane == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs * p.K);
+}

@@ -99,6 +99,7 @@ struct kh_engine {
     double adj_sign = 0.0;  // +1 / -1: every control operator equals +/- its adjoint exactly (else 0)
     bool real_spectrum = false;  // every operator Hermitian (bit for bit) and f = -+i
     bool mini = false;           // kind q2, N <= 16, K <= 8: the one-wave-per-objective kernels (kh_mini.h)
+    bool quad = false;           // mini with N <= 4, K <= 4: the whole problem in one wave
     double *d_q2_theta = nullptr, *d_q2_c0 = nullptr, *d_q2_rows = nullptr, *d_ratios = nullptr;  // series tables of the register-tile kernels
     long long timeout_ticks = 100000000LL;  // KH_TIMEOUT_MS: bound on any in-kernel wait (100 MHz ticks; 1 s)
 };
@@ -114,14 +115,14 @@ static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
 
 extern "C" const char *kh_last_error(void) { return g_last_error.c_str(); }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.3 (gfx950; tile64q2, tile64, mini16, coop16/mfma, generic, generic/csr kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.3 (gfx950; tile64q2, tile64, mini16, mini4, coop16/mfma, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
     switch (e->kind) {
         case KIND_TILE_RPT2: return "tile64/256";
         case KIND_TILE_RPT1: return "tile64/512";
-        case KIND_TILE_Q2: return e->mini ? "mini16/wave" : "tile64q2/512";
+        case KIND_TILE_Q2: return e->mini ? (e->quad ? "mini4/wave" : "mini16/wave") : "tile64q2/512";
         case KIND_COOP: return "coop16/mfma";
         default: return e->d_csr_fw != nullptr ? "generic/csr" : "generic";
     }
@@ -338,6 +339,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         e->grid_update = e->K;
         e->mini = true;
     }
+    e->quad = e->mini && e->N <= KH_QUAD_N && e->K <= KH_QUAD_MAXK && !(force && strcmp(force, "mini") == 0);
     // objectives sharing ONE operator list with a state too large for a register tile: one Taylor
     // term of all objectives is a dense (N x N)(N x K) product -> fp64 matrix cores (kh_coop.h)
     {
@@ -622,7 +624,9 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     const int direction = backward ? -1 : +1;
     KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
     int rc = KH_OK;
-    if (e->kind_store == KIND_TILE_Q2 && e->mini) {
+    if (e->kind_store == KIND_TILE_Q2 && e->quad) {
+        kh_quad_sweep_store<<<1, 64, 0, st>>>(p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
+    } else if (e->kind_store == KIND_TILE_Q2 && e->mini) {
         kh_mini_sweep_store<<<e->K, 64, 0, st>>>(p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
     } else if (e->kind_store == KIND_TILE_Q2) {
         kh_q2_sweep_store<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(
@@ -708,7 +712,12 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     // plain tile kernel (2 tiles) there -- measured 39 vs ~20 us per interval.
     const bool stepwise = !u.internal_exchange;
     int rc = KH_OK;
-    if (e->kind == KIND_TILE_Q2 && e->mini && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
+    if (e->kind == KIND_TILE_Q2 && e->quad && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
+        if (u.sigma != nullptr)
+            kh_quad_forward_update<true><<<1, 64, 0, st>>>(p, e->d_sq_fw, u, ex);
+        else
+            kh_quad_forward_update<false><<<1, 64, 0, st>>>(p, e->d_sq_fw, u, ex);
+    } else if (e->kind == KIND_TILE_Q2 && e->mini && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
         if (u.sigma != nullptr)
             kh_mini_forward_update<true><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
         else

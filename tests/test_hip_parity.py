@@ -87,8 +87,10 @@ def test_sweeps_match_oracle(name):
     assert np.abs(psi2.cpu().numpy() - ref_psi).max() < tol
     assert np.abs(ga2.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
     assert np.abs((opt2 - opt).cpu().numpy()).max() < 1e-12 * scale
-    assert eng.kernel.startswith(('tile64', 'mini16')) == (spec.N <= 64)
-    assert (eng.kernel == 'mini16/wave') == (spec.N <= 16 and spec.K <= 8 and spec.L == 1)
+    assert eng.kernel.startswith(('tile64', 'mini')) == (spec.N <= 64)
+    small = spec.N <= 16 and spec.K <= 8 and spec.L == 1
+    quad = small and spec.N <= 4 and spec.K <= 4
+    assert (eng.kernel == 'mini4/wave') == quad and (eng.kernel == 'mini16/wave') == (small and not quad)
     assert (eng.kernel == 'tile64/256') == (name == 'c5_k300')
     assert (eng.kernel == 'coop16/mfma') == (name.startswith('c4_d') and spec.N > 64 or name.startswith('shared'))
     eng.close()
@@ -220,7 +222,7 @@ def test_objective_propagate_on_device():
 
 
 SECOND_ORDER_CASES = [
-    ('c3', None), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
+    ('c3', None), ('c5_n16', None), ('c3', 'mini'), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
     ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c2l', None),
     ('c4_d9', None), ('shared_n96_L2', None), ('c3', 'coop'), ('shared_n96_L2', 'coop16cols'),
 ]
@@ -749,7 +751,7 @@ def test_two_ranks_sharded_on_one_gpu(case):
     for _, pulses, tau, used_p2p, kernel in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
-        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini16/wave'}.get(case, 'coop16/mfma')
+        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave'}.get(case, 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
     print("cross-GPU exchange through peer windows used:", [o[3] for o in out])
 
