@@ -814,15 +814,17 @@ def test_full_size_c4_liouville_properties(monkeypatch):
     eng2.close()
 
 
-@pytest.mark.parametrize('kernel', ['q2', 'tile512', 'generic'])
+@pytest.mark.parametrize('kernel', ['q2', 'tile512', 'generic', 'mini', 'one-wave'])
 def test_nonuniform_grid_and_large_step_norms(kernel, monkeypatch):
     """Non-uniform dt and ||H dt|| up to ~4 (several Taylor sub-steps per interval,
-    degrees changing along the grid), non-Hermitian drift: every kernel family."""
+    degrees changing along the grid), non-Hermitian drift: every kernel family
+    ('one-wave': N = 4, the whole problem in one wave, objectives of different norms)."""
     from krotov_amd.engine import HipKrotovEngine
 
-    monkeypatch.setenv('KH_KERNEL', kernel)
+    if kernel != 'one-wave':
+        monkeypatch.setenv('KH_KERNEL', kernel)
     rng = np.random.default_rng(11)
-    K, N, nt = 3, 10, 25
+    K, N, nt = 3, (4 if kernel == 'one-wave' else 10), 25
     tl = np.cumsum(np.concatenate([[0.0], rng.uniform(0.02, 0.4, nt - 1)]))
     ops = []
     for k in range(K):
@@ -836,6 +838,8 @@ def test_nonuniform_grid_and_large_step_norms(kernel, monkeypatch):
     gp = [0.8 * np.cos(np.arange(nt - 1) * 0.7)]
     S = [np.linspace(0.2, 1.0, nt - 1)]
     eng = HipKrotovEngine(ops, np.diff(tl))
+    assert eng.kernel == {'q2': 'tile64q2/512', 'tile512': 'tile64/512', 'mini': 'mini16/wave',
+                          'one-wave': 'mini4/wave'}.get(kernel, kernel)
     fw_T, states = eng.forward(np.array(gp), init, store=True)
     ref_T, ref_states = ko.forward_propagation(prob, gp, store=True)
     assert np.abs(states.cpu().numpy() - ref_states).max() < 1e-11
