@@ -5,11 +5,13 @@ API-compatible with ``krotov.objectives`` (reference src/krotov/objectives.py:
 ``ensemble_objectives``, 1097-1121 ``liouvillian``) for the parts on or next to
 the hot path.  Operators and states may be QuTiP-like objects (anything with
 ``.full()`` / ``.dag()``) or NumPy arrays; QuTiP itself is never imported, so
-there is no type checking, ``mesolve`` delegation or pretty printing here;
-``Objective.propagate`` (338-433) runs on the engine's forward sweep.
+``Objective.propagate`` (338-433) runs on the engine's forward sweep,
+``summarize`` / ``str`` (445-578) number the components like the reference,
+``mesolve`` delegates to QuTiP when it is installed.
 """
 import copy
 import itertools
+from collections import defaultdict
 
 import numpy as np
 
@@ -87,7 +89,10 @@ class Objective:
     """
 
     type_checking = True
+    str_use_unicode = True
     _default_attribs = ['initial_state', 'H', 'target', 'c_ops']
+    _counter = defaultdict(int, {'u{count}(t)': 1})
+    _count_cache = {}
 
     def __init__(self, *, initial_state, H, target, c_ops=None):
         if self.type_checking:
@@ -209,13 +214,136 @@ class Objective:
             result.expect = [np.array([expect(oper, st) for st in states]) for oper in e_ops]
         return result
 
+    def mesolve(self, tlist, *, rho0=None, H=None, c_ops=None, e_ops=None, args=None, **kwargs):
+        """The reference delegates this to :func:`qutip.mesolve` (objectives.py:260-336: controls piecewise
+        constant CENTERED on the grid points, QuTiP's ODE solver).  Done here the same way when QuTiP is
+        installed and the components are QuTiP objects; otherwise use :meth:`propagate`."""
+        try:
+            import qutip
+        except ImportError as exc:
+            raise NotImplementedError(
+                "Objective.mesolve delegates to qutip.mesolve and QuTiP is not installed; "
+                "Objective.propagate(tlist, propagator=krotov_amd.propagators.expm) runs on the GPU") from exc
+        return qutip.mesolve(H=self.H if H is None else H, rho0=self.initial_state if rho0 is None else rho0,
+                             tlist=tlist, c_ops=self.c_ops if c_ops is None else c_ops,
+                             e_ops=[] if e_ops is None else e_ops, args={} if args is None else args, **kwargs)
+
+    @classmethod
+    def reset_symbol_counters(cls):
+        """Restart the numbering :meth:`summarize` gives to the objects it meets (reference
+        objectives.py:435-443)."""
+        cls._counter = defaultdict(int, {'u{count}(t)': 1})
+        cls._count_cache = {}
+
+    def summarize(self, use_unicode=True, reset_symbol_counters=False):
+        """One-line summary, e.g. ``a₀[2] to a₁[2] via [a₂[2,2], [a₃[2,2], u₁(t)]]`` (reference
+        objectives.py:445-572): every distinct object gets a symbol by category -- ``a`` NumPy arrays, ``u``
+        control functions, and for QuTiP-like objects (``.type``, ``.dims``, ``.isherm``) ``Ψ`` states, ``ρ``
+        density matrices, ``H`` / ``A`` (non-)Hermitian operators, ``𝓛`` super-operators, ``L`` Lindblad
+        operators -- numbered per process in order of first appearance, the same object always with the same
+        number; ``use_unicode=False`` gives the ASCII spelling."""
+        if reset_symbol_counters:
+            self.reset_symbol_counters()
+        cls = type(self)
+        part = lambda obj, role: _summarize_component(obj, role, cls._counter, cls._count_cache, use_unicode)  # noqa: E731
+        res = part(self.initial_state, 'state')
+        if self.target is not None:
+            same_kind = (hasattr(self.initial_state, 'dims') and hasattr(self.target, 'dims')
+                         and self.target.dims == self.initial_state.dims)
+            res += " to " + part(self.target, 'state' if same_kind else 'target')
+        res += " via "
+        if len(self.c_ops) == 0:
+            res += part(self.H, 'op')
+        else:
+            res += '{H:' + part(self.H, 'op') + ', c_ops:(' + ",".join(part(c, 'lindblad') for c in self.c_ops) + ')}'
+        return res
+
+    def __str__(self):
+        return self.summarize(use_unicode=self.str_use_unicode)
+
     def __repr__(self):
-        return "Objective(initial_state=%r, target=%r, H=<%d terms>, c_ops=<%d>)" % (
-            type(self.initial_state).__name__,
-            type(self.target).__name__,
-            len(self.H) if isinstance(self.H, list) else 1,
-            len(self.c_ops),
-        )
+        return "%s[%s]" % (self.__class__.__name__, str(self))
+
+
+def _pattern_of(obj, role, use_unicode):
+    """Category pattern of a component (reference objectives.py:1124-1171), or None for unknown objects."""
+    if callable(obj) and not hasattr(obj, 'dims'):
+        return 'u{count}(t)' if role == 'op' else None
+    if isinstance(obj, np.ndarray):
+        return 'a{count}[{dims}]'
+    kind = getattr(obj, 'type', None)
+    if kind is None or not hasattr(obj, 'dims'):
+        return None
+    if kind == 'ket':
+        return '|Ψ{count}({dims})⟩' if use_unicode else '|Psi{count}({dims})>'
+    if kind == 'bra':
+        return '⟨Ψ{count}({dims})|' if use_unicode else '<Psi{count}({dims})|'
+    if kind == 'oper':
+        if role == 'lindblad':
+            return 'L{count}[{dims}]'
+        if getattr(obj, 'isherm', False):
+            if role == 'state':
+                return 'ρ{count}[{dims}]' if use_unicode else 'rho{count}[{dims}]'
+            return 'H{count}[{dims}]'
+        return 'A{count}[{dims}]'
+    if kind == 'super':
+        return '𝓛{count}[{dims}]' if use_unicode else 'Lv{count}[{dims}]'
+    raise NotImplementedError("Unknown qobj type: %s" % kind)
+
+
+def _dims_of(obj, use_unicode):
+    """Shape / tensor structure of a component as text (reference objectives.py:1174-1200)."""
+    times = '⊗' if use_unicode else '*'
+    kind = getattr(obj, 'type', None)
+    if kind is not None and hasattr(obj, 'dims'):
+        join = lambda dim: times.join("%d" % d for d in dim)  # noqa: E731
+        if kind == 'ket':
+            return join(obj.dims[0])
+        if kind == 'bra':
+            return join(obj.dims[1])
+        if kind == 'oper':
+            return ",".join(join(dim) for dim in obj.dims)
+        if kind == 'super':
+            return ",".join('[%s,%s]' % (join(dim[0]), join(dim[1])) for dim in obj.dims)
+        raise NotImplementedError("Unknown qobj type: %s" % kind)
+    if hasattr(obj, 'shape'):
+        return ",".join(str(int(d)) for d in obj.shape)
+    return None
+
+
+def _summarize_component(obj, role, counter=None, count_cache=None, use_unicode=True):
+    """Text of one component of an objective (reference objectives.py:1203-1309)."""
+    from .result import ControlPlaceholder
+
+    if role not in ('state', 'target', 'op', 'lindblad'):
+        raise ValueError("Unknown %s not in %s" % (role, ['state', 'target', 'op', 'lindblad']))
+    counter = Objective._counter if counter is None else counter
+    count_cache = Objective._count_cache if count_cache is None else count_cache
+    if isinstance(obj, list):
+        return '[' + ", ".join(_summarize_component(o, role, counter, count_cache, use_unicode) for o in obj) + ']'
+    if isinstance(obj, (ControlPlaceholder, float, complex)):
+        return str(obj)
+    pattern = _pattern_of(obj, role, use_unicode)
+    if pattern is None:  # unknown object: its own text, on one line, truncated to 40 characters
+        res = str(obj).replace("\n", " ")
+        if len(res) > 40:
+            res = res[:39] + "…" if use_unicode else res[:37] + "..."
+        return res
+    key = id(obj)  # the same OBJECT keeps its number; equal copies get new ones
+    if key in count_cache:
+        count = count_cache[key]
+    else:
+        count = counter[pattern]
+        count_cache[key] = count
+        counter[pattern] += 1
+        if pattern == 'A{count}[{dims}]':  # Hermitian and non-Hermitian operators share one numbering
+            counter['H{count}[{dims}]'] += 1
+        elif pattern == 'H{count}[{dims}]':
+            counter['A{count}[{dims}]'] += 1
+    count_str = str(count)
+    if use_unicode:
+        count_str = "".join(chr(ord(d) - ord('0') + 0x2080) for d in count_str)
+    return pattern.format(count=count_str, dims=_dims_of(obj, use_unicode))
 
 
 def _operator_like(x):

@@ -415,6 +415,63 @@ def make_print_debug_cases():
     print(out.getvalue())
 
 
+def summarize_cases(objective_cls, make_q):
+    """Texts of Objective.summarize for objectives of NumPy arrays and of QuTiP-like objects (shared with
+    tests/test_reference_unit_cases.py).  ``make_q(type, dims, isherm)`` builds a QuTiP-like object."""
+    lines = []
+    u1, u2 = (lambda t, args: 1.0), (lambda t, args: 1.0)
+    a1, a2 = np.zeros(100, dtype=complex), np.ones(100, dtype=complex)
+    # NumPy mode
+    H = [np.eye(4, dtype=complex), [np.ones((4, 4), dtype=complex), u1], [np.zeros((4, 4), dtype=complex), u2]]
+    psi0, psi1 = np.zeros(4, dtype=complex), np.ones(4, dtype=complex)
+    C1, C2 = [[np.eye(4), a1]], [[np.eye(4) * 2, a2]]
+    obj = objective_cls(initial_state=psi0, target=psi1, H=H)
+    obj.reset_symbol_counters()
+    lines.append(obj.summarize())
+    obj2 = objective_cls(initial_state=psi0, target=psi1, H=H, c_ops=[C1, C2])
+    lines.append(obj2.summarize())
+    lines.append(obj2.summarize(use_unicode=False))
+    lines.append(str(obj2))
+    lines.append(repr(obj))
+    # QuTiP-like components
+    ket = lambda: make_q('ket', [[2, 2], [1, 1]], False)  # noqa: E731
+    oper = lambda herm: make_q('oper', [[2, 2], [2, 2]], herm)  # noqa: E731
+    sup = lambda: make_q('super', [[[2, 2], [2, 2]], [[2, 2], [2, 2]]], False)  # noqa: E731
+    k0, k1 = ket(), ket()
+    Hq = [oper(True), [oper(True), u1], [oper(False), u2]]
+    obj3 = objective_cls(initial_state=k0, target=k1, H=Hq, c_ops=[[[oper(False), a1]], oper(False)])
+    lines.append(obj3.summarize(reset_symbol_counters=True))
+    lines.append(obj3.summarize(use_unicode=False))
+    rho0, rho1 = oper(True), oper(True)
+    obj4 = objective_cls(initial_state=rho0, target=rho1, H=[sup(), [sup(), u1]])
+    lines.append(obj4.summarize())
+    lines.append(objective_cls(initial_state=k0, target='PE', H=Hq).summarize())
+    lines.append(objective_cls(initial_state=make_q('bra', [[1, 1], [2, 2]], False), target=None,
+                               H=[Hq[0], [Hq[1][0], 0.5]]).summarize(use_unicode=False))
+    return lines
+
+
+def make_summarize_cases():
+    """Text of the reference's own ``Objective.summarize`` / ``str`` / ``repr`` for the cases above ->
+    tests/golden/summarize_cases.txt (QuTiP-like objects: instances of a subclass of the stubbed qutip.Qobj)."""
+    krotov = import_reference_krotov()
+    import qutip
+
+    class FakeQ(qutip.Qobj):
+        def __new__(cls, *a, **k):
+            return object.__new__(cls)
+
+    def make_q(kind, dims, isherm):
+        q = FakeQ()
+        q.type, q.dims, q.isherm = kind, dims, isherm
+        return q
+
+    lines = summarize_cases(krotov.Objective, make_q)
+    with open(os.path.join(HERE, 'summarize_cases.txt'), 'w', encoding='utf8') as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
 def make_c5_full():
     """Headline configuration through the real reference loop: 1 iteration
     (~2.5 sweeps * 256 * 4000 props at ~0.8 ms each => ~35 min, one core)."""
@@ -440,6 +497,8 @@ if __name__ == '__main__':
         make_print_table_cases()
     if 'print_debug' in what:
         make_print_debug_cases()
+    if 'summarize' in what:
+        make_summarize_cases()
     for w in what:
         if w in REF_CASES:
             make_ref_fixtures([w])

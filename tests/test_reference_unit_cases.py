@@ -5,6 +5,8 @@ test_overlap.py (file:line given per test)."""
 import logging
 from functools import partial
 
+import os
+
 import numpy as np
 import pytest
 
@@ -412,6 +414,34 @@ def test_derivative_wrt_pulse_cases():
         derivative_wrt_pulse(objs, 0, controls, mapping, i_pulse=0, time_index=0)
     mu = derivative_wrt_pulse(objs, 1, controls, mapping, i_pulse=1, time_index=0)
     assert np.abs(mu(k1) - sz @ k1).max() == 0
+
+
+def test_objective_summarize_text():
+    """Objective.summarize / str / repr (reference objectives.py:445-578 and its doctests; the scenarios of
+    tests/test_objectives.py:559-651): the same text as the reference's own implementation writes for objectives
+    of NumPy arrays and of QuTiP-like objects (tests/golden/summarize_cases.txt, made by
+    make_reference_goldens.py summarize), the same object always with the same number, copies with new ones."""
+    import copy
+    import importlib.util
+    golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    spec = importlib.util.spec_from_file_location('make_goldens', os.path.join(golden_dir, 'make_reference_goldens.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class FakeQ:  # what the summary looks at in a qutip.Qobj
+        def __init__(self, kind, dims, isherm):
+            self.type, self.dims, self.isherm = kind, dims, isherm
+            self.shape = (4, 1 if kind == 'ket' else 4)
+
+    got = mod.summarize_cases(krotov_amd.Objective, FakeQ)
+    want = open(os.path.join(golden_dir, 'summarize_cases.txt'), encoding='utf8').read().splitlines()
+    assert got == want
+    obj = krotov_amd.Objective(initial_state=np.zeros(2), target=np.ones(2), H=[np.eye(2), [np.eye(2), lambda t, a: 0]])
+    first = obj.summarize(reset_symbol_counters=True)
+    assert obj.summarize() == first  # same objects, same numbers
+    assert copy.deepcopy(obj).summarize() != first  # new objects, new numbers
+    assert copy.deepcopy(obj).summarize(reset_symbol_counters=True) == first
+    krotov_amd.Objective.reset_symbol_counters()
 
 
 def test_gate_objectives_single_qubit_gate():
