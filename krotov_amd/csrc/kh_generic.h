@@ -135,14 +135,21 @@ __device__ __forceinline__ int kh_gen_expm_action(const KhSweepArgs &p, const cp
     for (int l = 0; l < L; ++l) theta += fabs(eps[l]) * norms_k[1 + l];
     theta *= dt;
     int nsub, m;
-    kh_degree_lookup(theta, p.deg_theta, p.theta_max, p.inv_theta_max, 12, &nsub, &m);
-    const double h = dt / nsub;
+    // thresholds and term ratios of the engine's series (kh_common.h, "Series coefficients": Taylor, or the
+    // shorter real-spectrum series when every operator is Hermitian)
+    kh_degree_lookup(theta, p.q2_theta, p.theta_max, p.inv_theta_max, 12, &nsub, &m);
+    const double *ratio = p.ratios + (size_t)m * KH_RATIO_STRIDE;
+    const double h = dt / nsub, c0 = ratio[0];
     for (int sub = 0; sub < nsub; ++sub) {
-        for (int i = tid; i < N; i += KH_GEN_THREADS) s.xa[i] = s.acc[i];
+        for (int i = tid; i < N; i += KH_GEN_THREADS) {
+            const cplx v = s.acc[i];
+            s.xa[i] = v;  // the chain starts from v itself, the sum from T_0 = c_0 v
+            s.acc[i] = c_make(c0 * v.x, c0 * v.y);
+        }
         __syncthreads();
         cplx *xin = s.xa, *xout = s.xb;
         for (int j = 1; j <= m; ++j) {
-            const double hj = h * kh_inv_table[j];
+            const double hj = h * ratio[j];
             const cplx coef = c_make(p.fre * hj, p.fim * hj);
             for (int row0 = 0; row0 < N; row0 += 16) {
                 const int row = row0 + grp;

@@ -464,8 +464,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         }
         KH_HIP_E(hipGetLastError());
     }
-    auto is_tile = [](int kind) { return kind == KIND_TILE_Q2 || kind == KIND_TILE_RPT1 || kind == KIND_TILE_RPT2; };
-    if (is_tile(e->kind) || is_tile(e->kind_store)) {
+    {  // (every kernel family but the cooperative one reads the series tables)
         std::vector<double> tab(KH_MAX_DEGREE + 1), c0(KH_MAX_DEGREE + 1), rows((size_t)(KH_MAX_DEGREE + 1) * KH_Q2_ROWS * 2),
             ratios((size_t)(KH_MAX_DEGREE + 1) * KH_RATIO_STRIDE);
         if (e->real_spectrum) {
