@@ -278,6 +278,16 @@ int kh_check(kh_engine *engine);
  * sweep, so kernels count them), stats[1] = intervals, stats[2] = workgroups. */
 int kh_last_stats(kh_engine *engine, double stats[4]);
 
+/* The coefficient tables the kernels evaluate exp(f A dt) v with (host only, no GPU needed; for inspection
+ * and tests).  The series is sum_j c_j (f A dt)^j v with real c_j; for every degree m <= 64:
+ *   theta[m]            largest ||A dt|| the degree serves at tolerance `tol` (tol <= 0: 2^-53),
+ *   ratios[m*65 + 0]    c_0,   ratios[m*65 + 1] = c_1,   ratios[m*65 + j] = c_j / c_{j-1}  (j = 2..m).
+ * real_spectrum = 0: Taylor (c_j = 1/j!, any generator; replaces SciPy's Pade expm behind
+ * krotov.propagators.expm, propagators.py:100-117).  real_spectrum = 1: what an engine uses when every
+ * operator equals its own adjoint and f = -+i: the truncated Chebyshev series of exp(-+i theta x) on [-1, 1]
+ * in powers of (-+i theta x), even degrees only, theta <= 2 (Taylor beyond). */
+int kh_series_tables(int32_t real_spectrum, double tol, double *theta /* [65] */, double *ratios /* [65*65] */);
+
 #ifdef __cplusplus
 }
 #endif

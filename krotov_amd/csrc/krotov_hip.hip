@@ -1059,6 +1059,20 @@ extern "C" int kh_check(kh_engine *e) {
     return KH_OK;
 }
 
+extern "C" int kh_series_tables(int32_t real_spectrum, double tol, double *theta, double *ratios) {
+    if (theta == nullptr || ratios == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
+    static_assert(KH_MAX_DEGREE == 64 && KH_RATIO_STRIDE == 65, "documented table sizes");
+    if (!(tol > 0.0)) tol = ldexp(1.0, -53);
+    std::vector<double> c0(KH_MAX_DEGREE + 1), rows((size_t)(KH_MAX_DEGREE + 1) * KH_Q2_ROWS * 2);
+    if (real_spectrum) {
+        kh_build_real_spectrum_rows(tol, theta, c0.data(), rows.data(), ratios);
+    } else {
+        kh_build_degree_table(tol, theta);
+        kh_build_taylor_rows(c0.data(), rows.data(), ratios);
+    }
+    return KH_OK;
+}
+
 extern "C" int kh_last_stats(kh_engine *e, double stats[4]) {
     if (e == nullptr || stats == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
     double d[4] = {0, 0, 0, 0};

@@ -51,3 +51,54 @@ def test_bad_arguments_are_reported_not_crashed():
                  lambda: lib.kh_tau(None, None, None, None, None)):
         assert call() == -1
         assert lib.kh_last_error() != b''
+
+
+def test_series_tables_evaluate_the_exponential():
+    """kh_series_tables (host code of the library, no GPU): the coefficient tables the kernels use.  Taylor:
+    ratios 1/j, degree 14 at theta = 0.5.  Real-spectrum series: fewer terms at the same
+    tolerance (degree 12 at theta = 0.5, 14 at theta = 1), thresholds non-decreasing, and -- the point -- the
+    polynomial sum_j c_j (-i A)^j v reproduces exp(-i A) v to rounding for Hermitian A with ||A|| = theta[m],
+    evaluated exactly the way the two-terms-per-phase kernels do (A^2 chain + one product with A)."""
+    import ctypes
+
+    import numpy as np
+    import scipy.linalg
+
+    lib = _lib.load()
+    theta_t, ratios_t = (ctypes.c_double * 65)(), (ctypes.c_double * (65 * 65))()
+    theta_c, ratios_c = (ctypes.c_double * 65)(), (ctypes.c_double * (65 * 65))()
+    assert lib.kh_series_tables(0, 0.0, theta_t, ratios_t) == 0
+    assert lib.kh_series_tables(1, 0.0, theta_c, ratios_c) == 0
+    assert lib.kh_series_tables(1, 0.0, None, ratios_c) == -1
+    tt, tc = np.array(theta_t), np.array(theta_c)
+    rt, rc = np.array(ratios_t).reshape(65, 65), np.array(ratios_c).reshape(65, 65)
+    assert np.all(np.diff(tt) >= 0) and np.all(np.diff(tc) >= 0)
+    assert np.all(rt[:, 0] == 1.0) and np.allclose(rt[20, 1:21], 1.0 / np.arange(1, 21), rtol=0, atol=0)
+    degree = lambda tab, th: int(np.argmax(tab >= th))  # noqa: E731  smallest m with th <= tab[m]
+    assert degree(tt, 0.5) == 14 and degree(tt, 1.0) == 18
+    assert degree(tc, 0.5) == 12 and degree(tc, 1.0) == 14
+    assert np.all(tc[2:19:2] > tt[2:19:2])  # every even degree up to 18 serves a larger norm
+    rng = np.random.default_rng(3)
+    N = 24
+    G = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    Hm = (G + G.conj().T) / 2
+    Hm /= np.linalg.norm(Hm, 2)
+    v = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    v /= np.linalg.norm(v)
+    for m in (8, 10, 12, 14, 16):
+        A = Hm * tc[m]
+        c = np.cumprod(np.concatenate([[rc[m, 0], rc[m, 1] / rc[m, 0]], rc[m, 2:m + 1]]))  # c_0 .. c_m
+        assert abs(c[0] - 1) < 1e-15 and np.allclose(c, 1 / np.array([scipy.special.factorial(j) for j in range(m + 1)]),
+                                                     rtol=1e-3)
+        B, f = A @ A, -1j
+        state, term, s = c[0] * v, c[0] * v, c[1] * v
+        for p in range(m // 2):
+            term = (c[2 * p + 2] / c[2 * p]) * (f * f) * (B @ term)
+            state = state + term
+            if 2 * p + 3 <= m:
+                s = s + (c[2 * p + 3] / c[2 * p + 2]) * term
+        state = state + f * (A @ s)
+        assert np.linalg.norm(state - scipy.linalg.expm(-1j * A) @ v) < 6e-16, m
+        # the Taylor polynomial of the same degree is NOT good enough at this norm
+        taylor = sum(np.linalg.matrix_power(-1j * A, j) @ v / scipy.special.factorial(j) for j in range(m + 1))
+        assert np.linalg.norm(taylor - scipy.linalg.expm(-1j * A) @ v) > 3e-15, m
