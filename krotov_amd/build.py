@@ -6,9 +6,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, 'csrc', 'krotov_hip.hip')
-DEPS = [os.path.join(HERE, 'csrc', f) for f in ('kh_common.h', 'kh_generic.h', 'kh_tile64.h', 'kh_tile64q2.h')] + [
-    os.path.join(ROOT, 'include', 'krotov_hip.h')
-]
+
+
+def _deps():
+    """Everything the library is compiled from: every header under csrc/ (globbed, so a new kernel file
+    cannot be forgotten) and the public C header."""
+    import glob
+
+    return sorted(glob.glob(os.path.join(HERE, 'csrc', '*.h'))) + [os.path.join(ROOT, 'include', 'krotov_hip.h')]
+
+
 OUT = os.path.join(HERE, 'libkrotov_hip.so')
 
 
@@ -21,8 +28,10 @@ def _hipcc():
 
 def build(force=False, verbose=False):
     """Compile the HIP kernels + C ABI for gfx950 if the library is stale."""
-    srcs = [SRC] + DEPS
+    srcs = [SRC] + _deps()
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs):
+        if verbose:
+            print('krotov_amd.build: %s is up to date (reused)' % OUT, file=sys.stderr)
         return OUT
     cmd = [
         _hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
@@ -31,6 +40,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    if verbose:
+        print('krotov_amd.build: compiled %s' % OUT, file=sys.stderr)
     return OUT
 
 

@@ -382,7 +382,9 @@ class HipKrotovEngine:
 
         with self._timed('update'):
             done = False
-            if graph_chunk > 0 and nt - 1 > 2 * graph_chunk:
+            # (second order: kh_update_step_dev bakes the trajectory / sigma pointers of kh_set_second_order
+            # into the captured launches, and those buffers are swapped every iteration -- no replay there)
+            if graph_chunk > 0 and nt - 1 > 2 * graph_chunk and self._so is None:
                 try:
                     stepper = _Stepper()
                     stepper.begin()

@@ -37,4 +37,16 @@ def derivative_wrt_pulse(objectives, i_objective, pulses, pulses_mapping, i_puls
     if hasattr(total, 'full') or callable(total):
         return total  # Qobj-like: callable on states
     dense = to_dense(total)
-    return lambda state: dense @ np.asarray(state)
+    if is_super:
+        return lambda state: dense @ np.asarray(state)
+
+    def apply(state):
+        # array-typed operators carry no `.type`: Liouville space is recognised the way the device path
+        # does it -- a square d x d density matrix under an operator of dimension d^2 -- and then
+        # mu = i dL/d(eps) acts on the column-stacked vec(rho) (reference mu.py:130-134, propagators.py:307)
+        st = np.asarray(state)
+        if st.ndim == 2 and st.shape[0] == st.shape[1] and st.size == dense.shape[0] and st.shape[0] > 1:
+            return (1j * (dense @ st.ravel('F'))).reshape(st.shape, order='F')
+        return dense @ st
+
+    return apply

@@ -327,6 +327,11 @@ class _LazyStates:
     def __iter__(self):
         return (self[k] for k in range(len(self)))
 
+    def __reduce__(self):
+        # pickled (Result.dump from a check_convergence hook, copy.deepcopy) as the plain list of states
+        # it stands for: the fetch closure holds device tensors and must not travel
+        return (list, (list(self),))
+
 
 class _DeviceTrajectory:
     """States of one objective on the time grid, one device row per access."""
@@ -416,8 +421,10 @@ class _HipBackend:
             self.world = dist.get_world_size(process_group)
         # contiguous shard of objectives for this rank
         self.k0, self.k1 = shard_range(K_total, self.world, self.rank)
-        if self.k1 <= self.k0:
-            raise ValueError("rank %d has no objectives (K=%d, world=%d)" % (self.rank, K_total, self.world))
+        if K_total < self.world:
+            # the same error on EVERY rank, before any collective (a lone raising rank would leave the
+            # others hanging in the first all-gather)
+            raise ValueError("%d objectives cannot be sharded over %d ranks" % (K_total, self.world))
         self.K_total = K_total
         L = n_controls
         dense = {}

@@ -22,10 +22,13 @@ __all__ = ['shard_range', 'gather_rows', 'run_update_loop']
 
 
 def shard_range(K, world, rank):
-    """Contiguous block ``[k0, k1)`` of the ``K`` objectives owned by ``rank``."""
-    per = (K + world - 1) // world
-    k0 = min(rank * per, K)
-    return k0, min(k0 + per, K)
+    """Contiguous block ``[k0, k1)`` of the ``K`` objectives owned by ``rank``.
+
+    Balanced: the first ``K % world`` ranks own one objective more, so no rank is empty whenever
+    ``K >= world`` (K = 5 over 4 ranks is 2 + 1 + 1 + 1, not 2 + 2 + 1 + 0)."""
+    base, extra = divmod(K, world)
+    k0 = rank * base + min(rank, extra)
+    return k0, k0 + base + (1 if rank < extra else 0)
 
 
 def gather_rows(local, K, world, group, device):
@@ -46,7 +49,8 @@ def gather_rows(local, K, world, group, device):
     send = torch.from_numpy(np.ascontiguousarray(pad)).to(device)
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send, group=group)
-    return np.concatenate([r.cpu().numpy() for r in recv], axis=0)[:K]
+    sizes = [shard_range(K, world, r) for r in range(world)]
+    return np.concatenate([r.cpu().numpy()[: k1 - k0] for r, (k0, k1) in zip(recv, sizes)], axis=0)
 
 
 def run_update_loop(stepper, n_intervals, all_reduce):
