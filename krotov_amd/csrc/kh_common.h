@@ -408,6 +408,52 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
     return true;
 }
 
+// The gather for ONE control, spread over the WAVES waves of the workgroup and split in two halves: every wave
+// takes 256 / WAVES slots, one slot (two granules) per lane.  kh_gather_part_begin issues the loads -- they are in
+// flight while the caller does other work -- and kh_gather_part_end checks them, polls on if a producer was late,
+// and returns the wave's partial sum (lanes in a fixed order).  The caller adds the WAVES partial sums in wave
+// order after a barrier, so every workgroup derives the bit-identical total.  At most 256 workgroups.
+struct KhGatherPart {
+    kh_u64 a, b;
+};
+template <int WAVES>
+__device__ __forceinline__ void kh_gather_part_begin(const KhExchange &ex, int parity, unsigned int epoch, int wave,
+                                                     int lane, KhGatherPart &g) {
+    constexpr int SPW = 256 / WAVES;
+    const kh_u64 *base = ex.slots + (size_t)parity * ex.G * 2;
+    const int wg = wave * SPW + lane;
+    const bool live = lane < SPW && wg < ex.G;
+    const int wgc = live ? wg : 0;  // (branch-free: idle lanes re-read slot 0 and substitute the neutral granule)
+    const kh_u64 va = __hip_atomic_load(base + (size_t)wgc * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const kh_u64 vb = __hip_atomic_load(base + (size_t)wgc * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g.a = live ? va : (kh_u64)epoch << 32;
+    g.b = live ? vb : (kh_u64)epoch << 32;
+}
+template <int WAVES>
+__device__ __forceinline__ bool kh_gather_part_end(const KhExchange &ex, int parity, unsigned int epoch, int wave, int lane,
+                                                   KhGatherPart g, double *partial) {
+    const long long t0 = wall_clock64();
+    unsigned int spins = 0;
+    for (;;) {
+        const bool ok = ((unsigned int)(g.a >> 32) == epoch) && ((unsigned int)(g.b >> 32) == epoch);
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0) {  // wave-uniform
+            const bool gave_up =
+                (wall_clock64() - t0 > ex.timeout_ticks) ||
+                (__hip_atomic_load(ex.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+            if (__any(gave_up)) {
+                if (lane == 0) __hip_atomic_store(ex.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        kh_gather_part_begin<WAVES>(ex, parity, epoch, wave, lane, g);
+    }
+    const kh_u64 bits = ((g.a & 0xffffffffull) << 32) | (g.b & 0xffffffffull);
+    *partial = sum64(__longlong_as_double((long long)bits));  // (idle lanes hold +0.0)
+    return true;
+}
+
 // ---- cross-GPU stage -------------------------------------------------------
 __device__ __forceinline__ void kh_p2p_publish(const KhExchange &ex, int parity, int L, int lane,
                                                const double *values, unsigned int epoch) {

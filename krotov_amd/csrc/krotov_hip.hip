@@ -21,6 +21,7 @@
 #include "kh_generic.h"
 #include "kh_tile64.h"
 #include "kh_tile64q2.h"
+#include "kh_tile64mm.h"
 #include "kh_coop.h"
 #include "kh_mini.h"
 
@@ -74,7 +75,7 @@ struct kh_engine {
     cplx *d_phi = nullptr;            // [K][N]
     kh_u64 *d_slots = nullptr;        // [2][G][L][2]
     unsigned int *d_abort = nullptr;
-    double *d_stats = nullptr;        // [4]
+    double *d_stats = nullptr;        // [4] (+ 64 trace stamps behind them in a KH_TIMING build)
     double *d_wg_partial = nullptr;   // [G][L]
     const double *guess_dev = nullptr;  // remembered by kh_update_begin
     // second-order update (kh_set_second_order); all NULL = first order
@@ -98,6 +99,10 @@ struct kh_engine {
     int coop_poll_delay = 12;  // KH_COOP_DELAY: the same for the cooperative kernels' block exchange
     double adj_sign = 0.0;  // +1 / -1: every control operator equals +/- its adjoint exactly (else 0)
     bool real_spectrum = false;  // every operator Hermitian (bit for bit) and f = -+i
+    bool hermitian = false;      // the same, whichever series tables are in use (KH_TAYLOR): kh_tile64mm.h
+    int mm_nio = 2;              // 4-row blocks per wave of that kernel: 2 -> 8 waves (KH_MM_WAVES=4: 4 -> 4 waves)
+    bool use_mm = false;         // KH_MM=1: the matrix-core update kernel (kh_tile64mm.h) instead of the vector-FMA one
+    double *d_mm_tab = nullptr;  // [KH_MAX_DEGREE+1][KH_MM_TAB_STRIDE] coefficient rows of the two-chain form
     bool mini = false;           // kind q2, N <= 16, K <= 8: the one-wave-per-objective kernels (kh_mini.h)
     bool quad = false;           // mini with N <= 4, K <= 4: the whole problem in one wave
     double *d_q2_theta = nullptr, *d_q2_c0 = nullptr, *d_q2_rows = nullptr, *d_ratios = nullptr;  // series tables of the register-tile kernels
@@ -170,6 +175,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_q2_c0);
     (void)hipFree(e->d_q2_rows);
     (void)hipFree(e->d_ratios);
+    (void)hipFree(e->d_mm_tab);
     (void)hipFree(e->d_csr_fw);
     (void)hipFree(e->d_csr_bw);
     (void)hipFree((void *)e->d_coop_fops_fw);
@@ -275,6 +281,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         e->adj_sign = flags[0] == 0 ? 1.0 : (flags[1] == 0 ? -1.0 : 0.0);
         // every generator Hermitian and f = -+i: real spectrum (the q2 kernels' shorter series, kh_common.h)
         e->real_spectrum = flags[0] == 0 && flags[2] == 0 && !e->is_super;
+        e->hermitian = e->real_spectrum;
+        if (const char *d = getenv("KH_MM")) e->use_mm = atoi(d) != 0;
         if (const char *d = getenv("KH_TAYLOR"))  // A/B switch: plain Taylor coefficients everywhere
             if (atoi(d) != 0) e->real_spectrum = false;
         if (const char *d = getenv("KH_NO_ADJ"))  // A/B switch: keep <chi|H phi> on the forward side
@@ -481,6 +489,17 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         KH_HIP_E(hipMemcpy(e->d_q2_theta, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
         KH_HIP_E(hipMemcpy(e->d_q2_c0, c0.data(), sizeof(double) * c0.size(), hipMemcpyHostToDevice));
         KH_HIP_E(hipMemcpy(e->d_q2_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
+        if (e->kind == KIND_TILE_Q2 && e->hermitian) {
+            std::vector<double> mm((size_t)(KH_MAX_DEGREE + 1) * KH_MM_TAB_STRIDE);
+            kh_build_mm_tab(c0.data(), rows.data(), mm.data());
+            KH_HIP_E(hipMalloc(&e->d_mm_tab, sizeof(double) * mm.size()));
+            KH_HIP_E(hipMemcpy(e->d_mm_tab, mm.data(), sizeof(double) * mm.size(), hipMemcpyHostToDevice));
+            KH_HIP_E(hipFuncSetAttribute((const void *)kh_mm_forward_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kh_mm_lds_bytes()));
+            KH_HIP_E(hipFuncSetAttribute((const void *)kh_mm_forward_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kh_mm_lds_bytes()));
+            if (const char *d = getenv("KH_MM_WAVES")) e->mm_nio = atoi(d) == 4 ? 4 : 2;
+        }
     }
     if (e->kind == KIND_TILE_Q2) {
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -503,8 +522,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     KH_HIP_E(hipMalloc(&e->d_slots, e->slots_bytes));
     KH_HIP_E(hipMalloc(&e->d_abort, sizeof(unsigned int)));
     KH_HIP_E(hipMemset(e->d_abort, 0, sizeof(unsigned int)));
-    KH_HIP_E(hipMalloc(&e->d_stats, sizeof(double) * 4));
-    KH_HIP_E(hipMemset(e->d_stats, 0, sizeof(double) * 4));
+    KH_HIP_E(hipMalloc(&e->d_stats, sizeof(double) * 68));
+    KH_HIP_E(hipMemset(e->d_stats, 0, sizeof(double) * 68));
     KH_HIP_E(hipMalloc(&e->d_wg_partial, sizeof(double) * (size_t)e->grid_update * Lx));
     KH_HIP_E(hipDeviceSynchronize());
 #undef KH_HIP_E
@@ -721,6 +740,15 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             kh_mini_forward_update<true><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
         else
             kh_mini_forward_update<false><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
+    } else if (e->kind == KIND_TILE_Q2 && !stepwise && u.sigma == nullptr && u.adj_sign == 1.0 && e->hermitian && p.fre == 0.0 && p.fim == -1.0 &&
+               e->use_mm && e->d_mm_tab != nullptr && u.n_begin == 0 && u.n_end == e->nt - 1) {
+        // first order, Hermitian operators: matrix-core kernel with the exchange hidden behind half the series
+        KhExchange exa = ex;
+        exa.first_poll_delay = e->adj_poll_delay;
+        if (e->mm_nio == 2)
+            kh_mm_forward_update<2><<<e->K, KhMm<2>::THREADS, kh_mm_lds_bytes(), st>>>(p, e->d_sq_fw, u, exa, e->d_mm_tab);
+        else
+            kh_mm_forward_update<4><<<e->K, KhMm<4>::THREADS, kh_mm_lds_bytes(), st>>>(p, e->d_sq_fw, u, exa, e->d_mm_tab);
     } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
         if (u.sigma != nullptr)
             kh_q2_forward_update<true, false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
@@ -1082,9 +1110,17 @@ extern "C" int kh_last_stats(kh_engine *e, double stats[4]) {
     stats[2] = e->last_wgs;
     stats[3] = 0.0;
 #ifdef KH_TIMING
+    stats[0] = d[0];
     stats[1] = d[1];
     stats[2] = d[2];
     stats[3] = d[3];
+    if (getenv("KH_TRACE")) {  // per-point clock stamps of one interval of workgroup 0 (kernels that record them)
+        double tr[64];
+        KH_HIP(hipMemcpy(tr, e->d_stats + 4, sizeof(tr), hipMemcpyDeviceToHost));
+        fprintf(stderr, "KH_TRACE (cycles since the interval's start):");
+        for (int i = 0; i < 64 && (i == 0 || tr[i] != 0.0); ++i) fprintf(stderr, " %d:%.0f", i, tr[i] - tr[0]);
+        fprintf(stderr, "\n");
+    }
 #endif
     return KH_OK;
 }

@@ -384,7 +384,7 @@ class HipKrotovEngine:
             done = False
             # (second order: kh_update_step_dev bakes the trajectory / sigma pointers of kh_set_second_order
             # into the captured launches, and those buffers are swapped every iteration -- no replay there)
-            if graph_chunk > 0 and nt - 1 > 2 * graph_chunk and self._so is None:
+            if graph_chunk > 0 and nt - 1 > 2 * graph_chunk and getattr(self, '_so', None) is None:
                 try:
                     stepper = _Stepper()
                     stepper.begin()

@@ -29,3 +29,6 @@ ms = min(eng.kernel_times_ms()['update'])
 n = nt - 1
 print('%s K=%d update %.2f ms (%.2f us/interval); ticks/interval: exchange %.0f  build+phases %.0f  partial %.0f' % (
     eng.kernel, K, ms, ms * 1e3 / n, buf[1] / n, buf[2] / n, buf[3] / n))
+if buf[0] < 0:  # matrix-core kernel (kh_tile64mm.h): its own four stamps
+    print('  mm kernel, cycles/interval: rebuild %.0f | tiles -> partial sum %.0f | tiles -> last product %.0f | exchange wait %.0f' % (
+        -buf[0] / n, buf[1] / n, buf[2] / n, buf[3] / n))
