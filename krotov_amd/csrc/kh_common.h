@@ -66,6 +66,7 @@ __device__ __forceinline__ double dpp_move(double v) {
 #define KH_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i within each 8 lanes
 #define KH_DPP_MIRROR 0x140      // lane i <-> 15-i within each 16-lane row
 #define KH_DPP_ROR8 0x128        // lane i <- lane (i + 8) % 16 within each 16-lane row
+#define KH_DPP_ROR4 0x124        // lane i <- lane (i + 4) % 16 within each 16-lane row
 
 // all-reduce (sum) over groups of 4 / 8 / 16 adjacent lanes; every lane of the
 // group ends up with the same value, summed in the same order.

@@ -36,6 +36,9 @@
 #include "kh_tile64.h"
 #include "kh_tile64q2.h"
 
+#include <type_traits>
+#include <utility>
+
 #define KH_MM_XLEN 256                      // doubles of one vector pair in operand order
 #define KH_MM_TAB_ROWS (KH_Q2_ROWS + 1)     // per product t: {scale, c1, c2, -} per lane kind; last row: start values
 #define KH_MM_TAB_STRIDE (KH_MM_TAB_ROWS * 2 * 4)  // doubles per degree
@@ -46,7 +49,6 @@
 #else
 #define KH_MM_TRACE(i) do { } while (0)
 #endif
-#define KH_DPP_ROR4 0x124   // lane i <- lane (i + 4) % 16 within each 16-lane row
 #define KH_DPP_REV4 0x1B    // quad_perm [3,2,1,0]
 
 // Host: the per-degree coefficient rows of the two-chain form, from the series' c0 / rows tables
@@ -121,6 +123,17 @@ __device__ __forceinline__ KhMmLds kh_mm_carve(char *smem) {
     s.tab = s.gsum + 16;
     s.deg = s.tab + KH_MM_TAB_STRIDE;
     return s;
+}
+
+// f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>): a loop whose index is a constant
+// expression inside the body (the unrolled interval below selects its work with `if constexpr`)
+template <class F, int... I>
+__device__ __forceinline__ void kh_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void kh_static_for(F &&f) {
+    kh_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // NIO = 4-row blocks per wave: 2 -> 8 waves (two per SIMD, 256 registers each), 4 -> 4 waves (one per SIMD, 512)
@@ -522,7 +535,118 @@ kh_mm_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         t_build += tq1 - tq0;
         KH_MM_TRACE(2);
 #endif
-        for (int sub = 0; sub < nsub; ++sub) {
+        // ---- the common interval, unrolled: one sub-step, a partial sum due, P products with P known at compile
+        // time -- every decision the generic loop below takes per product is a constant here
+        auto fast_interval = [&](auto Pc) {
+            constexpr int P = decltype(Pc)::value, Pf = (P + 1) / 2;
+            double acc1[NIO], acc2[NIO], yS[NIO], wF[NIO];
+#pragma unroll
+            for (int io = 0; io < NIO; ++io) {
+                acc1[io] = ini.x * own[io];
+                acc2[io] = (h * ini.y) * own[io];
+            }
+            kh_static_for<P>([&](auto Tc) {
+                constexpr int t = decltype(Tc)::value;
+                constexpr int xin = t == 0 ? 0 : 1 + ((t - 1) & 1), xout = 1 + (t & 1);
+                double x[4], y[NIO];
+                kh_mm_readx(s.x0 + xin * KH_MM_XLEN, lane, x);
+                const double *tb = s.tab + (size_t)(t * 2 + kind) * 4;
+                const double2 tb01 = *(const double2 *)tb;
+                const double c2t = tb[2];
+                kh_mm_pass<NIO>(B, x, sgn, y);
+                const double sc = mh2 * tb01.x, hc = h * c2t;
+#pragma unroll
+                for (int io = 0; io < NIO; ++io) {
+                    y[io] *= sc;
+                    acc1[io] = fma(tb01.y, y[io], acc1[io]);
+                    acc2[io] = fma(hc, y[io], acc2[io]);
+                }
+                if constexpr (t + 1 < Pf) {  // the w chain takes its injection a_q w + h b_q conj(f) w'
+                    double out[NIO];
+#pragma unroll
+                    for (int io = 0; io < NIO; ++io) out[io] = isF ? y[io] : fma(hc, g2[io], fma(tb01.y, own[io], y[io]));
+                    put(xout, true, out);
+                } else if constexpr (t + 1 < P) {
+                    put(xout, true, y);
+                }
+                if constexpr (t == P - 2) put(KH_MM_SLOT_XS + par, isF, acc2);  // s is complete
+                if constexpr (t == 0) {
+                    put(KH_MM_SLOT_XH + par, isF, chin);  // chi(t_{n+3}), loaded an interval ago
+                    if (n + 1 < nt - 1) {  // (issued here, read at the end of the interval: never waited for)
+                        dt_ld = p.dt[n + 1];
+                        guess_ld = u.guess[n + 1];
+                        shape_ld = u.shape[n + 1];
+                    }
+                }
+                if constexpr (t == Pf - 1) {  // Im <w | phi(t_{n+1})> from the two half chains
+                    double v = 0.0;
+#pragma unroll
+                    for (int io = 0; io < NIO; ++io) {
+                        const double wrev = dpp_move<KH_DPP_REV4>(own[io]);                   // w, other component
+                        const double wpF = dpp_move<KH_DPP_XOR2>(fma(deps, u2[io], u1[io]));  // w', same component
+                        const double e1 = fma(y[io], dpp_move<KH_DPP_REV4>(y[io]), acc1[io] * wrev);
+                        v += fma(fim, wpF * acc2[io], sgn * e1);
+                    }
+                    const double tot = kh_mm_wave_sum(maskd * v);
+                    if (lane == 0) red[(n + 1) & 1][wave] = tot;
+                }
+                if constexpr (t == Pf) {  // first product in the shadow: H1 [chi(t_{n+3}) | w(t_{n+2})]
+                    kh_mm_readx(s.x0 + (KH_MM_SLOT_XH + par) * KH_MM_XLEN, lane, x);
+                    kh_mm_pass<NIO>(h1, x, sgn, wF);
+                }
+                if constexpr (t == P - 1) {  // A [s | w(t_{n+2})]: the odd terms, and u1 of the next interval
+                    kh_mm_readx(s.x0 + (KH_MM_SLOT_XS + par) * KH_MM_XLEN, lane, x);
+                    kh_mm_pass<NIO>(A, x, sgn, yS);
+                    exch_begin(n + 1);  // the exchange's granule loads go out here: back when the interval is done
+                }
+                if constexpr (t + 1 < P || t == Pf - 1) __syncthreads();
+                if constexpr (t == Pf - 1) {
+#ifdef KH_TIMING
+                    t_crit += clock64() - tq1;
+#endif
+                    exch_publish(n + 1);
+                }
+            });
+            if constexpr (Pf == P) {  // (P == 1 is not routed here; kept for completeness)
+                double x[4];
+                kh_mm_readx(s.x0 + (KH_MM_SLOT_XH + par) * KH_MM_XLEN, lane, x);
+                kh_mm_pass<NIO>(h1, x, sgn, wF);
+            }
+            nmv += P + 2;
+            // new state: even terms + f A s;  the w pipeline moves on (see the generic loop)
+#pragma unroll
+            for (int io = 0; io < NIO; ++io) {
+                const double nv = fma(fim * sgn, dpp_move<KH_DPP_XOR1>(yS[io]), acc1[io]);
+                const int bw = (NIO * wave + io) & 3;
+                const double w2 = s.x0[(KH_MM_SLOT_XS + par) * KH_MM_XLEN + (wj >> 1) * 128 + (16 * hi + 4 * bw + lo) * 2 + (wj & 1)];
+                own[io] = isF ? nv : w2;
+                if (!isF) {
+                    u1[io] = yS[io];
+                    u2[io] = wF[io];
+                }
+            }
+            eps_last = eps;
+            put_f2w(KH_MM_SLOT_XS + (par ^ 1), wF);
+            put_f2w(KH_MM_SLOT_XH + (par ^ 1), wF);
+            load_chi(n + 4, chin);  // for the next interval's H1 product: in flight across the exchange
+            put(0, true, own);
+        };
+        bool fast_done = false;
+#ifndef KH_MM_NO_FAST
+        if (nsub == 1 && with_d) {
+            fast_done = true;
+            switch (P) {
+                case 3: fast_interval(std::integral_constant<int, 3>{}); break;
+                case 4: fast_interval(std::integral_constant<int, 4>{}); break;
+                case 5: fast_interval(std::integral_constant<int, 5>{}); break;
+                case 6: fast_interval(std::integral_constant<int, 6>{}); break;
+                case 7: fast_interval(std::integral_constant<int, 7>{}); break;
+                case 8: fast_interval(std::integral_constant<int, 8>{}); break;
+                default: fast_done = false;
+            }
+        }
+#endif
+        for (int sub = fast_done ? nsub : 0; sub < nsub; ++sub) {
             // the partial sum is taken in the middle of the LAST sub-step; earlier ones run straight through
             const bool mid = with_d && sub + 1 == nsub;
             const bool lastsub = sub + 1 == nsub;
