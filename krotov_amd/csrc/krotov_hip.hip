@@ -13,6 +13,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -118,7 +119,49 @@ static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
     return KH_OK;
 }
 
+// The update-sweep kernels that exchange partial sums in-kernel spin until EVERY workgroup of the grid has
+// published: all of them must be resident at once.  Launching them cooperatively makes the runtime check the grid
+// against the occupancy of this very kernel (register / LDS footprint as built) and run it without other kernels
+// of the process in between -- instead of assuming one workgroup per CU from multiProcessorCount.
+// KH_COOP_LAUNCH=0 keeps plain launches (A/B timing: a cooperative launch costs ~15-20 us of host time).
+static bool g_coop_launch = [] {
+    const char *d = getenv("KH_COOP_LAUNCH");
+    return d == nullptr || atoi(d) != 0;
+}();
+
+template <class... Params, class... Args>
+static int launch_persistent(void (*kernel)(Params...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    if (!g_coop_launch || grid.x * grid.y * grid.z == 1) {
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+        return KH_OK;
+    }
+    std::tuple<Params...> packed(args...);
+    void *ptrs[sizeof...(Params)];
+    int i = 0;
+    std::apply([&](auto &...a) { ((ptrs[i++] = (void *)&a), ...); }, packed);
+    const hipError_t err = hipLaunchCooperativeKernel((const void *)kernel, grid, block, ptrs, (unsigned int)lds, st);
+    if (err == hipErrorCooperativeLaunchTooLarge) {
+        (void)hipGetLastError();
+        return kh_fail(KH_ERR_UNSUPPORTED, "the update sweep's %u workgroups cannot all be resident on this device",
+                       grid.x * grid.y * grid.z);
+    }
+    if (err != hipSuccess) return kh_fail(KH_ERR_HIP, "hipLaunchCooperativeKernel failed: %s", hipGetErrorString(err));
+    return KH_OK;
+}
+
+// grid <= (resident workgroups per CU of THIS kernel) x CUs ?  (checked once per kernel at engine creation)
+static int check_residency(const kh_engine *e, const void *func, int threads, size_t lds, int grid, const char *what);
+
 extern "C" const char *kh_last_error(void) { return g_last_error.c_str(); }
+
+static int check_residency(const kh_engine *e, const void *func, int threads, size_t lds, int grid, const char *what) {
+    int per_cu = 0;
+    KH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, threads, lds));
+    if ((long long)per_cu * e->num_cus < grid)
+        return kh_fail(KH_ERR_UNSUPPORTED, "%s: %d workgroups needed at once, %d x %d CUs resident", what, grid, per_cu,
+                       e->num_cus);
+    return KH_OK;
+}
 
 extern "C" const char *kh_version(void) { return "krotov_hip 0.3 (gfx950; tile64q2, tile64, mini16, mini4, coop16/mfma, generic, generic/csr kernels)"; }
 
@@ -513,6 +556,22 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
 
     }
 
+    if (e->kind == KIND_TILE_Q2 && !e->mini && e->K > 1) {
+        // every workgroup of the single-launch update sweep must be resident at once: ask the occupancy of the kernel
+        // as built (registers, LDS) instead of assuming one per CU; if it does not fit, the generic kernels (which
+        // loop over objectives inside at most #CUs workgroups) take over
+        int rc = check_residency(e, (const void *)kh_q2_forward_update<false, true>, KH_Q2_THREADS, kh_q2_lds_bytes(), e->K,
+                                 "kh_q2_forward_update");
+        if (rc == KH_OK)
+            rc = check_residency(e, (const void *)kh_q2_forward_update<true, false>, KH_Q2_THREADS, kh_q2_lds_bytes(), e->K,
+                                 "kh_q2_forward_update (second order)");
+        if (rc != KH_OK) {
+            e->kind = KIND_GENERIC;
+            e->kind_store = KIND_TILE_RPT1;
+            e->grid_update = e->K < max_wgs ? e->K : max_wgs;
+        }
+    }
+
     // ---- workspaces
     KH_HIP_E(hipMalloc(&e->d_phi, sizeof(cplx) * (size_t)e->K * e->N));
     const int Lx = e->L > 0 ? e->L : 1;
@@ -615,9 +674,9 @@ static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *p
     const int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS>, kh_coop_lds_bytes(15));
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
-    kh_coop_sweep_store<MAXKS, COLS><<<dim3(e->coop_G, e->coop_Y), KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(
-        p, coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
-    return KH_OK;
+    return launch_persistent(kh_coop_sweep_store<MAXKS, COLS>, dim3(e->coop_G, e->coop_Y), dim3(KH_COOP_THREADS),
+                             kh_coop_lds_bytes(e->coop_ks), st, p, coop_args(e, direction < 0), exchange_args(e, true), pulses,
+                             in, store, out, direction);
 }
 
 template <int MAXKS, int COLS>
@@ -630,10 +689,8 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     const dim3 grid(e->coop_G, e->coop_Y);
     if (u.sigma != nullptr)
-        kh_coop_forward_update<MAXKS, COLS, true><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e, false), u, ex);
-    else
-        kh_coop_forward_update<MAXKS, COLS, false><<<grid, KH_COOP_THREADS, kh_coop_lds_bytes(e->coop_ks), st>>>(p, coop_args(e, false), u, ex);
-    return KH_OK;
+        return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks), st, p, coop_args(e, false), u, ex);
+    return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks), st, p, coop_args(e, false), u, ex);
 }
 
 static int sweep_store(kh_engine *e, bool backward, const double *pulses, const cplx *in, cplx *store, cplx *out,
@@ -696,11 +753,16 @@ static int launch_tile_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
                                           : (const void *)kh_tile_forward_update<RPT, LT, false>;
     const int rc = ensure_dynamic_lds(e, func, lds);
     if (rc != KH_OK) return rc;
+    if (!u.internal_exchange) {  // one launch per interval (sharded sweep): nothing waits inside the kernel
+        if (u.sigma != nullptr)
+            kh_tile_forward_update<RPT, LT, true><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
+        else
+            kh_tile_forward_update<RPT, LT, false><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
+        return KH_OK;
+    }
     if (u.sigma != nullptr)
-        kh_tile_forward_update<RPT, LT, true><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
-    else
-        kh_tile_forward_update<RPT, LT, false><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
-    return KH_OK;
+        return launch_persistent(kh_tile_forward_update<RPT, LT, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, ex);
+    return launch_persistent(kh_tile_forward_update<RPT, LT, false>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, ex);
 }
 
 static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
@@ -745,20 +807,21 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         // first order, Hermitian operators: matrix-core kernel with the exchange hidden behind half the series
         KhExchange exa = ex;
         exa.first_poll_delay = e->adj_poll_delay;
+        const double *tab = e->d_mm_tab;
         if (e->mm_nio == 2)
-            kh_mm_forward_update<2><<<e->K, KhMm<2>::THREADS, kh_mm_lds_bytes(), st>>>(p, e->d_sq_fw, u, exa, e->d_mm_tab);
+            rc = launch_persistent(kh_mm_forward_update<2>, dim3(e->K), dim3(KhMm<2>::THREADS), kh_mm_lds_bytes(), st, p, e->d_sq_fw, u, exa, tab);
         else
-            kh_mm_forward_update<4><<<e->K, KhMm<4>::THREADS, kh_mm_lds_bytes(), st>>>(p, e->d_sq_fw, u, exa, e->d_mm_tab);
+            rc = launch_persistent(kh_mm_forward_update<4>, dim3(e->K), dim3(KhMm<4>::THREADS), kh_mm_lds_bytes(), st, p, e->d_sq_fw, u, exa, tab);
     } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
+        const dim3 g(e->K), b(KH_Q2_THREADS);
         if (u.sigma != nullptr)
-            kh_q2_forward_update<true, false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
+            rc = launch_persistent(kh_q2_forward_update<true, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else if (u.adj_sign != 0.0) {
             KhExchange exa = ex;
             exa.first_poll_delay = e->adj_poll_delay;
-            kh_q2_forward_update<false, true><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, exa);
-        }
-        else
-            kh_q2_forward_update<false, false><<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(p, e->d_sq_fw, u, ex);
+            rc = launch_persistent(kh_q2_forward_update<false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
+        } else
+            rc = launch_persistent(kh_q2_forward_update<false, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_COOP && !stepwise) {
         if (e->coop_cols == 4)
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 4>(e, p, u, ex, st) : launch_coop_update<16, 4>(e, p, u, ex, st);
@@ -776,7 +839,10 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     } else {
         const size_t lds = kh_gen_lds_bytes(e->N);
         rc = ensure_dynamic_lds(e, (const void *)kh_gen_forward_update, lds);
-        if (rc == KH_OK) kh_gen_forward_update<<<e->grid_update, KH_GEN_THREADS, lds, st>>>(p, u, ex);
+        if (rc == KH_OK && !u.internal_exchange)
+            kh_gen_forward_update<<<e->grid_update, KH_GEN_THREADS, lds, st>>>(p, u, ex);
+        else if (rc == KH_OK)
+            rc = launch_persistent(kh_gen_forward_update, dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, p, u, ex);
     }
     if (rc != KH_OK) return rc;
     KH_HIP(hipGetLastError());

@@ -45,6 +45,7 @@ from .conversions import (
     pulse_onto_tlist,
     pulse_options_dict_to_list,
 )
+from ._lib import KrotovHipError as _KrotovHipError
 from .info_hooks import chain
 from .mu import derivative_wrt_pulse
 from .parallelization import serial_map
@@ -578,8 +579,19 @@ class _HipBackend:
         lambdas = eng.dev(np.asarray(lambda_vals, dtype=np.float64), t.float64)
         done = False
         if self.group is None:
-            opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
-            done = True
+            try:
+                opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
+                eng.check()
+                done = True
+            except _KrotovHipError as exc:
+                # the single-launch sweep needs all its workgroups resident at once; if the GPU could not give it that
+                # (CUs held by another stream or process: its in-kernel exchange times out), redo the sweep interval by
+                # interval -- one launch each, nothing waits inside a kernel -- like the sharded path does
+                logging.getLogger('krotov').warning(
+                    "single-launch update sweep failed (%s); repeating it with one launch per interval", exc)
+                opt, psi_T, g_a = eng.forward_update_sharded(
+                    self.chi_store, norms_loc, self.init, guess, shapes, lambdas, lambda x: None, graph_chunk=0)
+                done = True
         elif self.p2p:
             # one persistent launch per rank; the per-GPU sums cross the node inside the kernel
             failed = 0

@@ -522,8 +522,9 @@ def test_transmon17_dump_on_device():
     tau = np.array(res.tau_vals)
     sgn = np.sign((tau[0] * np.conj(g['tau_vals'][5])).real)
     assert np.abs(sgn * tau[0] - g['tau_vals'][5]).max() < 1e-8
-    if np.all(sgn > 0):
-        assert np.abs(tau - g['tau_vals'][5:9]).max() < 1e-8
+    # (tau is fixed by the committed states: a flipped sign would be a different problem, not a phase convention)
+    assert np.all(sgn > 0)
+    assert np.abs(tau - g['tau_vals'][5:9]).max() < 1e-8
 
 
 def test_ensemble_dump_on_device():
@@ -656,12 +657,12 @@ def test_full_size_c5_properties():
     opt = a[0].cpu().numpy()
     assert np.all(np.isfinite(opt)) and opt[0, 0] == pulses[0, 0] and opt[0, -1] == pulses[0, -1]
     assert float((torch.linalg.vector_norm(a[1], dim=1) - 1).abs().max()) < 1e-11
-    path = os.path.join(os.path.dirname(__file__), 'golden', 'ref_c5_full.npz')
-    if os.path.exists(path):
-        g = np.load(path)
-        assert np.abs(opt - g['all_pulses'][1]).max() < 1e-10
-        tau1 = eng.tau(spec.target, a[1]).cpu().numpy()
-        assert np.abs(tau1 - g['tau_vals'][1]).max() < 1e-10
+    # one iteration of the reference's own optimize_pulses loop at full size (tests/golden/README.md): a lost
+    # fixture fails the test, it does not skip the comparison
+    g = golden('ref_c5_full')
+    assert np.abs(opt - g['all_pulses'][1]).max() < 1e-10
+    tau1 = eng.tau(spec.target, a[1]).cpu().numpy()
+    assert np.abs(tau1 - g['tau_vals'][1]).max() < 1e-10
     eng.close()
 
 
@@ -753,7 +754,10 @@ def test_two_ranks_sharded_on_one_gpu(case):
         assert np.abs(tau - ref['tau_vals']).max() < tol
         assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave'}.get(case, 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
-    print("cross-GPU exchange through peer windows used:", [o[3] for o in out])
+    # the path this test is here for: the sums crossed the ranks inside the persistent kernels, through the
+    # peer-mapped windows -- not through the per-interval fallback
+    if os.environ.get('KH_P2P', '1') != '0':
+        assert all(o[3] for o in out), "peer-window exchange was not used: %r" % ([o[3] for o in out],)
 
 
 def test_full_size_c4_liouville_properties(monkeypatch):
@@ -856,3 +860,153 @@ def test_nonuniform_grid_and_large_step_norms(kernel, monkeypatch):
     assert np.abs(g_a.cpu().numpy() - ref_ga).max() < 1e-11
     assert eng.stats()['matvecs'] > 0
     eng.close()
+
+
+def _rccl_one_rank_worker(port, queue):
+    """One rank, nccl (= RCCL) backend, peer windows off: the per-interval form of the update sweep with a real
+    RCCL all-reduce between the launches and HIP-graph replay of the interval loop."""
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), KH_P2P='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        import krotov_amd as ka
+        from krotov_amd import configs as cfg
+
+        spec = cfg.config_c5(K=6, N=64, nt=301, L=1)  # (301 intervals: several replays of the 64-interval graph)
+        objectives, pulse_options = cfg.spec_to_objectives(spec, ka)
+        res = ka.optimize_pulses(
+            objectives, pulse_options, spec.tlist, propagator=ka.propagators.expm,
+            chi_constructor=ka.functionals.chis_re, iter_stop=2, store_all_pulses=True,
+            process_group=dist.group.WORLD)
+        queue.put((np.array(res.all_pulses), np.array(res.tau_vals)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_per_interval_one_rank():
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    queue = ctx.Queue()
+    proc = ctx.Process(target=_rccl_one_rank_worker, args=(port, queue))
+    proc.start()
+    pulses, tau = queue.get(timeout=300)
+    proc.join(timeout=60)
+    assert proc.exitcode == 0
+    ref = oracle_optimize(configs.config_c5(K=6, N=64, nt=301, L=1), 2)
+    assert np.abs(pulses - ref['all_pulses']).max() < 1e-12 * max(1.0, np.abs(ref['all_pulses']).max())
+    assert np.abs(tau - ref['tau_vals']).max() < 1e-12
+
+
+def test_control_in_several_terms_on_device():
+    """One control driving several terms of H (reference tests/test_mu.py:52-129: sigma_+ and sigma_- under the
+    same control, so that dH/d eps = sigma_x): the device path sums the operators of a control once
+    (krotov_amd/optimize.py, ``summed``) and must agree with the same problem written with the summed operator,
+    and with the oracle."""
+    rng = np.random.default_rng(11)
+    N, K, nt = 6, 3, 121
+    tlist = np.linspace(0.0, 3.0, nt)
+
+    def herm(scale):
+        G = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        return scale * (G + G.conj().T) / 2
+
+    H0 = [herm(1.0) for _ in range(K)]
+    lower = np.diag(np.sqrt(np.arange(1, N)), 1).astype(complex)  # sigma_- / annihilation-like
+    ctrl = 0.3 * np.sin(np.pi * tlist / tlist[-1])
+    psi0 = np.zeros(N, dtype=complex)
+    psi0[0] = 1.0
+    psi1 = np.zeros(N, dtype=complex)
+    psi1[1] = 1.0
+    split = [krotov_amd.Objective(initial_state=psi0, target=psi1, H=[H0[k], [lower, ctrl], [lower.conj().T, ctrl]])
+             for k in range(K)]
+    joined = [krotov_amd.Objective(initial_state=psi0, target=psi1, H=[H0[k], [lower + lower.conj().T, ctrl]])
+              for k in range(K)]
+    S = lambda t: krotov_amd.shapes.flattop(t, 0.0, tlist[-1], 0.3, func='sinsq')  # noqa: E731
+    out = []
+    for objs in (split, joined):
+        res = krotov_amd.optimize_pulses(
+            objs, {id(ctrl): dict(lambda_a=2.0, update_shape=S)}, tlist, propagator=krotov_amd.propagators.expm,
+            chi_constructor=krotov_amd.functionals.chis_re, iter_stop=2, store_all_pulses=True)
+        out.append((np.array(res.all_pulses), np.array(res.tau_vals)))
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-13 and np.abs(out[0][1] - out[1][1]).max() < 1e-13
+    # oracle on the summed operator
+    ops = [[H0[k], lower + lower.conj().T] for k in range(K)]
+    prob = ko.OracleProblem(ops, np.array([psi0] * K), np.array([psi1] * K), tlist)
+    _, gp, Sarr = ko.initialize_controls([ctrl], [S], tlist)
+    ref = ko.optimize(prob, gp, Sarr, [2.0], ko.chis_re, 2, norm=lambda p, c: float(np.linalg.norm(c)))
+    assert np.abs(out[0][0] - np.array(ref['all_pulses'])).max() < 1e-12
+    assert np.abs(out[0][1] - np.array(ref['tau_vals'])).max() < 1e-12
+
+
+def test_dump_result_and_continue_on_device(tmp_path):
+    """check_convergence = dump_result on the device path (result.states is still a device-backed view when the
+    hook runs), then Result.load + continue_from."""
+    spec = configs.config_c5(K=4, N=64, nt=61)
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    path = str(tmp_path / 'oct.dump')
+    kw = dict(propagator=krotov_amd.propagators.expm, chi_constructor=krotov_amd.functionals.chis_re,
+              store_all_pulses=True)
+    res = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=2,
+                                     check_convergence=krotov_amd.convergence.dump_result(path, every=1), **kw)
+    loaded = krotov_amd.result.Result.load(path, objectives=objectives)
+    assert list(loaded.iters) == [0, 1, 2]
+    assert np.abs(np.array([np.asarray(x) for x in loaded.states]) - np.array([np.asarray(x) for x in res.states])).max() == 0.0
+    cont = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=4, continue_from=loaded, **kw)
+    scratch = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=4, **kw)
+    assert list(cont.iters) == list(range(5))
+    assert np.abs(np.array(cont.all_pulses[3:]) - np.array(scratch.all_pulses[3:])).max() < 1e-12
+    assert np.abs(np.array(cont.tau_vals[3:]) - np.array(scratch.tau_vals[3:])).max() < 1e-12
+
+
+def test_two_update_sweeps_on_two_streams():
+    """Two engines, each filling the GPU with one workgroup per objective, launched back to back on two streams: the
+    single-launch update sweeps need all their workgroups resident at once, so the launches must not interleave
+    (cooperative launch) -- both must come back complete and equal to their solo runs."""
+    import torch
+
+    specs = [configs.config_c5(K=256, N=64, nt=201, seed=s) for s in (0, 1)]
+    engs, args, solo = [], [], []
+    for spec in specs:
+        eng = _engine(spec)
+        gp, S, lam = oracle_controls(spec)
+        pulses = np.array(gp)
+        chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+        chi = eng.backward(chi_T, pulses)
+        a = (chi, np.full(spec.K, 1.0 / (2 * spec.K)), spec.init, pulses, np.array(S), np.array(lam))
+        a = tuple(x if torch.is_tensor(x) else eng.dev(x, torch.complex128 if np.iscomplexobj(x) else torch.float64)
+                  for x in a)
+        out = eng.forward_update(*a)
+        eng.check()
+        engs.append(eng)
+        args.append(a)
+        solo.append([o.clone() for o in out])
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    both = []
+    for _ in range(3):
+        both = []
+        for eng, a, st in zip(engs, args, streams):
+            with torch.cuda.stream(st):
+                both.append(eng.forward_update(*a))
+        torch.cuda.synchronize()
+        for eng, out, ref in zip(engs, both, solo):
+            eng.check()
+            assert all(torch.equal(o, r) for o, r in zip(out, ref))
+    for eng in engs:
+        eng.close()
