@@ -288,6 +288,12 @@ int kh_last_stats(kh_engine *engine, double stats[4]);
  * in powers of (-+i theta x), even degrees only, theta <= 2 (Taylor beyond). */
 int kh_series_tables(int32_t real_spectrum, double tol, double *theta /* [65] */, double *ratios /* [65*65] */);
 
+/* Test hook (no counterpart in the reference): keep `workgroups` CUs busy for `milliseconds` on `stream` with a
+ * kernel that does nothing but hold a CU's LDS -- the situation the single-launch update sweep must survive
+ * (another stream of the process holding compute units while its workgroups need to be resident all at once).
+ * tests/test_hip_parity.py::test_update_sweep_next_to_a_busy_stream. */
+int kh_debug_occupy(kh_engine *engine, int32_t workgroups, double milliseconds, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,7 @@ SYMBOLS = {
     'kh_chi_boundary': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     'kh_check': (ctypes.c_int, [_P]),
     'kh_last_stats': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double)]),
+    'kh_debug_occupy': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_double, _P]),
     'kh_series_tables': (ctypes.c_int, [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double)]),
 }

@@ -121,8 +121,11 @@ static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
 
 // The update-sweep kernels that exchange partial sums in-kernel spin until EVERY workgroup of the grid has
 // published: all of them must be resident at once.  Launching them cooperatively makes the runtime check the grid
-// against the occupancy of this very kernel (register / LDS footprint as built) and run it without other kernels
-// of the process in between -- instead of assuming one workgroup per CU from multiProcessorCount.
+// against the occupancy of this very kernel (register / LDS footprint as built) -- instead of assuming one
+// workgroup per CU from multiProcessorCount.  It does NOT keep other streams off the device (ROCm 7.2, measured:
+// tests/test_hip_parity.py::test_update_sweep_next_to_a_busy_stream): CUs held by somebody else still lead to a
+// partial start, which the bounded in-kernel waits turn into KH_ERR_TIMEOUT and the caller into a repeat of the
+// sweep with one launch per interval (krotov_amd/optimize.py).
 // KH_COOP_LAUNCH=0 keeps plain launches (A/B timing: a cooperative launch costs ~15-20 us of host time).
 static bool g_coop_launch = [] {
     const char *d = getenv("KH_COOP_LAUNCH");
@@ -1164,6 +1167,26 @@ extern "C" int kh_series_tables(int32_t real_spectrum, double tol, double *theta
         kh_build_degree_table(tol, theta);
         kh_build_taylor_rows(c0.data(), rows.data(), ratios);
     }
+    return KH_OK;
+}
+
+// holds one CU per workgroup (all of its LDS) until `ticks` of the 100 MHz wall clock have passed
+__global__ void __launch_bounds__(512) kh_occupy_kernel(long long ticks, int *sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long t0 = wall_clock64();
+    smem[threadIdx.x] = (char)threadIdx.x;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (smem[(threadIdx.x + 1) & 511] == 77 && ticks < 0) *sink = 1;
+}
+
+extern "C" int kh_debug_occupy(kh_engine *e, int32_t workgroups, double milliseconds, void *stream) {
+    if (e == nullptr || workgroups < 1 || !(milliseconds >= 0.0) || milliseconds > 1000.0)
+        return kh_fail(KH_ERR_INVALID, "bad argument");
+    const size_t lds = 128 * 1024;
+    const int rc = ensure_dynamic_lds(e, (const void *)kh_occupy_kernel, lds);
+    if (rc != KH_OK) return rc;
+    kh_occupy_kernel<<<workgroups, 512, lds, (hipStream_t)stream>>>((long long)(milliseconds * 1e5), (int *)e->d_abort + 0);
+    KH_HIP(hipGetLastError());
     return KH_OK;
 }
 

@@ -1010,3 +1010,71 @@ def test_two_update_sweeps_on_two_streams():
             assert all(torch.equal(o, r) for o, r in zip(out, ref))
     for eng in engs:
         eng.close()
+
+
+def test_update_sweep_next_to_a_busy_stream(monkeypatch):
+    """Half of the CUs are held by another stream of the process when the single-launch update sweep (one workgroup
+    per CU, all of them needed at once) is launched.  Neither a plain nor a cooperative launch waits for the other
+    stream on ROCm 7.2 (measured: both start on the free half), so the sweep's in-kernel waits run into their bound
+    (5 ms here, 60 ms of occupation): the C ABI must report KH_ERR_TIMEOUT -- no hang, no silently wrong pulses --
+    and the per-interval form of the sweep, which ``optimize_pulses`` falls back to, must give the solo result."""
+    import torch
+
+    from krotov_amd import _lib
+
+    monkeypatch.setenv('KH_TIMEOUT_MS', '5')
+    spec = configs.config_c5(K=256, N=64, nt=201)
+    eng = _engine(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    chi = eng.backward(chi_T, pulses)
+    a = (chi, np.full(spec.K, 1.0 / (2 * spec.K)), spec.init, pulses, np.array(S), np.array(lam))
+    solo = eng.forward_update(*a)
+    eng.check()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        _lib.check(eng._lib.kh_debug_occupy(eng._handle, 128, 60.0, eng._stream()))
+    out = eng.forward_update(*a)  # (default stream: nothing orders it behind the side stream)
+    torch.cuda.synchronize()
+    try:
+        eng.check()
+        assert all(torch.equal(o, r) for o, r in zip(out, solo))  # (it fitted after all)
+    except _lib.KrotovHipError as exc:
+        assert 'timed out' in str(exc)
+    again = eng.forward_update_sharded(*a, lambda x: None, graph_chunk=0)
+    eng.check()
+    scale = max(1.0, float(solo[0].abs().max()))
+    assert float((again[0] - solo[0]).abs().max()) < 1e-12 * scale
+    assert float((again[1] - solo[1]).abs().max()) < 1e-12
+    eng.close()
+
+
+def test_optimize_pulses_survives_a_busy_stream(monkeypatch):
+    """The same disturbance under ``optimize_pulses``: the iteration whose update sweep times out is redone interval
+    by interval and the run ends with the pulses of an undisturbed one."""
+    import torch
+
+    import krotov_amd.engine as engine_mod
+    from krotov_amd import _lib
+
+    monkeypatch.setenv('KH_TIMEOUT_MS', '5')
+    spec = configs.config_c5(K=256, N=64, nt=201)
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    kw = dict(propagator=krotov_amd.propagators.expm, chi_constructor=krotov_amd.functionals.chis_re, iter_stop=3,
+              store_all_pulses=True)
+    calm = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, **kw)
+    side = torch.cuda.Stream()
+
+    def disturb(**args):
+        if args['iteration'] == 1:  # right before the sweeps of iteration 2
+            eng = engine_mod.LAST_ENGINE()
+            with torch.cuda.stream(side):
+                _lib.check(eng._lib.kh_debug_occupy(eng._handle, 128, 60.0, eng._stream()))
+        return None
+
+    busy = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, info_hook=disturb, **kw)
+    torch.cuda.synchronize()
+    assert np.abs(np.array(busy.all_pulses) - np.array(calm.all_pulses)).max() < 1e-12
+    assert np.abs(np.array(busy.tau_vals) - np.array(calm.tau_vals)).max() < 1e-12
