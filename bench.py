@@ -12,9 +12,13 @@ the bracket the reference times per iteration (optimize.py:396 -> 510).  Inputs
 are synthetic (``krotov_amd.configs.config_c5``) and resident in HBM before the
 timed region.  One JSON line is printed by rank 0.
 
-For N > 1 the driver launches this file under ``torch.distributed.run``; the
-objectives are sharded over the ranks (weak scaling: 256 per GPU) and the L
-update sums are all-reduced once per time interval over RCCL.
+For N > 1 the driver launches this file under ``torch.distributed.run``.  The
+headline line is BASELINE config 5 itself: 256 objectives IN TOTAL sharded over the
+N ranks (``"scaling": "strong"``: 256/N per GPU), the L update sums crossing the
+GPUs once per time interval (peer-mapped windows inside the persistent kernels, or
+one RCCL all-reduce).  The same JSON line carries a second measurement under
+``"weak"``: 256 objectives PER GPU (``--scaling weak`` makes that one the headline
+instead).  At N = 1 the two coincide.
 """
 import argparse
 import gc
@@ -74,10 +78,12 @@ def cpu_baseline(args):
     from oracle import cpu_baseline as cb
 
     cores = len(os.sched_getaffinity(0))
-    P = max(1, min(cores, args.cpu_procs))
+    P = max(1, min(cores, args.cpu_procs if args.cpu_procs > 0 else cores, args.K))
     K_s = min(args.K, 2 * P)
-    # calibrate: time of one dense expm @ state at this N on this host
-    calib = configs.config_c5(K=1, N=args.N, nt=41, L=args.L)
+    # calibrate: time of one dense expm @ state at this N on this host (a first short run warms the worker's
+    # imports and caches up; the second, longer one is the measurement)
+    cb.timed_iteration(configs.config_c5(K=1, N=args.N, nt=21, L=args.L), processes=1)
+    calib = configs.config_c5(K=1, N=args.N, nt=401, L=args.L)
     r = cb.timed_iteration(calib, processes=1)
     t_prop = r['seconds'] / r['props']
     per_proc = (K_s + P - 1) // P
@@ -94,8 +100,33 @@ def cpu_baseline(args):
                   'step (SciPy if present), 1 BLAS thread per process, %d processes; %.1f s' % (
                       K_s, nt_s, r['processes'], r['seconds']),
         'seconds_per_prop_single_core': t_prop,
+        'seconds_per_prop_in_the_sample': r['seconds'] * r['processes'] / r['props'],
         'host_cores_visible': cores,
+        'cpu_model': _cpu_model(),
+        'expm': 'scipy.linalg.expm %s' % _scipy_version() if _scipy_version() else "oracle's own Pade-13 (NumPy)",
+        'note': 'per-core cost in the sample vs alone: what P processes sharing the memory system and one '
+                'synchronisation per time interval (the reference\'s parallel_map_fw_prop_step structure) cost on '
+                'top of the arithmetic; scripts/cpu_probe.py prints the pieces on the box',
     }
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def _scipy_version():
+    try:
+        import scipy
+
+        return scipy.__version__
+    except Exception:
+        return None
 
 
 def main():
@@ -103,7 +134,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--K', type=int, default=256, help='objectives per GPU')
+    ap.add_argument('--K', type=int, default=256, help='objectives (in total: strong scaling; per GPU: weak scaling)')
     ap.add_argument('--N', type=int, default=64)
     ap.add_argument('--nt', type=int, default=4001)
     ap.add_argument('--L', type=int, default=1)
@@ -112,12 +143,14 @@ def main():
                     help="c5 (default): BASELINE config 5, the configuration the metric is quoted on; c4: config 4 "
                          "(transmon Liouvillian, N=400, 16 density matrices sharing one operator list), a "
                          "single-GPU variant line for profiles/, not the headline")
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
+                    help='strong (default): --K objectives in total over all GPUs = BASELINE config 5; weak: --K per GPU. '
+                         'The other one is measured too and reported under "weak" / "strong" of the same line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the multi-GPU code path (stepwise sweep + RCCL all-reduce per interval) even on 1 rank')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
-    ap.add_argument('--cpu-procs', type=int, default=64)
+    ap.add_argument('--cpu-procs', type=int, default=0, help='worker processes of the CPU baseline (0: every visible core)')
     args = ap.parse_args()
 
     import numpy as np
@@ -153,149 +186,164 @@ def main():
     import krotov_amd
     from krotov_amd import configs, engine as _engine_mod
 
-    K_total = args.K * world if args.scaling == 'weak' else args.K
-    propagator = krotov_amd.propagators.expm
-    if args.workload == 'c4':
-        spec = configs.config_c4()
-        K_total, args.K, args.N, args.nt, args.L = spec.K, spec.K, spec.N, len(spec.tlist), spec.L
-        args.no_cpu_baseline = True
-        propagator = krotov_amd.propagators.HipExpm(liouville=True)
-    else:
-        spec = configs.config_c5(K=K_total, N=args.N, nt=args.nt, L=args.L, distinct=args.distinct)
-    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    def measure(scaling):
+        K_total = args.K * world if scaling == 'weak' else args.K
+        propagator = krotov_amd.propagators.expm
+        if args.workload == 'c4':
+            spec = configs.config_c4()
+            K_total, args.K, args.N, args.nt, args.L = spec.K, spec.K, spec.N, len(spec.tlist), spec.L
+            args.no_cpu_baseline = True
+            propagator = krotov_amd.propagators.HipExpm(liouville=True)
+        else:
+            spec = configs.config_c5(K=K_total, N=args.N, nt=args.nt, L=args.L, distinct=args.distinct)
+        objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
 
-    n_iter = args.warmup + args.steps
-    marks = {}
+        n_iter = args.warmup + args.steps
+        marks = {}
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    stamps = []
-
-    def hook(**kw):
-        it = kw['iteration']
-        if os.environ.get('KH_BENCH_DEBUG'):
+        def barrier():
             torch.cuda.synchronize()
-            stamps.append((it, time.perf_counter()))
-        if it == args.warmup:
-            eng = _engine_mod.LAST_ENGINE()
-            if eng is not None:
-                eng.kernel_times_ms(reset=True)
-            gc.collect()  # set-up garbage (K objectives, nested lists) is collected before, not inside, the timed steps
-            barrier()
-            marks['t0'] = time.perf_counter()
-        elif it == n_iter:
-            barrier()
-            marks['t1'] = time.perf_counter()
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        stamps = []
+
+        def hook(**kw):
+            it = kw['iteration']
+            if os.environ.get('KH_BENCH_DEBUG'):
+                torch.cuda.synchronize()
+                stamps.append((it, time.perf_counter()))
+            if it == args.warmup:
+                eng = _engine_mod.LAST_ENGINE()
+                if eng is not None:
+                    eng.kernel_times_ms(reset=True)
+                gc.collect()  # set-up garbage (K objectives, nested lists) is collected before, not inside, the timed steps
+                barrier()
+                marks['t0'] = time.perf_counter()
+            elif it == n_iter:
+                barrier()
+                marks['t1'] = time.perf_counter()
+            return None
+
+        res = krotov_amd.optimize_pulses(
+            objectives, pulse_options, spec.tlist,
+            propagator=propagator,
+            chi_constructor=krotov_amd.functionals.chis_re,
+            info_hook=hook, iter_stop=n_iter, process_group=group,
+        )
+        elapsed = marks['t1'] - marks['t0']
+        if stamps and rank == 0:
+            print('per-iteration ms:', [round(1e3 * (b[1] - a[1]), 2) for a, b in zip(stamps, stamps[1:])], file=sys.stderr)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        eng = _engine_mod.LAST_ENGINE()
+        times = eng.kernel_times_ms(reset=True)
+        stats = eng.stats()
+        kernel_names = {
+            'tile64q2/512': ('kh_q2_forward_update', 'kh_q2_sweep_store'),
+            'mini16/wave': ('kh_mini_forward_update', 'kh_mini_sweep_store'),
+            'mini4/wave': ('kh_quad_forward_update', 'kh_quad_sweep_store'),
+            'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
+            'coop16/mfma': ('kh_coop_forward_update', 'kh_coop_sweep_store'),
+        }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
+        if group is not None and not getattr(eng, '_p2p_used', False) and eng.kernel != 'generic':
+            # per-interval launches (RCCL path) run the two-tile kernel, see krotov_hip.hip:launch_update
+            kernel_names = ('kh_tile_forward_update', kernel_names[1])
+
+        if rank == 0:
+            K_loc = eng.K
+            props = K_total * (args.nt - 1) * 2 * args.steps
+            f_bw, f_up = algorithmic_flops(K_loc, args.N, args.nt, args.L)
+            b_bw, b_up = algorithmic_bytes(K_loc, args.N, args.nt, args.L)
+            t_bw = float(np.mean(times['backward'][-args.steps:])) * 1e-3
+            t_up = float(np.mean(times['update'][-args.steps:])) * 1e-3
+            ms_per_step = elapsed / args.steps * 1e3
+            dominant = 'update' if t_up >= t_bw else 'backward'
+            f_dom, t_dom = (f_up, t_up) if dominant == 'update' else (f_bw, t_bw)
+            out = {
+                'metric': 'state*timestep propagations/s (Krotov iterations/s in iterations_per_sec), ' +
+                          ('16-objective N=400 Liouvillian (variant)' if args.workload == 'c4' else
+                           '256-objective N=64 ensemble'),
+                'value': props / elapsed,
+                'unit': 'props/s',
+                'iterations_per_sec': args.steps / elapsed,
+                'n_gpus': world,
+                'steps': args.steps,
+                'warmup': args.warmup,
+                'ms_per_step': ms_per_step,
+                'higher_is_better': True,
+                'scaling': scaling,
+                'vs_baseline': None,
+                'dtype': 'f64',
+                'data': 'synthetic',
+                'config': {
+                    'workload': ('BASELINE config 4 (variant line): transmon X-gate in Liouville space, %d density-matrix '
+                                 'objectives sharing one %d-dim Liouvillian x %d time steps, L=%d control, chis_re, '
+                                 'complex128; one step = one Krotov iteration' % (K_total, args.N, args.nt - 1, args.L))
+                    if args.workload == 'c4' else
+                                'BASELINE config 5: robustness ensemble, %d objectives%s x N=%d x %d time steps, '
+                                'L=%d control, chis_re, complex128; one step = one Krotov iteration '
+                                '(backward sweep + forward/update sweep)' % (
+                                    K_total, ' (%d per GPU)' % eng.K if world > 1 else '', args.N, args.nt - 1, args.L),
+                    'objectives': K_total, 'N': args.N, 'time_steps': args.nt - 1, 'controls': args.L,
+                    'distinct_drifts': bool(args.distinct),
+                    'parallelism': 'objectives sharded over %d GPU(s); per time step the L update sums cross the '
+                                   'GPUs %s' % (world, 'inside the persistent kernel (peer-mapped windows over xGMI)'
+                                                if getattr(eng, '_p2p_used', False) else
+                                                ('by one RCCL all-reduce' if world > 1 or args.force_dist else '(single GPU: in-kernel exchange)')),
+                    'kernel': eng.kernel,
+                },
+                'roofline': {
+                    'bound': 'mfma' if eng.kernel == 'coop16/mfma' else 'fp64 vector FMA (peak = the fp64 MFMA peak; the two share one pipe, scripts/ubench_hybrid.hip)',
+                    'kernel': kernel_names[0] if dominant == 'update' else kernel_names[1],
+                    'achieved': f_dom / t_dom / 1e12,
+                    'peak': FP64_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s',
+                    'frac': f_dom / t_dom / 1e12 / FP64_PEAK_TFLOPS,
+                    'traffic': pmc_traffic(kernel_names[0] if dominant == 'update' else kernel_names[1], K_loc, args),
+                    'traffic_source': 'profiles/pmc_latest.json: rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE) of an '
+                                      'earlier run of this command on the same build, NOT measured in this run',
+                    'note': ('fp64 MFMA (v_mfma_f64_16x16x4): the objectives share the operators, so a Taylor term is a '
+                             'dense (N x N)(N x K) product; latency-bound by one cross-workgroup exchange per term. '
+                             'Credited flops as below with m = 14 per propagation (SURVEY.md 8d), whatever was issued. '
+                             if eng.kernel == 'coop16/mfma' else
+                             'fp64 vector-FMA bound (complex matrix-vector products cannot use MFMA tiles); the fp64 '
+                             'vector peak equals the fp64 MFMA peak on MI355X (78.6 TFLOP/s). ') +
+                            'Algorithmic (credited) flops: K*(nt-1)*(8 N^2 * 14 [+ L*(8 N^2 + 8 N) for the update sweep]), '
+                            'SURVEY.md 8d, whatever was issued: the q2 kernels evaluate the same degree-14 polynomial '
+                            'with 8 matrix-vector products per step (A^2 chain + one A product by linearity); see '
+                            'kernels.matvecs_issued_last_update_sweep for the executed count.',
+                    'launch_ms': t_dom * 1e3,
+                },
+                'kernels': {
+                    'backward_sweep_ms': t_bw * 1e3,
+                    'update_sweep_ms': t_up * 1e3,
+                    'backward_tflops': f_bw / t_bw / 1e12,
+                    'update_tflops': f_up / t_up / 1e12,
+                    'backward_hbm_gbs': b_bw / t_bw / 1e9,
+                    'update_hbm_gbs': b_up / t_up / 1e9,
+                    'hbm_frac_of_8TBs': max(b_bw / t_bw, b_up / t_up) / 1e9 / HBM_PEAK_GBS,
+                    'matvecs_issued_last_update_sweep': stats['matvecs'],
+                    'matvecs_credited_per_sweep': K_loc * (args.nt - 1) * (TAYLOR_DEGREE + args.L),
+                    'update_executed_tflops': stats['matvecs'] * 8.0 * args.N * args.N / t_up / 1e12,
+                },
+                'final_J_T_re': float(1 - np.mean(np.array(res.tau_vals[-1]).real)),
+            }
+            return out
         return None
 
-    res = krotov_amd.optimize_pulses(
-        objectives, pulse_options, spec.tlist,
-        propagator=propagator,
-        chi_constructor=krotov_amd.functionals.chis_re,
-        info_hook=hook, iter_stop=n_iter, process_group=group,
-    )
-    elapsed = marks['t1'] - marks['t0']
-    if stamps and rank == 0:
-        print('per-iteration ms:', [round(1e3 * (b[1] - a[1]), 2) for a, b in zip(stamps, stamps[1:])], file=sys.stderr)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    eng = _engine_mod.LAST_ENGINE()
-    times = eng.kernel_times_ms(reset=True)
-    stats = eng.stats()
-    kernel_names = {
-        'tile64q2/512': ('kh_q2_forward_update', 'kh_q2_sweep_store'),
-        'mini16/wave': ('kh_mini_forward_update', 'kh_mini_sweep_store'),
-        'mini4/wave': ('kh_quad_forward_update', 'kh_quad_sweep_store'),
-        'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
-        'coop16/mfma': ('kh_coop_forward_update', 'kh_coop_sweep_store'),
-    }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
-    if group is not None and not getattr(eng, '_p2p_used', False) and eng.kernel != 'generic':
-        # per-interval launches (RCCL path) run the two-tile kernel, see krotov_hip.hip:launch_update
-        kernel_names = ('kh_tile_forward_update', kernel_names[1])
-
+    other = 'weak' if args.scaling == 'strong' else 'strong'
+    out = measure(args.scaling)
+    second = measure(other) if world > 1 and args.workload == 'c5' else None
     if rank == 0:
-        K_loc = eng.K
-        props = K_total * (args.nt - 1) * 2 * args.steps
-        f_bw, f_up = algorithmic_flops(K_loc, args.N, args.nt, args.L)
-        b_bw, b_up = algorithmic_bytes(K_loc, args.N, args.nt, args.L)
-        t_bw = float(np.mean(times['backward'][-args.steps:])) * 1e-3
-        t_up = float(np.mean(times['update'][-args.steps:])) * 1e-3
-        ms_per_step = elapsed / args.steps * 1e3
-        dominant = 'update' if t_up >= t_bw else 'backward'
-        f_dom, t_dom = (f_up, t_up) if dominant == 'update' else (f_bw, t_bw)
-        out = {
-            'metric': 'state*timestep propagations/s (Krotov iterations/s in iterations_per_sec), ' +
-                      ('16-objective N=400 Liouvillian (variant)' if args.workload == 'c4' else
-                       '256-objective N=64 ensemble'),
-            'value': props / elapsed,
-            'unit': 'props/s',
-            'iterations_per_sec': args.steps / elapsed,
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': ms_per_step,
-            'higher_is_better': True,
-            'scaling': args.scaling,
-            'vs_baseline': None,
-            'dtype': 'f64',
-            'data': 'synthetic',
-            'config': {
-                'workload': ('BASELINE config 4 (variant line): transmon X-gate in Liouville space, %d density-matrix '
-                             'objectives sharing one %d-dim Liouvillian x %d time steps, L=%d control, chis_re, '
-                             'complex128; one step = one Krotov iteration' % (K_total, args.N, args.nt - 1, args.L))
-                if args.workload == 'c4' else
-                            'BASELINE config 5: robustness ensemble, %d objectives%s x N=%d x %d time steps, '
-                            'L=%d control, chis_re, complex128; one step = one Krotov iteration '
-                            '(backward sweep + forward/update sweep)' % (
-                                K_total, ' (%d per GPU)' % args.K if world > 1 else '', args.N, args.nt - 1, args.L),
-                'objectives': K_total, 'N': args.N, 'time_steps': args.nt - 1, 'controls': args.L,
-                'distinct_drifts': bool(args.distinct),
-                'parallelism': 'objectives sharded over %d GPU(s); per time step the L update sums cross the '
-                               'GPUs %s' % (world, 'inside the persistent kernel (peer-mapped windows over xGMI)'
-                                            if getattr(eng, '_p2p_used', False) else
-                                            ('by one RCCL all-reduce' if world > 1 or args.force_dist else '(single GPU: in-kernel exchange)')),
-                'kernel': eng.kernel,
-            },
-            'roofline': {
-                'bound': 'mfma',
-                'kernel': kernel_names[0] if dominant == 'update' else kernel_names[1],
-                'achieved': f_dom / t_dom / 1e12,
-                'peak': FP64_PEAK_TFLOPS,
-                'unit': 'TFLOP/s',
-                'frac': f_dom / t_dom / 1e12 / FP64_PEAK_TFLOPS,
-                'traffic': pmc_traffic(kernel_names[0] if dominant == 'update' else kernel_names[1], K_loc, args),
-                'note': ('fp64 MFMA (v_mfma_f64_16x16x4): the objectives share the operators, so a Taylor term is a '
-                         'dense (N x N)(N x K) product; latency-bound by one cross-workgroup exchange per term. '
-                         'Credited flops as below with m = 14 per propagation (SURVEY.md 8d), whatever was issued. '
-                         if eng.kernel == 'coop16/mfma' else
-                         'fp64 vector-FMA bound (complex matrix-vector products cannot use MFMA tiles); the fp64 '
-                         'vector peak equals the fp64 MFMA peak on MI355X (78.6 TFLOP/s). ') +
-                        'Algorithmic (credited) flops: K*(nt-1)*(8 N^2 * 14 [+ L*(8 N^2 + 8 N) for the update sweep]), '
-                        'SURVEY.md 8d, whatever was issued: the q2 kernels evaluate the same degree-14 polynomial '
-                        'with 8 matrix-vector products per step (A^2 chain + one A product by linearity); see '
-                        'kernels.matvecs_issued_last_update_sweep for the executed count.',
-                'launch_ms': t_dom * 1e3,
-            },
-            'kernels': {
-                'backward_sweep_ms': t_bw * 1e3,
-                'update_sweep_ms': t_up * 1e3,
-                'backward_tflops': f_bw / t_bw / 1e12,
-                'update_tflops': f_up / t_up / 1e12,
-                'backward_hbm_gbs': b_bw / t_bw / 1e9,
-                'update_hbm_gbs': b_up / t_up / 1e9,
-                'hbm_frac_of_8TBs': max(b_bw / t_bw, b_up / t_up) / 1e9 / HBM_PEAK_GBS,
-                'matvecs_issued_last_update_sweep': stats['matvecs'],
-                'matvecs_credited_per_sweep': K_loc * (args.nt - 1) * (TAYLOR_DEGREE + args.L),
-                'update_executed_tflops': stats['matvecs'] * 8.0 * args.N * args.N / t_up / 1e12,
-            },
-            'final_J_T_re': float(1 - np.mean(np.array(res.tau_vals[-1]).real)),
-        }
+        if second is not None:
+            # the same job with the other partitioning of the objectives (see the module docstring)
+            out[other] = {k: second[k] for k in ('value', 'unit', 'iterations_per_sec', 'ms_per_step', 'scaling')}
+            out[other]['objectives'] = second['config']['objectives']
+            out[other]['kernels'] = {k: second['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']

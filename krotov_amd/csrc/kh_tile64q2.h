@@ -106,6 +106,26 @@ __device__ __forceinline__ void kh_q2_build(const KhQ2Lds &s, int tid, double ep
     }
 }
 
+// The update kernels keep A and B resident and advance them from interval to interval instead:
+//   A += (eps - eps') H1,   B += (eps - eps') P1 + (eps^2 - eps'^2) P2      (P1, P2 from LDS)
+// Only H1, A and B stay in registers (96 VGPRs instead of the 160 of H1, P1, P2, A, B): no spills.  Every
+// KH_Q2_REFRESH intervals A and B restart from H0 and P0 in global memory (eps' = 0), so rounding cannot drift
+// (64 updates: a few ulp of the tiles).
+#define KH_Q2_REFRESH 64
+__device__ __forceinline__ void kh_q2_advance(const KhQ2Lds &s, int tid, double eps, double eps_prev, const cplx (&h1)[8],
+                                              cplx (&a)[8], cplx (&b)[8]) {
+    const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const cplx q1 = s.h0[j * KH_Q2_THREADS + tid];  // (the update kernels stage P1, P2 where the plain sweep has H0, P0)
+        const cplx q2 = s.p0[j * KH_Q2_THREADS + tid];
+        a[j].x = fma(e1, h1[j].x, a[j].x);
+        a[j].y = fma(e1, h1[j].y, a[j].y);
+        b[j].x = fma(e2, q2.x, fma(e1, q1.x, b[j].x));
+        b[j].y = fma(e2, q2.y, fma(e1, q1.y, b[j].y));
+    }
+}
+
 // state <- exp(f A dt) state with two Taylor terms per phase.  On entry
 // buf[cur] holds the state; on exit buf[cur] holds the new state.  f*f is real
 // (-1 in Hilbert space, +1 for Liouvillians): c2 = f^2 h^2 / (j1 j2).
@@ -310,12 +330,11 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
 
     const cplx *const *ops_k = p.ops + (size_t)k * 2;
     const cplx *const *sq_k = sq + (size_t)k * 3;
-    kh_q2_stage_tile(ops_k[0], N, wave, lane, tid, s.h0);
-    kh_q2_stage_tile(sq_k[0], N, wave, lane, tid, s.p0);
-    cplx h1[8], p1[8], p2[8];
+    kh_q2_stage_tile(sq_k[1], N, wave, lane, tid, s.h0);  // P1, P2 (kh_q2_advance)
+    kh_q2_stage_tile(sq_k[2], N, wave, lane, tid, s.p0);
+    cplx h1[8], a[8], b[8];
     kh_q2_load_tile(ops_k[1], N, wave, lane, h1);  // also dH/d eps (mu.py:123-134)
-    kh_q2_load_tile(sq_k[1], N, wave, lane, p1);
-    kh_q2_load_tile(sq_k[2], N, wave, lane, p2);
+    double eps_prev = 0.0;
     // (wave-uniform scalars live in SGPRs: the VGPR file is full of operator tiles)
     const double nrm0 = kh_uniform(p.op_norms[(size_t)k * 2]), nrm1 = kh_uniform(p.op_norms[(size_t)k * 2 + 1]);
     const double chi_norm = kh_uniform(u.chi_norms[k]);
@@ -410,7 +429,14 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     long long t_ex = 0, t_prop = 0, t_part = 0;
     const long long t_all0 = clock64();
 #endif
-    for (int n = u.n_begin; n < u.n_end; ++n) {
+    for (int nr = u.n_begin; nr < u.n_end; nr += KH_Q2_REFRESH) {
+    // restart A = H0, B = P0 from global memory (outside the interval loop: the loop body keeps one definition of
+    // the tiles, which the register allocator needs to keep them in place)
+    kh_q2_load_tile(ops_k[0], N, wave, lane, a);
+    kh_q2_load_tile(sq_k[0], N, wave, lane, b);
+    eps_prev = 0.0;
+    const int n_stop = nr + KH_Q2_REFRESH < u.n_end ? nr + KH_Q2_REFRESH : u.n_end;
+    for (int n = nr; n < n_stop; ++n) {
         const int par = n & 1;
         if constexpr (!ADJ) {
             if (n + 1 < nt - 1) load_chi(n + 1);
@@ -469,8 +495,8 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
             kh_q2_load_rows(p, s, m, tid);
             m_rows = m;
         }
-        cplx a[8], b[8];
-        kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
+        kh_q2_advance(s, tid, eps, eps_prev, h1, a, b);
+        eps_prev = eps;
         stepw_next = kh_uniform(shape_next / lam);  // (under the LDS latency of the tile reads)
         cplx *fw_out = nullptr;
         if constexpr (SO) fw_out = u.fw_store + ((size_t)k * nt + n) * N;
@@ -504,6 +530,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
 #ifdef KH_TIMING
         t_part += clock64() - tq2;
 #endif
+    }
     }
 #ifdef KH_TIMING
     if (tid == 0 && k == 0 && p.stats != nullptr) {
