@@ -78,16 +78,28 @@ def cpu_baseline(args):
     from oracle import cpu_baseline as cb
 
     cores = len(os.sched_getaffinity(0))
-    P = max(1, min(cores, args.cpu_procs if args.cpu_procs > 0 else cores, args.K))
-    K_s = min(args.K, 2 * P)
     # calibrate: time of one dense expm @ state at this N on this host (a first short run warms the worker's
     # imports and caches up; the second, longer one is the measurement)
     cb.timed_iteration(configs.config_c5(K=1, N=args.N, nt=21, L=args.L), processes=1)
-    calib = configs.config_c5(K=1, N=args.N, nt=401, L=args.L)
-    r = cb.timed_iteration(calib, processes=1)
+    r = cb.timed_iteration(configs.config_c5(K=1, N=args.N, nt=401, L=args.L), processes=1)
     t_prop = r['seconds'] / r['props']
+    # how many worker processes?  The reference would use every core (parallel_map); its per-interval
+    # synchronisation makes that slower, not faster, beyond some count on a large box -- short pilots pick the count
+    # that gives THIS baseline its best throughput (all visible cores, half of them (SMT), 64)
+    if args.cpu_procs > 0:
+        candidates = [min(cores, args.cpu_procs, args.K)]
+    else:
+        candidates = sorted({max(1, min(c, args.K, cores)) for c in (cores, cores // 2, 64)}, reverse=True)
+    pilots = {}
+    for P in candidates:
+        K_p = min(args.K, 2 * P)
+        rp = cb.timed_iteration(configs.config_c5(K=K_p, N=args.N, nt=31, L=args.L, distinct=args.distinct), processes=P)
+        pilots[P] = rp['props'] / rp['seconds']
+    P = max(pilots, key=pilots.get)
+    K_s = min(args.K, 2 * P)
     per_proc = (K_s + P - 1) // P
-    nt_s = int(min(args.nt - 1, max(20, args.cpu_seconds / (2 * per_proc * t_prop))))
+    t_in_sample = P / pilots[P]  # seconds per propagation per process, synchronisation included
+    nt_s = int(min(args.nt - 1, max(30, args.cpu_seconds / (2 * per_proc * t_in_sample))))
     spec = configs.config_c5(K=K_s, N=args.N, nt=nt_s + 1, L=args.L, distinct=args.distinct)
     r = cb.timed_iteration(spec, processes=P)
     return {
@@ -102,6 +114,7 @@ def cpu_baseline(args):
         'seconds_per_prop_single_core': t_prop,
         'seconds_per_prop_in_the_sample': r['seconds'] * r['processes'] / r['props'],
         'host_cores_visible': cores,
+        'pilot_props_per_s_by_process_count': {str(k): v for k, v in pilots.items()},
         'cpu_model': _cpu_model(),
         'expm': 'scipy.linalg.expm %s' % _scipy_version() if _scipy_version() else "oracle's own Pade-13 (NumPy)",
         'note': 'per-core cost in the sample vs alone: what P processes sharing the memory system and one '

@@ -52,7 +52,6 @@ struct KhCoopArgs {
 };
 
 struct KhCoopLds {
-    double part[KH_COOP_WAVES][8][64];     // per-wave partial blocks (re: regs 0-3, im: 4-7)
     double red[2][4][KH_COOP_MAX_L];       // owner waves' pieces of the update sums, by interval parity
     double D[2][KH_COOP_MAX_L + 1];        // reduced sums + ok flag, by interval parity
     double deg[KH_MAX_DEGREE + 2];
@@ -61,11 +60,25 @@ struct KhCoopLds {
 #ifdef KH_TIMING
     double tim[7];
 #endif
-    double frag[1];  // [ks][2][KH_COOP_THREADS] operator fragment of the current interval (dynamic size)
+    double frag[1];  // [ks][2][KH_COOP_THREADS] operator fragment of the current interval (dynamic size), then
+                     // the per-wave partial blocks: [WAVES][8][64] (16 objectives per workgroup: re regs 0-3, im 4-7)
+                     // or [WAVES][2][64] (4 objectives: element (row r, column c) of the block at [4 r + c])
 };
 
-__host__ __device__ inline size_t kh_coop_lds_bytes(int ks) {
-    return sizeof(KhCoopLds) + sizeof(double) * 2 * (size_t)ks * KH_COOP_THREADS;
+__host__ __device__ inline size_t kh_coop_lds_bytes(int ks, int cols = KH_COOP_COLS) {
+    return sizeof(KhCoopLds) + sizeof(double) * 2 * (size_t)ks * KH_COOP_THREADS +
+           sizeof(double) * KH_COOP_WAVES * (cols == 4 ? 2 : 8) * 64;
+}
+__device__ __forceinline__ double *kh_coop_part(KhCoopLds &s, int ks) { return s.frag + 2 * (size_t)ks * KH_COOP_THREADS; }
+
+// 4 objectives per workgroup: the wave's share of the k range, in groups of 16 columns of the operator (balanced:
+// the first `groups % 8` waves take one group more)
+__host__ __device__ inline int kh_coop4_groups(int N) { return (N + 15) / 16; }
+__host__ __device__ inline int kh_coop4_slots(int N) { return 4 * ((kh_coop4_groups(N) + KH_COOP_WAVES - 1) / KH_COOP_WAVES); }
+__host__ __device__ inline void kh_coop4_share(int N, int wave, int *start, int *count) {
+    const int groups = kh_coop4_groups(N), base = groups / KH_COOP_WAVES, extra = groups % KH_COOP_WAVES;
+    *count = base + (wave < extra ? 1 : 0);
+    *start = wave * base + (wave < extra ? wave : extra);
 }
 
 // A thread's view of the fragment: element q is {re, im} at f[(2 q) T], f[(2 q + 1) T]
@@ -80,13 +93,29 @@ struct KhCoopFrag {
 // the MFMA A-operand layout -- sits at [((g WAVES + wave) ks + q) 64 + lane], zero beyond N.  A fragment
 // (re)build then reads 1 KiB per wave-level load, fully coalesced, without bounds checks; from the row-major
 // matrix the same load touched 16 half-used lines (measured: 4.2 -> see DESIGN.md us per table per interval).
-__global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, int N, int G, int ks) {
+// With 4 objectives per workgroup (cols == 4) the four 4x4x4 blocks of v_mfma_f64_4x4x4_4b take four consecutive
+// k-steps instead of four row groups: slot q = 4 gi + rb of a wave is the A operand for its gi-th group of 16
+// columns and the row group rb -- row 16 g + 4 rb + (lane & 3), column 16 (start + gi) + 4 ((lane >> 2) & 3) +
+// (lane >> 4).  The vector block of a group then IS the B operand as loaded (one element per lane, no replication
+// across blocks, no ds_bpermute): see kh_coop_round.
+__global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, int N, int G, int ks,
+                                       int cols) {
     const size_t total = (size_t)G * KH_COOP_WAVES * ks * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         const size_t t = idx >> 6;
         const int q = (int)(t % ks), wave = (int)((t / ks) % KH_COOP_WAVES), g = (int)(t / ks / KH_COOP_WAVES);
-        const int row = g * 16 + (lane & 15), col = (wave * ks + q) * 4 + (lane >> 4);
+        int row, col;
+        if (cols == 4) {
+            int start, count;
+            kh_coop4_share(N, wave, &start, &count);
+            const int gi = q >> 2, rb = q & 3;
+            row = g * 16 + 4 * rb + (lane & 3);
+            col = gi < count ? 16 * (start + gi) + 4 * ((lane >> 2) & 3) + (lane >> 4) : N;
+        } else {
+            row = g * 16 + (lane & 15);
+            col = (wave * ks + q) * 4 + (lane >> 4);
+        }
         out[idx] = (row < N && col < N) ? in[(size_t)row * N + col] : c_make(0.0, 0.0);
     }
 }
