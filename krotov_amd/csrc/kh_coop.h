@@ -185,9 +185,10 @@ __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned in
 // bound by the number of wave-level loads the CU issues (8 waves x 52 at N = 400), not by their bytes --
 // and the elements are moved into the MFMA operand layout with ds_bpermute.
 template <int MAXKS, int COLS>
-__device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y,
+__device__ __forceinline__ void kh_coop_round16(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y,
                                               int N, const KhCoopFrag &f, KhCoopLds &s, int tid, int wave, int lane,
                                               cplx &w) {
+    double *part = kh_coop_part(s, c.ks);
     constexpr int KPL = 16 / COLS;               // k-steps per load group
     constexpr int NG = (MAXKS + KPL - 1) / KPL;  // load groups
     const unsigned int epoch = c.epoch_base + rid;
@@ -307,13 +308,13 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
         }
     }
     if constexpr (COLS == 4) {
-        s.part[wave][0][lane] = acc4_r;
-        s.part[wave][1][lane] = acc4_i;
+        part[(wave * 8 + 0) * 64 + lane] = acc4_r;
+        part[(wave * 8 + 1) * 64 + lane] = acc4_i;
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            s.part[wave][i][lane] = acc_r[i];
-            s.part[wave][4 + i][lane] = acc_i[i];
+            part[(wave * 8 + i) * 64 + lane] = acc_r[i];
+            part[(wave * 8 + 4 + i) * 64 + lane] = acc_i[i];
         }
     }
 #ifdef KH_TIMING
@@ -336,19 +337,171 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
             const int src = 16 * (r & 3) + 4 * (r >> 2) + oc;  // D lane of row 4 blk + row', column
 #pragma unroll
             for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
-                w.x += s.part[wv][0][src];
-                w.y += s.part[wv][1][src];
+                w.x += part[(wv * 8 + 0) * 64 + src];
+                w.y += part[(wv * 8 + 1) * 64 + src];
             }
         } else {
             const int src = (r & 3) * 16 + oc, reg = r >> 2;
 #pragma unroll
             for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
-                w.x += s.part[wv][reg][src];
-                w.y += s.part[wv][4 + reg][src];
+                w.x += part[(wv * 8 + reg) * 64 + src];
+                w.y += part[(wv * 8 + 4 + reg) * 64 + src];
             }
         }
     }
     __syncthreads();  // part[] is free for the next round
+}
+
+// The same round for 4 objectives per workgroup.  A wave's share of the k range is `count` groups of 16 columns
+// (kh_coop4_share); a group's 16 x 4 block of the term is ONE element per lane -- lane (hi, b, lo) <- row
+// 16 (start + gi) + 4 b + hi, column lo -- which is exactly the B operand of v_mfma_f64_4x4x4_4b when its four
+// 4x4x4 blocks b take four consecutive k-steps (the operator fragments are stored to match, kh_coop_permute_kernel):
+// no replication across blocks, no ds_bpermute (208 of them per wave and round in the first version: 1.2 us).
+// Four row groups rb = 0..3 need four MFMA sets per group; the blocks' partial sums are added with two row
+// rotations, and the wave's 16 x 4 block goes to LDS as 64 values per component: element (row r, column c) at 4 r + c.
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y, int N,
+                                               const KhCoopFrag &f, KhCoopLds &s, int tid, int wave, int lane, cplx &w) {
+    constexpr int MAXG = MAXKS / 4;  // groups per wave
+    double *part = kh_coop_part(s, c.ks);
+    const unsigned int epoch = c.epoch_base + rid;
+    int start, count;
+    kh_coop4_share(N, wave, &start, &count);
+    const int roff = 4 * ((lane >> 2) & 3) + (lane >> 4), lcol = lane & 3;  // this lane's element of a group
+    kh_u64 g[MAXG][4];
+    const long long t0 = wall_clock64();
+#ifdef KH_TIMING
+    const long long tq0 = clock64();
+#endif
+    unsigned int spins = 0;
+    for (int d = 0; d < c.first_poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+    // first pass through L2 (fast; may see a stale line); padding: tag ok, value +0.0
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j) {
+        const int row = 16 * (start + j) + roff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[j][i] = (kh_u64)epoch << 32;
+        if (j < count && row < N) {
+            const kh_u64 *sl = kh_coop_slot(c, rid, y, row, lcol);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    bool all_fresh = true;
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) all_fresh = all_fresh && ((unsigned int)(g[j][i] >> 32) == epoch);
+#ifdef KH_TIMING
+    {
+        const int stale_lanes = __popcll(__ballot(!all_fresh));
+        if (tid == 0 && blockIdx.x == 0) s.tim[5] += (double)stale_lanes;
+    }
+    const long long tqf = clock64();
+    if (tid == 0 && blockIdx.x == 0) s.tim[4] += (double)(tqf - tq0);
+#endif
+    // otherwise: only what was stale, bypassing L2, until everything carries the round's tag
+    while (!__all(all_fresh)) {
+#ifdef KH_TIMING
+        if (tid == 0 && blockIdx.x == 0) s.tim[6] += 1.0;
+#endif
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < MAXG; ++j) {
+            const int row = 16 * (start + j) + roff;
+            if (j < count && row < N) {
+                const kh_u64 *sl = kh_coop_slot(c, rid, y, row, lcol);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if ((unsigned int)(g[j][i] >> 32) != epoch)
+                        g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXG; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ok = ok && ((unsigned int)(g[j][i] >> 32) == epoch);
+        all_fresh = ok;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 63u) == 0) {
+            const bool gave_up =
+                (wall_clock64() - t0 > ex.timeout_ticks) ||
+                (__hip_atomic_load(ex.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+            if (__any(gave_up)) {
+                if (lane == 0) {
+                    __hip_atomic_store(ex.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s.abort = 1;
+                }
+                break;
+            }
+        }
+    }
+#ifdef KH_TIMING
+    const long long tq1 = clock64();
+#endif
+    double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};  // one accumulator pair per row group
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j) {
+        if (j < count) {
+            const double vr = __hiloint2double((int)(unsigned int)(g[j][0] & 0xffffffffull), (int)(unsigned int)(g[j][1] & 0xffffffffull));
+            const double vi = __hiloint2double((int)(unsigned int)(g[j][2] & 0xffffffffull), (int)(unsigned int)(g[j][3] & 0xffffffffull));
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const double fr = f.re(4 * j + rb), fi = f.im(4 * j + rb);
+                ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vr, ar[rb], 0, 0, 0);
+                ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fi, -vi, ar[rb], 0, 0, 0);
+                ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vi, ai[rb], 0, 0, 0);
+                ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fi, vr, ai[rb], 0, 0, 0);
+            }
+        }
+    }
+    // D lane = 16 (row within the group) + 4 (block = k-step) + column: add the four blocks, one lane of four writes
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        ar[rb] += dpp_move<KH_DPP_ROR8>(ar[rb]);
+        ar[rb] += dpp_move<KH_DPP_ROR4>(ar[rb]);
+        ai[rb] += dpp_move<KH_DPP_ROR8>(ai[rb]);
+        ai[rb] += dpp_move<KH_DPP_ROR4>(ai[rb]);
+        if (((lane >> 2) & 3) == 0) {
+            const int e = 16 * rb + 4 * (lane >> 4) + (lane & 3);
+            part[(wave * 2 + 0) * 64 + e] = ar[rb];
+            part[(wave * 2 + 1) * 64 + e] = ai[rb];
+        }
+    }
+#ifdef KH_TIMING
+    const long long tq2 = clock64();
+#endif
+    __syncthreads();
+#ifdef KH_TIMING
+    const long long tq3 = clock64();
+    if (tid == 0 && blockIdx.x == 0) {
+        s.tim[0] += (double)(tq1 - tq0);
+        s.tim[1] += (double)(tq2 - tq1);
+        s.tim[2] += (double)(tq3 - tq2);
+        s.tim[3] += (double)spins;
+    }
+#endif
+    w = c_make(0.0, 0.0);
+    if (tid < 64) {  // owner of element (row tid / 4, column tid % 4)
+#pragma unroll
+        for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
+            w.x += part[(wv * 2 + 0) * 64 + tid];
+            w.y += part[(wv * 2 + 1) * 64 + tid];
+        }
+    }
+    __syncthreads();  // part[] is free for the next round
+}
+
+template <int MAXKS, int COLS>
+__device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y,
+                                              int N, const KhCoopFrag &f, KhCoopLds &s, int tid, int wave, int lane,
+                                              cplx &w) {
+    if constexpr (COLS == 4)
+        kh_coop_round4<MAXKS>(c, ex, rid, y, N, f, s, tid, wave, lane, w);
+    else
+        kh_coop_round16<MAXKS, COLS>(c, ex, rid, y, N, f, s, tid, wave, lane, w);
 }
 
 // A = op_0 + sum_l eps_l op_l (fragments rebuilt from L2 once per interval; ops: fragment-ordered copies)

@@ -415,8 +415,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             e->kind = KIND_COOP;
             e->coop_G = G;
             e->coop_Y = Y;
-            e->coop_ks = (e->N + 31) / 32;
             e->coop_cols = cols;
+            e->coop_ks = cols == 4 ? kh_coop4_slots(e->N) : (e->N + 31) / 32;  // operator-fragment slots per lane
             e->coop_vbuf_bytes = sizeof(kh_u64) * KH_COOP_RING * (size_t)Y * G * 16 * KH_COOP_COLS * 4;
             KH_HIP_E(hipMalloc(&e->d_coop_vbuf, e->coop_vbuf_bytes));
             e->grid_update = e->K < max_wgs ? e->K : max_wgs;  // (stepwise launches use the generic kernel)
@@ -494,7 +494,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                 const hipError_t err = hipMalloc(&dst, sizeof(cplx) * elems);
                 if (err != hipSuccess) return err;
                 e->owned.push_back(dst);
-                kh_coop_permute_kernel<<<(unsigned)((elems + 255) / 256), 256>>>(src, dst, e->N, e->coop_G, e->coop_ks);
+                kh_coop_permute_kernel<<<(unsigned)((elems + 255) / 256), 256>>>(src, dst, e->N, e->coop_G, e->coop_ks, e->coop_cols);
                 it = perm_of.emplace(src, dst).first;
             }
             *out = it->second;
@@ -674,11 +674,11 @@ static KhCoopArgs coop_args(const kh_engine *e, bool backward) {
 template <int MAXKS, int COLS>
 static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
                              cplx *out, int direction, hipStream_t st) {
-    const int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS>, kh_coop_lds_bytes(15));
+    const int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS>, kh_coop_lds_bytes(COLS == 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     return launch_persistent(kh_coop_sweep_store<MAXKS, COLS>, dim3(e->coop_G, e->coop_Y), dim3(KH_COOP_THREADS),
-                             kh_coop_lds_bytes(e->coop_ks), st, p, coop_args(e, direction < 0), exchange_args(e, true), pulses,
+                             kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, direction < 0), exchange_args(e, true), pulses,
                              in, store, out, direction);
 }
 
@@ -687,13 +687,13 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
                               hipStream_t st) {
     const void *func = u.sigma != nullptr ? (const void *)kh_coop_forward_update<MAXKS, COLS, true>
                                           : (const void *)kh_coop_forward_update<MAXKS, COLS, false>;
-    const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(15));
+    const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(COLS == 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     const dim3 grid(e->coop_G, e->coop_Y);
     if (u.sigma != nullptr)
-        return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks), st, p, coop_args(e, false), u, ex);
-    return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks), st, p, coop_args(e, false), u, ex);
+        return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
+    return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
 }
 
 static int sweep_store(kh_engine *e, bool backward, const double *pulses, const cplx *in, cplx *store, cplx *out,
