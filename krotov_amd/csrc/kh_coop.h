@@ -46,6 +46,8 @@ struct KhCoopArgs {
                               // workgroups, each fetching a narrower block per term with fewer loads
     int ks;                   // k-steps (of 4 columns) per wave: 32 * ks >= N
     int first_poll_delay;     // s_sleep units (64 cycles) before a round's first fetch
+    int xcd_rows;             // > 0: one-dimensional grid of 8 * xcd_rows blocks, block b = 8 g + y (see kh_coop_place)
+    unsigned int *xcc;        // [Y * G] XCC id + 1 of every workgroup (placement check, zeroed with vbuf)
     const cplx *const *fops;  // [1 + L] this direction's (shared) operators in fragment order
     const cplx *const *sq;    // one control only: P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 of this direction's
                               // operators (A^2 = P0 + eps P1 + eps^2 P2) in fragment order, or NULL: term-by-term series
@@ -56,7 +58,7 @@ struct KhCoopLds {
     double D[2][KH_COOP_MAX_L + 1];        // reduced sums + ok flag, by interval parity
     double deg[KH_MAX_DEGREE + 2];
     int abort;
-    int pad;
+    int local;  // this column group's workgroups all sit on ONE XCD: term blocks are exchanged through its L2
 #ifdef KH_TIMING
     double tim[7];
 #endif
@@ -120,6 +122,56 @@ __global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__rest
     }
 }
 
+// Workgroup placement.  The term block of a column group is written by its G workgroups and read by the same G
+// workgroups, every round.  If they all sit on ONE XCD, the block can stay in that XCD's L2: producers store with
+// workgroup scope (the line is kept in L2), consumers load with agent scope (L1 bypassed, L2-served) -- no trip
+// through the memory side.  Blocks are dispatched round-robin over the 8 XCDs (block b on XCD b % 8: observed, not
+// promised), so the launch uses a one-dimensional grid with b = 8 g + y: column group y lands on XCD y.  Nothing
+// relies on that: every workgroup publishes the XCC id it really runs on (safe protocol), and a column group uses
+// the L2 form only if all its members report the same one -- otherwise the memory-side form below.
+#define KH_HW_REG_XCC_ID 20
+__device__ __forceinline__ unsigned int kh_xcc_id() {
+    return __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | KH_HW_REG_XCC_ID) & 0xf;
+}
+__device__ __forceinline__ bool kh_coop_place(const KhCoopArgs &c, int &g, int &y) {
+    if (c.xcd_rows > 0) {
+        g = blockIdx.x >> 3;
+        y = blockIdx.x & 7;
+        return g < c.G && y < c.Y;
+    }
+    g = blockIdx.x;
+    y = blockIdx.y;
+    return true;
+}
+// (all threads; contains barriers) s.local <- 1 iff the G workgroups of column group y report one XCC id
+__device__ __forceinline__ void kh_coop_check_placement(const KhCoopArgs &c, const KhExchange &ex, KhCoopLds &s, int g,
+                                                        int y, int tid) {
+    if (tid == 0) s.local = 0;
+    if (c.xcd_rows <= 0 || c.xcc == nullptr) {
+        __syncthreads();
+        return;
+    }
+    if (tid == 0) {
+        const unsigned int mine = kh_xcc_id() + 1u;
+        __hip_atomic_store(c.xcc + (size_t)y * c.G + g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true;
+        const long long t0 = wall_clock64();
+        for (int i = 0; i < c.G && same; ++i) {
+            unsigned int v;
+            while ((v = __hip_atomic_load(c.xcc + (size_t)y * c.G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                if (wall_clock64() - t0 > ex.timeout_ticks) {  // (somebody is not there: the rounds will notice too)
+                    v = 0xffffffffu;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            same = v == mine;
+        }
+        s.local = same ? 1 : 0;
+    }
+    __syncthreads();
+}
+
 // this lane's elements of row block g of a fragment-ordered operator (NULL: zero operator)
 __device__ __forceinline__ const cplx *kh_coop_frag_src(const cplx *op, int g, int wave, int lane, int ks) {
     return op == nullptr ? nullptr : op + ((size_t)(g * KH_COOP_WAVES + wave) * ks) * 64 + lane;
@@ -164,10 +216,17 @@ __device__ __forceinline__ kh_u64 *kh_coop_slot(const KhCoopArgs &c, unsigned in
 
 // owner thread: element (row, col) of round `rid`
 __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned int rid, int y, int row, int col,
-                                                cplx v) {
+                                                cplx v, bool local = false) {
     kh_u64 *g = kh_coop_slot(c, rid, y, row, col);
     const kh_u64 tag = (kh_u64)(c.epoch_base + rid) << 32;
     const kh_u64 re = (kh_u64)__double_as_longlong(v.x), im = (kh_u64)__double_as_longlong(v.y);
+    if (local) {  // (kept in the XCD's L2: kh_coop_place)
+        __hip_atomic_store(g + 0 * KH_COOP_COLS, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(g + 1 * KH_COOP_COLS, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(g + 2 * KH_COOP_COLS, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(g + 3 * KH_COOP_COLS, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
     __hip_atomic_store(g + 0 * KH_COOP_COLS, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(g + 1 * KH_COOP_COLS, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(g + 2 * KH_COOP_COLS, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -383,9 +442,15 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
         for (int i = 0; i < 4; ++i) g[j][i] = (kh_u64)epoch << 32;
         if (j < count && row < N) {
             const kh_u64 *sl = kh_coop_slot(c, rid, y, row, lcol);
+            if (s.local) {  // one XCD: its L2 has the producers' stores (agent-scope loads bypass only the L1)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int i = 0; i < 4; ++i)
+                    g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
     bool all_fresh = true;
@@ -534,7 +599,7 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
                 const cplx t = c_mul(c_make(fre * hj, fim * hj), w);
                 state.x += t.x;
                 state.y += t.y;
-                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, j == m ? state : t);
+                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, j == m ? state : t, s.local != 0);
             }
             ++rid;
         }
@@ -580,7 +645,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
                     sacc.x = fma(hn, t2.x, sacc.x);
                     sacc.y = fma(hn, t2.y, sacc.y);
                 }
-                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, last ? sacc : t2);
+                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, last ? sacc : t2, s.local != 0);
             }
             ++rid;
         }
@@ -592,7 +657,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             const cplx odd = c_mul(c_make(fre, fim), w);
             state.x += odd.x;
             state.y += odd.y;
-            if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, state);
+            if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, state, s.local != 0);
         }
         ++rid;
     }
@@ -610,19 +675,22 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
     extern __shared__ __attribute__((aligned(16))) char kh_coop_smem[];
     KhCoopLds &s = *(KhCoopLds *)kh_coop_smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int g = blockIdx.x, y = blockIdx.y, rowbase = g * 16;
+    int g, y;
+    if (!kh_coop_place(c, g, y)) return;
+    const int rowbase = g * 16;
     const int N = p.N, nt = p.nt, L = p.L;
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
 #ifdef KH_TIMING
     if (tid < 7) s.tim[tid] = 0.0;
 #endif
+    kh_coop_check_placement(c, ex, s, g, y, tid);
     const int r = tid / COLS, col = tid % COLS, row = rowbase + r, k = y * COLS + col;
     const bool owner_valid = tid < 16 * COLS && row < N;  // (columns beyond K carry zeros)
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
     unsigned int rid = 1;
-    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state);
+    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state, s.local != 0);
     if (has_state && store != nullptr) store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + row] = state;
     __syncthreads();
     double rounds = 0.0;
@@ -663,9 +731,12 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
         const int cols = min(c.cols, p.K - y * c.cols);
         atomicAdd(p.stats, rounds * cols);
 #ifdef KH_TIMING
-        p.stats[1] = s.tim[0] / rounds + 1e6 * (double)(long long)(s.tim[4] / rounds);
-        p.stats[2] = s.tim[1] / rounds + 1e6 * (double)(long long)(100.0 * s.tim[5] / rounds);
-        p.stats[3] = s.tim[2] / rounds + 1e6 * (double)(long long)(100.0 * s.tim[6] / rounds);
+        if (y == 0) {
+            p.stats[1] = s.tim[0] / rounds + 1e6 * (double)(long long)(s.tim[4] / rounds);
+            p.stats[2] = s.tim[1] / rounds + 1e6 * (double)(long long)(100.0 * s.tim[5] / rounds);
+            p.stats[3] = s.tim[2] / rounds + 1e6 * (double)(long long)(100.0 * s.tim[6] / rounds);
+            p.stats[4] = (double)s.local;
+        }
 #endif
     }
 }
@@ -679,18 +750,21 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
     extern __shared__ __attribute__((aligned(16))) char kh_coop_smem[];
     KhCoopLds &s = *(KhCoopLds *)kh_coop_smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int g = blockIdx.x, y = blockIdx.y, rowbase = g * 16;
-    const int wg = y * gridDim.x + g;  // linear workgroup index of the exchange
+    int g, y;
+    if (!kh_coop_place(c, g, y)) return;
+    const int rowbase = g * 16;
+    const int wg = y * c.G + g;  // linear workgroup index of the exchange
     const int N = p.N, nt = p.nt, L = p.L;
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
+    kh_coop_check_placement(c, ex, s, g, y, tid);
     const int r = tid / COLS, col = tid % COLS, row = rowbase + r, k = y * COLS + col;
     const bool owner_valid = tid < 16 * COLS && row < N;
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     const double chi_norm = has_state ? u.chi_norms[k] : 0.0;
     unsigned int rid = 1;
-    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state);
+    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state, s.local != 0);
     __syncthreads();
     double rounds = 0.0;
     double g_a_loc[KH_COOP_MAX_L];

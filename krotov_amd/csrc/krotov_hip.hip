@@ -58,6 +58,8 @@ struct kh_engine {
     // cooperative shared-operator kernels (kh_coop.h): row blocks, column groups, k-steps per wave
     int coop_G = 0, coop_Y = 0, coop_ks = 0, coop_cols = KH_COOP_COLS;
     kh_u64 *d_coop_vbuf = nullptr;
+    unsigned int *d_coop_xcc = nullptr;  // [Y * G] placement check of the cooperative kernels (zeroed per launch)
+    bool coop_xcd = false;               // one column group per XCD (kh_coop.h, kh_coop_place); KH_COOP_XCD=0: off
     size_t coop_vbuf_bytes = 0;
     // device-side problem data
     const cplx **d_ops_fw = nullptr;  // [K*(1+L)]
@@ -236,6 +238,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_wg_partial);
     (void)hipFree(e->d_coop_vbuf);
+    (void)hipFree(e->d_coop_xcc);
     for (void *ptr : e->p2p_opened) (void)hipIpcCloseMemHandle(ptr);
     (void)hipFree(e->p2p_window);
     (void)hipFree((void *)e->d_p2p_peers);
@@ -419,6 +422,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             e->coop_ks = cols == 4 ? kh_coop4_slots(e->N) : (e->N + 31) / 32;  // operator-fragment slots per lane
             e->coop_vbuf_bytes = sizeof(kh_u64) * KH_COOP_RING * (size_t)Y * G * 16 * KH_COOP_COLS * 4;
             KH_HIP_E(hipMalloc(&e->d_coop_vbuf, e->coop_vbuf_bytes));
+            KH_HIP_E(hipMalloc(&e->d_coop_xcc, sizeof(unsigned int) * (size_t)G * Y));
+            e->coop_xcd = cols == 4 && Y <= 8 && G <= 32 && !(getenv("KH_COOP_XCD") && atoi(getenv("KH_COOP_XCD")) == 0);
             e->grid_update = e->K < max_wgs ? e->K : max_wgs;  // (stepwise launches use the generic kernel)
             // A round (one Taylor term) costs a cross-workgroup exchange here, so fewer, longer
             // sub-steps pay: theta <= 4 needs ~31 terms per sub-step against 4 x 18 at theta <= 1.
@@ -668,6 +673,8 @@ static KhCoopArgs coop_args(const kh_engine *e, bool backward) {
     c.ks = e->coop_ks;
     c.cols = e->coop_cols;
     c.first_poll_delay = e->coop_poll_delay;
+    c.xcd_rows = e->coop_xcd ? e->coop_G : 0;
+    c.xcc = e->d_coop_xcc;
     return c;
 }
 
@@ -677,7 +684,8 @@ static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *p
     const int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS>, kh_coop_lds_bytes(COLS == 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
-    return launch_persistent(kh_coop_sweep_store<MAXKS, COLS>, dim3(e->coop_G, e->coop_Y), dim3(KH_COOP_THREADS),
+    KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
+    return launch_persistent(kh_coop_sweep_store<MAXKS, COLS>, e->coop_xcd ? dim3(8 * e->coop_G) : dim3(e->coop_G, e->coop_Y), dim3(KH_COOP_THREADS),
                              kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, direction < 0), exchange_args(e, true), pulses,
                              in, store, out, direction);
 }
@@ -690,7 +698,8 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(COLS == 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
-    const dim3 grid(e->coop_G, e->coop_Y);
+    KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
+    const dim3 grid = e->coop_xcd ? dim3(8 * e->coop_G) : dim3(e->coop_G, e->coop_Y);
     if (u.sigma != nullptr)
         return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
     return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);

@@ -15,6 +15,7 @@ chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
 for _ in range(2):
     chi = eng.backward(chi_T, pulses)
 buf = (ctypes.c_double * 4)()
+os.environ['KH_TRACE'] = '1'  # (the timing build prints the stamps behind the four statistics: [0] = term blocks through one XCD's L2?)
 torch.cuda.synchronize()
 eng._lib.kh_last_stats(eng._handle, buf)
 print('rounds*cols %d  cycles/round: poll %.0f (fast pass %d)  mfma+lds write %.0f  barrier %.0f | stale lanes after the fast pass %.2f/64, '
