@@ -1078,3 +1078,52 @@ def test_optimize_pulses_survives_a_busy_stream(monkeypatch):
     torch.cuda.synchronize()
     assert np.abs(np.array(busy.all_pulses) - np.array(calm.all_pulses)).max() < 1e-12
     assert np.abs(np.array(busy.tau_vals) - np.array(calm.tau_vals)).max() < 1e-12
+
+
+MM_CASES = {
+    'c5_n64': lambda: configs.config_c5(K=8, N=64, nt=61),
+    'c5_n33': lambda: configs.config_c5(K=5, N=33, nt=41),
+    'c5_k24_long': lambda: configs.config_c5(K=24, N=64, nt=301, distinct=True),  # several restarts of the tiles
+    'c5_n20_small_norm': lambda: _scaled(configs.config_c5(K=12, N=20, nt=41), 2e-3),   # degree 4: P = 2, Pf = 1
+    'c5_n20_tiny_norm': lambda: _scaled(configs.config_c5(K=12, N=20, nt=41), 1e-7),    # degree 2: P = 1
+    'c5_n48_large_norm': lambda: _scaled(configs.config_c5(K=9, N=48, nt=41), 3.0),     # sub-steps (theta > 1)
+}
+
+
+def _scaled(spec, factor):
+    """The same problem with every operator multiplied by ``factor`` (other series degrees / sub-step counts)."""
+    spec.H0 = [factor * h for h in spec.H0]
+    spec.Hc = [[factor * h for h in row] for row in spec.Hc]
+    return spec
+
+
+@pytest.mark.parametrize('name', sorted(MM_CASES))
+def test_matrix_core_update_kernel(name, monkeypatch):
+    """KH_MM=1: the update sweep with the partial sum taken in the middle of the series (kh_tile64mm.h) against the
+    oracle, and its pulses against the default kernel's."""
+    spec = MM_CASES[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    ref_T = ko.forward_propagation(prob, gp, store=False)
+    chi_T = CHI[spec.chi](prob, ref_T, ko.tau_vals(prob, ref_T))
+    norms = np.linalg.norm(chi_T, axis=1)
+    chi_T = chi_T / norms[:, None]
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    out = {}
+    for mm in ('0', '1'):
+        monkeypatch.setenv('KH_MM', mm)
+        eng = _engine(spec)
+        chi = eng.backward(chi_T, pulses)
+        opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+        eng.check()
+        out[mm] = (opt.cpu().numpy(), psi_T.cpu().numpy(), g_a.cpu().numpy(), eng.stats()['matvecs'])
+        eng.close()
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    for mm in ('0', '1'):
+        assert np.abs(out[mm][0] - np.array(ref_opt)).max() < 1e-12 * scale
+        assert np.abs(out[mm][1] - ref_psi).max() < 1e-12
+        assert np.abs(out[mm][2] - ref_ga).max() < 1e-12 * max(1.0, np.abs(ref_ga).max())
+    assert np.abs(out['1'][0] - out['0'][0]).max() < 1e-13 * scale
+    assert out['1'][3] != out['0'][3]  # (the two kernels issue different numbers of products: KH_MM was honoured)
