@@ -39,7 +39,8 @@
 typedef double kh_d4 __attribute__((ext_vector_type(4)));
 
 struct KhCoopArgs {
-    kh_u64 *vbuf;             // [KH_COOP_RING][Y][G*16][4][16] granules (columns >= cols unused)
+    kh_u64 *vbuf;             // cols = 16: [KH_COOP_RING][Y][G*16][4][16] granules; cols = 4: [KH_COOP_RING][Y][G]
+                              // [2][64][2], a 16-row group in the CONSUMER's lane order (kh_coop_slot4)
     unsigned int epoch_base;  // rounds of earlier launches (tags are monotonic: the buffer is never cleared)
     int G, Y;                 // row blocks, column groups
     int cols;                 // objectives per column group (the kernels' COLS): 16 or 4.  Fewer columns = more
@@ -69,7 +70,7 @@ struct KhCoopLds {
 
 __host__ __device__ inline size_t kh_coop_lds_bytes(int ks, int cols = KH_COOP_COLS) {
     return sizeof(KhCoopLds) + sizeof(double) * 2 * (size_t)ks * KH_COOP_THREADS +
-           sizeof(double) * KH_COOP_WAVES * (cols == 4 ? 2 : 8) * 64;
+           sizeof(double) * KH_COOP_WAVES * (cols <= 4 ? 2 : 8) * 64;
 }
 __device__ __forceinline__ double *kh_coop_part(KhCoopLds &s, int ks) { return s.frag + 2 * (size_t)ks * KH_COOP_THREADS; }
 
@@ -88,6 +89,17 @@ struct KhCoopFrag {
     double *f;  // s.frag + tid
     __device__ __forceinline__ double &re(int q) const { return f[(size_t)(2 * q) * KH_COOP_THREADS]; }
     __device__ __forceinline__ double &im(int q) const { return f[(size_t)(2 * q + 1) * KH_COOP_THREADS]; }
+    __device__ __forceinline__ bool nz(int) const { return true; }
+};
+
+// The same view of a fragment held in registers (slot index known at compile time after unrolling)
+template <int MAXKS, bool MASKED = false>
+struct KhCoopRegFrag {
+    const cplx (&v)[MAXKS];
+    unsigned int mask;  // MASKED: bit q clear = slot q is zero in every lane of the wave (its products are skipped)
+    __device__ __forceinline__ double re(int q) const { return v[q].x; }
+    __device__ __forceinline__ double im(int q) const { return v[q].y; }
+    __device__ __forceinline__ bool nz(int q) const { return !MASKED || ((mask >> q) & 1u) != 0u; }
 };
 
 // Operators are re-laid out once, at engine creation, in "fragment order": the element that lane `lane` of
@@ -108,7 +120,7 @@ __global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__rest
         const size_t t = idx >> 6;
         const int q = (int)(t % ks), wave = (int)((t / ks) % KH_COOP_WAVES), g = (int)(t / ks / KH_COOP_WAVES);
         int row, col;
-        if (cols == 4) {
+        if (cols <= 4) {
             int start, count;
             kh_coop4_share(N, wave, &start, &count);
             const int gi = q >> 2, rb = q & 3;
@@ -120,6 +132,29 @@ __global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__rest
         }
         out[idx] = (row < N && col < N) ? in[(size_t)row * N + col] : c_make(0.0, 0.0);
     }
+}
+
+// Zero slots.  Operators of physical models are often sparse in places (a control Hamiltonian's commutator
+// superoperator has a few entries per row; so has its square), and every table is zero-padded from N to the waves'
+// share of 16-column groups.  A slot -- the 64 elements one wave loads at once -- that is zero in all lanes is
+// marked once, at engine creation, in a 32-bit word per (row block, wave) stored BEHIND the table; fragment loads,
+// updates and (for the control operators' products) matrix-core instructions skip such slots.  Exact: skipped
+// terms are exact zeros.
+__global__ void kh_coop_mask_kernel(const cplx *__restrict__ tab, unsigned int *__restrict__ mask, int ks) {
+    const int lane = threadIdx.x;  // one wave per (row block, wave)
+    const cplx *src = tab + (size_t)blockIdx.x * ks * 64 + lane;
+    unsigned int m = 0;
+    for (int q = 0; q < ks; ++q) {
+        const cplx v = src[(size_t)q * 64];
+        if (__ballot(v.x != 0.0 || v.y != 0.0) != 0ull) m |= 1u << q;
+    }
+    if (lane == 0) mask[blockIdx.x] = m;
+}
+__host__ __device__ inline size_t kh_coop_table_elems(int G, int ks) { return (size_t)G * KH_COOP_WAVES * ks * 64; }
+__device__ __forceinline__ unsigned int kh_coop_frag_mask(const cplx *op, int G, int g, int wave, int ks) {
+    if (op == nullptr) return 0u;
+    const unsigned int *m = (const unsigned int *)(op + kh_coop_table_elems(G, ks));
+    return __builtin_amdgcn_readfirstlane(m[g * KH_COOP_WAVES + wave]);
 }
 
 // Workgroup placement.  The term block of a column group is written by its G workgroups and read by the same G
@@ -179,12 +214,12 @@ __device__ __forceinline__ const cplx *kh_coop_frag_src(const cplx *op, int g, i
 
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_load_frag(const cplx *op, int g, int wave, int lane, int ks,
-                                                  const KhCoopFrag &f) {
+                                                  const KhCoopFrag &f, unsigned int mask = ~0u) {
     const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
         if (q < ks) {
-            const cplx v = src != nullptr ? src[(size_t)q * 64] : c_make(0.0, 0.0);
+            const cplx v = (src != nullptr && ((mask >> q) & 1u)) ? src[(size_t)q * 64] : c_make(0.0, 0.0);
             f.re(q) = v.x;
             f.im(q) = v.y;
         }
@@ -194,12 +229,12 @@ __device__ __forceinline__ void kh_coop_load_frag(const cplx *op, int g, int wav
 // a += eps * op  (same fragment layout)
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_axpy_frag(const cplx *op, double eps, int g, int wave, int lane, int ks,
-                                                  const KhCoopFrag &a) {
+                                                  const KhCoopFrag &a, unsigned int mask = ~0u) {
     const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
     if (src == nullptr) return;
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
-        if (q < ks) {
+        if (q < ks && ((mask >> q) & 1u)) {
             const cplx v = src[(size_t)q * 64];
             a.re(q) = fma(eps, v.x, a.re(q));
             a.im(q) = fma(eps, v.y, a.im(q));
@@ -214,12 +249,68 @@ __device__ __forceinline__ kh_u64 *kh_coop_slot(const KhCoopArgs &c, unsigned in
            (((size_t)(rid % KH_COOP_RING) * c.Y + y) * ((size_t)c.G * 16) + row) * (4 * KH_COOP_COLS) + col;
 }
 
+// 4 objectives per workgroup: a 16-row group of the block is 2 KiB laid out as the consumer's wave reads it --
+// [half: re, im][lane][2 granules: hi, lo], lane (hi, b, lo) <-> row 4 b + hi, column lo (kh_coop_round4) -- so
+// one 16-byte load per lane and half fetches eight whole 128-byte lines (the first layout, 4 columns of the
+// 16-column rows above, touched 64 lines per group with 32 useful bytes each: the round's fetch was bound by the
+// number of line requests a CU can issue, 2048 per round, not by latency).
+__device__ __forceinline__ int kh_coop4_lane(int row_in_group, int col) {
+    return 16 * (row_in_group & 3) + 4 * (row_in_group >> 2) + col;
+}
+__device__ __forceinline__ size_t kh_coop_group4(const KhCoopArgs &c, unsigned int rid, int y, int group) {
+    return (((size_t)(rid % KH_COOP_RING) * c.Y + y) * (size_t)c.G + group) * 256;  // (granules)
+}
+__device__ __forceinline__ kh_u64 *kh_coop_slot4(const KhCoopArgs &c, unsigned int rid, int y, int group) {
+    return c.vbuf + kh_coop_group4(c, rid, y, group);
+}
+typedef unsigned int kh_u32x4 __attribute__((ext_vector_type(4)));
+#define KH_CPOL_SC0 1           // workgroup scope (may be served by the L1 / a stale L2 line)
+#define KH_CPOL_SC1 16          // agent scope
+#define KH_CPOL_VOLATILE (1u << 31)
+// two granules (16 bytes) of the lane's element; each granule carries its own tag, so only 8-byte atomicity is used
+template <int CPOL>
+__device__ __forceinline__ void kh_coop_load2(__amdgpu_buffer_rsrc_t rsrc, unsigned int byte_off, kh_u64 &a, kh_u64 &b) {
+    const kh_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, (int)(CPOL | KH_CPOL_VOLATILE));
+    a = (kh_u64)v.x | ((kh_u64)v.y << 32);
+    b = (kh_u64)v.z | ((kh_u64)v.w << 32);
+}
+
 // owner thread: element (row, col) of round `rid`
 __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned int rid, int y, int row, int col,
                                                 cplx v, bool local = false) {
-    kh_u64 *g = kh_coop_slot(c, rid, y, row, col);
     const kh_u64 tag = (kh_u64)(c.epoch_base + rid) << 32;
     const kh_u64 re = (kh_u64)__double_as_longlong(v.x), im = (kh_u64)__double_as_longlong(v.y);
+    if (c.cols == 2) {  // (a group is 1 KiB: [lane][2 granules], lane column n = re of objective n / im of objective n - 2)
+        kh_u64 *g = c.vbuf + kh_coop_group4(c, rid, y, row >> 4) / 2 + 2 * kh_coop4_lane(row & 15, col);
+        if (local) {
+            __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(g + 4, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(g + 5, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 4, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 5, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (c.cols == 4) {
+        kh_u64 *g = kh_coop_slot4(c, rid, y, row >> 4) + 2 * kh_coop4_lane(row & 15, col);
+        if (local) {
+            __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(g + 128, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(g + 129, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 128, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 129, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    kh_u64 *g = kh_coop_slot(c, rid, y, row, col);
     if (local) {  // (kept in the XCD's L2: kh_coop_place)
         __hip_atomic_store(g + 0 * KH_COOP_COLS, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(g + 1 * KH_COOP_COLS, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -243,9 +334,9 @@ __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned in
 // block (lane -> k offset lane / 4, column lane % 4) instead of one with 48 idle lanes -- the round is
 // bound by the number of wave-level loads the CU issues (8 waves x 52 at N = 400), not by their bytes --
 // and the elements are moved into the MFMA operand layout with ds_bpermute.
-template <int MAXKS, int COLS>
+template <int MAXKS, int COLS, class Frag>
 __device__ __forceinline__ void kh_coop_round16(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y,
-                                              int N, const KhCoopFrag &f, KhCoopLds &s, int tid, int wave, int lane,
+                                              int N, const Frag &f, KhCoopLds &s, int tid, int wave, int lane,
                                               cplx &w) {
     double *part = kh_coop_part(s, c.ks);
     constexpr int KPL = 16 / COLS;               // k-steps per load group
@@ -418,38 +509,43 @@ __device__ __forceinline__ void kh_coop_round16(const KhCoopArgs &c, const KhExc
 // no replication across blocks, no ds_bpermute (208 of them per wave and round in the first version: 1.2 us).
 // Four row groups rb = 0..3 need four MFMA sets per group; the blocks' partial sums are added with two row
 // rotations, and the wave's 16 x 4 block goes to LDS as 64 values per component: element (row r, column c) at 4 r + c.
-template <int MAXKS>
+template <int MAXKS, int COLS, class Frag>
 __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y, int N,
-                                               const KhCoopFrag &f, KhCoopLds &s, int tid, int wave, int lane, cplx &w) {
+                                               const Frag &f, KhCoopLds &s, int tid, int wave, int lane, cplx &w) {
     constexpr int MAXG = MAXKS / 4;  // groups per wave
     double *part = kh_coop_part(s, c.ks);
     const unsigned int epoch = c.epoch_base + rid;
     int start, count;
     kh_coop4_share(N, wave, &start, &count);
-    const int roff = 4 * ((lane >> 2) & 3) + (lane >> 4), lcol = lane & 3;  // this lane's element of a group
-    kh_u64 g[MAXG][4];
+    const int roff = 4 * ((lane >> 2) & 3) + (lane >> 4);  // this lane's row of a group (column lane & 3)
+    constexpr int NGR = COLS == 4 ? 4 : 2;         // granules of a lane's operand element
+    constexpr unsigned int GB = COLS == 4 ? 2048u : 1024u;  // bytes of a group in the ring
+    kh_u64 g[MAXG][NGR];
     const long long t0 = wall_clock64();
 #ifdef KH_TIMING
     const long long tq0 = clock64();
 #endif
     unsigned int spins = 0;
     for (int d = 0; d < c.first_poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+    // The whole ring as one buffer resource (KH_COOP_RING * Y * G * 2 KiB < 2 GiB: checked at engine creation);
+    // lane offsets inside a group are compile-time + 16 lane.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)c.vbuf, 0, (int)((size_t)KH_COOP_RING * c.Y * c.G * GB), 0x00020000);
+    const unsigned int ring_off = (unsigned int)(kh_coop_group4(c, rid, y, 0) * 8 / (2048u / GB)) + 16u * lane;
     // first pass through L2 (fast; may see a stale line); padding: tag ok, value +0.0
 #pragma unroll
     for (int j = 0; j < MAXG; ++j) {
         const int row = 16 * (start + j) + roff;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[j][i] = (kh_u64)epoch << 32;
+        for (int i = 0; i < NGR; ++i) g[j][i] = (kh_u64)epoch << 32;
         if (j < count && row < N) {
-            const kh_u64 *sl = kh_coop_slot(c, rid, y, row, lcol);
+            const unsigned int off = ring_off + GB * (start + j);
             if (s.local) {  // one XCD: its L2 has the producers' stores (agent-scope loads bypass only the L1)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                kh_coop_load2<KH_CPOL_SC1>(rsrc, off, g[j][0], g[j][1]);
+                if constexpr (COLS == 4) kh_coop_load2<KH_CPOL_SC1>(rsrc, off + 1024u, g[j][2], g[j][3]);
             } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                kh_coop_load2<KH_CPOL_SC0>(rsrc, off, g[j][0], g[j][1]);
+                if constexpr (COLS == 4) kh_coop_load2<KH_CPOL_SC0>(rsrc, off + 1024u, g[j][2], g[j][3]);
             }
         }
     }
@@ -457,7 +553,7 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
 #pragma unroll
     for (int j = 0; j < MAXG; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) all_fresh = all_fresh && ((unsigned int)(g[j][i] >> 32) == epoch);
+        for (int i = 0; i < NGR; ++i) all_fresh = all_fresh && ((unsigned int)(g[j][i] >> 32) == epoch);
 #ifdef KH_TIMING
     {
         const int stale_lanes = __popcll(__ballot(!all_fresh));
@@ -476,17 +572,19 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
         for (int j = 0; j < MAXG; ++j) {
             const int row = 16 * (start + j) + roff;
             if (j < count && row < N) {
-                const kh_u64 *sl = kh_coop_slot(c, rid, y, row, lcol);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if ((unsigned int)(g[j][i] >> 32) != epoch)
-                        g[j][i] = __hip_atomic_load(sl + i * KH_COOP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int off = ring_off + GB * (start + j);
+                if ((unsigned int)(g[j][0] >> 32) != epoch || (unsigned int)(g[j][1] >> 32) != epoch)
+                    kh_coop_load2<KH_CPOL_SC1>(rsrc, off, g[j][0], g[j][1]);
+                if constexpr (COLS == 4) {
+                    if ((unsigned int)(g[j][2] >> 32) != epoch || (unsigned int)(g[j][3] >> 32) != epoch)
+                        kh_coop_load2<KH_CPOL_SC1>(rsrc, off + 1024u, g[j][2], g[j][3]);
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < MAXG; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ok = ok && ((unsigned int)(g[j][i] >> 32) == epoch);
+            for (int i = 0; i < NGR; ++i) ok = ok && ((unsigned int)(g[j][i] >> 32) == epoch);
         all_fresh = ok;
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(2);
@@ -507,32 +605,60 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
     const long long tq1 = clock64();
 #endif
     double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};  // one accumulator pair per row group
+    if constexpr (COLS == 4) {
 #pragma unroll
-    for (int j = 0; j < MAXG; ++j) {
-        if (j < count) {
-            const double vr = __hiloint2double((int)(unsigned int)(g[j][0] & 0xffffffffull), (int)(unsigned int)(g[j][1] & 0xffffffffull));
-            const double vi = __hiloint2double((int)(unsigned int)(g[j][2] & 0xffffffffull), (int)(unsigned int)(g[j][3] & 0xffffffffull));
+        for (int j = 0; j < MAXG; ++j) {
+            if (j < count) {
+                const double vr = __hiloint2double((int)(unsigned int)(g[j][0] & 0xffffffffull), (int)(unsigned int)(g[j][1] & 0xffffffffull));
+                const double vi = __hiloint2double((int)(unsigned int)(g[j][2] & 0xffffffffull), (int)(unsigned int)(g[j][3] & 0xffffffffull));
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const double fr = f.re(4 * j + rb), fi = f.im(4 * j + rb);
-                ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vr, ar[rb], 0, 0, 0);
-                ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fi, -vi, ar[rb], 0, 0, 0);
-                ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vi, ai[rb], 0, 0, 0);
-                ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fi, vr, ai[rb], 0, 0, 0);
+                for (int rb = 0; rb < 4; ++rb) {
+                    if (!f.nz(4 * j + rb)) continue;
+                    const double fr = f.re(4 * j + rb), fi = f.im(4 * j + rb);
+                    ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vr, ar[rb], 0, 0, 0);
+                    ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fi, -vi, ar[rb], 0, 0, 0);
+                    ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vi, ai[rb], 0, 0, 0);
+                    ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fi, vr, ai[rb], 0, 0, 0);
+                }
             }
         }
-    }
-    // D lane = 16 (row within the group) + 4 (block = k-step) + column: add the four blocks, one lane of four writes
+        // D lane = 16 (row within the group) + 4 (block = k-step) + column: add the four blocks, one lane of four writes
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-        ar[rb] += dpp_move<KH_DPP_ROR8>(ar[rb]);
-        ar[rb] += dpp_move<KH_DPP_ROR4>(ar[rb]);
-        ai[rb] += dpp_move<KH_DPP_ROR8>(ai[rb]);
-        ai[rb] += dpp_move<KH_DPP_ROR4>(ai[rb]);
-        if (((lane >> 2) & 3) == 0) {
-            const int e = 16 * rb + 4 * (lane >> 4) + (lane & 3);
-            part[(wave * 2 + 0) * 64 + e] = ar[rb];
-            part[(wave * 2 + 1) * 64 + e] = ai[rb];
+        for (int rb = 0; rb < 4; ++rb) {
+            ar[rb] += dpp_move<KH_DPP_ROR8>(ar[rb]);
+            ar[rb] += dpp_move<KH_DPP_ROR4>(ar[rb]);
+            ai[rb] += dpp_move<KH_DPP_ROR8>(ai[rb]);
+            ai[rb] += dpp_move<KH_DPP_ROR4>(ai[rb]);
+            if (((lane >> 2) & 3) == 0) {
+                const int e = 16 * rb + 4 * (lane >> 4) + (lane & 3);
+                part[(wave * 2 + 0) * 64 + e] = ar[rb];
+                part[(wave * 2 + 1) * 64 + e] = ai[rb];
+            }
+        }
+    } else {
+        // 2 objectives: the operand's four columns are [re c0, re c1, im c0, im c1], so Re(F) and Im(F) need ONE
+        // MFMA each per group and row block (half the matrix-core work per objective of the 4-column form, which
+        // spends four); Re(F) X gives [Fr Xr | Fr Xi], Im(F) X gives [Fi Xr | Fi Xi]: the result is
+        // [Fr Xr - Fi Xi | Fr Xi + Fi Xr] = first + (-1, +1) * (second with its column pairs swapped).
+#pragma unroll
+        for (int j = 0; j < MAXG; ++j) {
+            if (j < count) {
+                const double v = __hiloint2double((int)(unsigned int)(g[j][0] & 0xffffffffull), (int)(unsigned int)(g[j][1] & 0xffffffffull));
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    if (!f.nz(4 * j + rb)) continue;
+                    ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.re(4 * j + rb), v, ar[rb], 0, 0, 0);
+                    ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.im(4 * j + rb), v, ai[rb], 0, 0, 0);
+                }
+            }
+        }
+        const double sgn = (lane & 2) ? 1.0 : -1.0;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            double e = fma(sgn, dpp_move<KH_DPP_XOR2>(ai[rb]), ar[rb]);
+            e += dpp_move<KH_DPP_ROR8>(e);
+            e += dpp_move<KH_DPP_ROR4>(e);
+            if (((lane >> 2) & 3) == 0) part[wave * 64 + 16 * rb + 4 * (lane >> 4) + (lane & 3)] = e;
         }
     }
 #ifdef KH_TIMING
@@ -549,24 +675,59 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
     }
 #endif
     w = c_make(0.0, 0.0);
-    if (tid < 64) {  // owner of element (row tid / 4, column tid % 4)
+    if constexpr (COLS == 4) {
+        if (tid < 64) {  // owner of element (row tid / 4, column tid % 4)
 #pragma unroll
-        for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
-            w.x += part[(wv * 2 + 0) * 64 + tid];
-            w.y += part[(wv * 2 + 1) * 64 + tid];
+            for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
+                w.x += part[(wv * 2 + 0) * 64 + tid];
+                w.y += part[(wv * 2 + 1) * 64 + tid];
+            }
+        }
+    } else {
+        if (tid < 32) {  // owner of element (row tid / 2, column tid % 2): re at [4 row + column], im two further
+            const int e = 4 * (tid >> 1) + (tid & 1);
+#pragma unroll
+            for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
+                w.x += part[wv * 64 + e];
+                w.y += part[wv * 64 + e + 2];
+            }
         }
     }
     __syncthreads();  // part[] is free for the next round
 }
 
-template <int MAXKS, int COLS>
+template <int MAXKS, int COLS, class Frag>
 __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y,
-                                              int N, const KhCoopFrag &f, KhCoopLds &s, int tid, int wave, int lane,
+                                              int N, const Frag &f, KhCoopLds &s, int tid, int wave, int lane,
                                               cplx &w) {
-    if constexpr (COLS == 4)
-        kh_coop_round4<MAXKS>(c, ex, rid, y, N, f, s, tid, wave, lane, w);
+    if constexpr (COLS <= 4)
+        kh_coop_round4<MAXKS, COLS>(c, ex, rid, y, N, f, s, tid, wave, lane, w);
     else
         kh_coop_round16<MAXKS, COLS>(c, ex, rid, y, N, f, s, tid, wave, lane, w);
+}
+
+// register fragment <- / += eps * (fragment-ordered operator)
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_reg_load(const cplx *op, int g, int wave, int lane, int ks, cplx (&r)[MAXKS],
+                                                 unsigned int mask = ~0u) {
+    const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q)
+        r[q] = (q < ks && src != nullptr && ((mask >> q) & 1u)) ? src[(size_t)q * 64] : c_make(0.0, 0.0);
+}
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_reg_axpy(const cplx *op, double eps, int g, int wave, int lane, int ks,
+                                                 cplx (&r)[MAXKS], unsigned int mask = ~0u) {
+    const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
+    if (src == nullptr) return;
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q) {
+        if (q < ks && ((mask >> q) & 1u)) {
+            const cplx v = src[(size_t)q * 64];
+            r[q].x = fma(eps, v.x, r[q].x);
+            r[q].y = fma(eps, v.y, r[q].y);
+        }
+    }
 }
 
 // A = op_0 + sum_l eps_l op_l (fragments rebuilt from L2 once per interval; ops: fragment-ordered copies)
@@ -614,9 +775,37 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
 // while the even terms go by, the last B round publishes s instead of a term, and ONE round with the A
 // fragment finishes the step.  ceil(m/2) + 1 rounds (each one cross-workgroup exchange) instead of m; the
 // fragment in LDS is rebuilt twice per step (B, then A) from L2.
+// The fragments are not rebuilt per interval but advanced: B (LDS) += (eps - eps') P1 + (eps^2 - eps'^2) P2 and
+// A (registers) += (eps - eps') H1 -- three table reads per interval instead of five; the caller restarts them from
+// P0 / H0 (kh_coop_sq_restart) every KH_COOP_REFRESH intervals, so rounding cannot drift.
+#define KH_COOP_REFRESH 64
+struct KhCoopSqMasks {
+    unsigned int h0, h1, p0, p1, p2;  // zero-slot masks of this wave's fragments (kh_coop_mask_kernel)
+};
+__device__ __forceinline__ KhCoopSqMasks kh_coop_sq_masks(const KhCoopArgs &c, int g, int wave) {
+    KhCoopSqMasks m = {0u, 0u, 0u, 0u, 0u};
+    if (c.sq != nullptr) {
+        m.h0 = kh_coop_frag_mask(c.fops[0], c.G, g, wave, c.ks);
+        m.h1 = kh_coop_frag_mask(c.fops[1], c.G, g, wave, c.ks);
+        m.p0 = kh_coop_frag_mask(c.sq[0], c.G, g, wave, c.ks);
+        m.p1 = kh_coop_frag_mask(c.sq[1], c.G, g, wave, c.ks);
+        m.p2 = kh_coop_frag_mask(c.sq[2], c.G, g, wave, c.ks);
+    }
+    return m;
+}
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_sq_restart(const KhCoopArgs &c, const KhCoopSqMasks &mk, int g, int wave,
+                                                   int lane, const KhCoopFrag &b, cplx (&areg)[MAXKS],
+                                                   double &eps_prev) {
+    kh_coop_load_frag<MAXKS>(c.sq[0], g, wave, lane, c.ks, b, mk.p0);
+    kh_coop_reg_load<MAXKS>(c.fops[0], g, wave, lane, c.ks, areg, mk.h0);
+    eps_prev = 0.0;
+}
+
 template <int MAXKS, int COLS>
 __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, const KhExchange &ex,
-                                                       double eps, const KhCoopFrag &a,
+                                                       const KhCoopSqMasks &mk, double eps, double &eps_prev, const KhCoopFrag &a,
+                                                       cplx (&areg)[MAXKS],
                                                        cplx &state, unsigned int &rid, KhCoopLds &s, int N, int y,
                                                        int g, int row, int col, bool owner_valid, double fre,
                                                        double fim, double dt, int nsub, int m, int tid, int wave,
@@ -624,11 +813,17 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
     const double h = nsub == 1 ? dt : dt / nsub;
     const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
     const int phases = (m + 1) >> 1;
-    const double eps1[1] = {eps};
+#ifndef KH_COOP_X_NOREBUILD  // (timing experiment: wrong results)
+    {
+        const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
+        kh_coop_axpy_frag<MAXKS>(c.sq[1], e1, g, wave, lane, c.ks, a, mk.p1);
+        kh_coop_axpy_frag<MAXKS>(c.sq[2], e2, g, wave, lane, c.ks, a, mk.p2);
+        kh_coop_reg_axpy<MAXKS>(c.fops[1], e1, g, wave, lane, c.ks, areg, mk.h1);
+        eps_prev = eps;
+    }
+#endif
+    const KhCoopRegFrag<MAXKS> af = {areg, ~0u};
     for (int sub = 0; sub < nsub; ++sub) {
-        kh_coop_load_frag<MAXKS>(c.sq[0], g, wave, lane, c.ks, a);
-        kh_coop_axpy_frag<MAXKS>(c.sq[1], eps, g, wave, lane, c.ks, a);
-        kh_coop_axpy_frag<MAXKS>(c.sq[2], eps * eps, g, wave, lane, c.ks, a);
         cplx sacc = c_make(h * state.x, h * state.y);
         for (int ph = 0; ph < phases; ++ph) {
             cplx w;
@@ -649,9 +844,8 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             }
             ++rid;
         }
-        kh_coop_build<MAXKS>(c.fops, eps1, 1, g, wave, lane, c.ks, a);
         cplx w;
-        kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+        kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, af, s, tid, wave, lane, w);
         if (s.abort) return false;
         if (tid < 16 * COLS) {
             const cplx odd = c_mul(c_make(fre, fim), w);
@@ -696,8 +890,14 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
     double rounds = 0.0;
     int m_hint = 12;
     const KhCoopFrag a = {s.frag + tid};
+    cplx areg[MAXKS];
+    double eps_prev = 0.0;
+    const KhCoopSqMasks mk = kh_coop_sq_masks(c, g, wave);
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q) areg[q] = c_make(0.0, 0.0);
     for (int step = 0; step < nt - 1; ++step) {
         const int n = direction > 0 ? step : nt - 2 - step;
+        if (c.sq != nullptr && step % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, areg, eps_prev);
         double eps[KH_COOP_MAX_L];
         double theta = p.op_norms[0];
 #pragma unroll
@@ -713,7 +913,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         if (c.sq != nullptr) {
-            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, eps[0], a, state, rid, s, N, y, g, row, col,
+            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, areg, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
                 return;
             rounds += (double)nsub * (((m + 1) >> 1) + 1);
@@ -772,8 +972,14 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
     for (int l = 0; l < KH_COOP_MAX_L; ++l) g_a_loc[l] = 0.0;
     int m_hint = 12;
     const KhCoopFrag a = {s.frag + tid};
+    cplx areg[MAXKS];
+    double eps_prev = 0.0;
+    const KhCoopSqMasks mk = kh_coop_sq_masks(c, g, wave);
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q) areg[q] = c_make(0.0, 0.0);
     for (int n = 0; n < nt - 1; ++n) {
         const int par = n & 1;
+        if (c.sq != nullptr && n % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, areg, eps_prev);
         // co-state (and, second order, previous-iteration state) element of this owner
         cplx bra = has_state ? u.chi_store[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0);
         if constexpr (SO) {
@@ -788,9 +994,16 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
 #pragma unroll
         for (int l = 0; l < KH_COOP_MAX_L; ++l) {
             if (l >= L) break;
-            kh_coop_load_frag<MAXKS>(c.fops[1 + l], g, wave, lane, c.ks, a);
             cplx w;
-            kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+            if (c.sq != nullptr) {  // (the LDS fragment holds B for the whole sweep: the control operator from registers)
+                cplx hreg[MAXKS];
+                kh_coop_reg_load<MAXKS>(c.fops[1 + l], g, wave, lane, c.ks, hreg, mk.h1);  // (sq: one control, l = 0)
+                const KhCoopRegFrag<MAXKS, true> hf = {hreg, mk.h1};
+                kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, hf, s, tid, wave, lane, w);
+            } else {
+                kh_coop_load_frag<MAXKS>(c.fops[1 + l], g, wave, lane, c.ks, a);
+                kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+            }
             if (wave < 4) {  // (lanes that own no element contribute zeros: chi_norm, bra, w are 0 there)
                 cplx ov = c_make(0.0, 0.0);
                 c_fma_conj(ov, bra, w);
@@ -834,7 +1047,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange e
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         if (c.sq != nullptr) {
-            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, eps[0], a, state, rid, s, N, y, g, row, col,
+            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, areg, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
                 return;
             rounds += (double)nsub * (((m + 1) >> 1) + 1);

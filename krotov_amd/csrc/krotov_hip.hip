@@ -99,7 +99,8 @@ struct kh_engine {
     // tuning knobs (s_sleep units of 64 cycles), read from the environment once at creation
     int poll_delay = 16;       // KH_POLL_DELAY: head start of the update-sum stores, ~0.4 us: measured best
     int adj_poll_delay = 0;    // KH_ADJ_DELAY: the same where a matrix-vector product already sits between store and poll
-    int coop_poll_delay = 12;  // KH_COOP_DELAY: the same for the cooperative kernels' block exchange
+    int coop_poll_delay = 0;   // KH_COOP_DELAY: the same for the cooperative kernels' block exchange (a polling pass is four
+                               // 16-byte loads per lane there: an early, stale pass costs little -- measured 0 best)
     double adj_sign = 0.0;  // +1 / -1: every control operator equals +/- its adjoint exactly (else 0)
     bool real_spectrum = false;  // every operator Hermitian (bit for bit) and f = -+i
     bool hermitian = false;      // the same, whichever series tables are in use (KH_TAYLOR): kh_tile64mm.h
@@ -406,9 +407,12 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         // the block fetch, which shrinks with the column count; the MFMA work per workgroup does not grow)
         const int G = (e->N + 15) / 16;
         int cols = G * ((e->K + 3) / 4) <= max_wgs ? 4 : KH_COOP_COLS;
+        // two objectives per workgroup (half the matrix-core work of a round per workgroup, twice the workgroups)
+        // where every column group still gets an XCD of its own (kh_coop_place): up to 8 groups of at most 32
+        if (e->K > 8 && (e->K + 1) / 2 <= 8 && G <= 32 && G * ((e->K + 1) / 2) <= max_wgs) cols = 2;
         if (const char *cenv = getenv("KH_COOP_COLS")) {  // testing
             const int want = atoi(cenv);
-            if ((want == 4 || want == 16) && G * ((e->K + want - 1) / want) <= max_wgs)
+            if ((want == 2 || want == 4 || want == 16) && G * ((e->K + want - 1) / want) <= max_wgs)
                 cols = want;
         }
         const int Y = (e->K + cols - 1) / cols;
@@ -419,11 +423,11 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             e->coop_G = G;
             e->coop_Y = Y;
             e->coop_cols = cols;
-            e->coop_ks = cols == 4 ? kh_coop4_slots(e->N) : (e->N + 31) / 32;  // operator-fragment slots per lane
+            e->coop_ks = cols <= 4 ? kh_coop4_slots(e->N) : (e->N + 31) / 32;  // operator-fragment slots per lane
             e->coop_vbuf_bytes = sizeof(kh_u64) * KH_COOP_RING * (size_t)Y * G * 16 * KH_COOP_COLS * 4;
             KH_HIP_E(hipMalloc(&e->d_coop_vbuf, e->coop_vbuf_bytes));
             KH_HIP_E(hipMalloc(&e->d_coop_xcc, sizeof(unsigned int) * (size_t)G * Y));
-            e->coop_xcd = cols == 4 && Y <= 8 && G <= 32 && !(getenv("KH_COOP_XCD") && atoi(getenv("KH_COOP_XCD")) == 0);
+            e->coop_xcd = cols <= 4 && Y <= 8 && G <= 32 && !(getenv("KH_COOP_XCD") && atoi(getenv("KH_COOP_XCD")) == 0);
             e->grid_update = e->K < max_wgs ? e->K : max_wgs;  // (stepwise launches use the generic kernel)
             // A round (one Taylor term) costs a cross-workgroup exchange here, so fewer, longer
             // sub-steps pay: theta <= 4 needs ~31 terms per sub-step against 4 x 18 at theta <= 1.
@@ -496,10 +500,12 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             auto it = perm_of.find(src);
             if (it == perm_of.end()) {
                 cplx *dst = nullptr;
-                const hipError_t err = hipMalloc(&dst, sizeof(cplx) * elems);
+                // (+ one zero-slot word per (row block, wave) behind the table: kh_coop_mask_kernel)
+                const hipError_t err = hipMalloc(&dst, sizeof(cplx) * elems + sizeof(unsigned int) * e->coop_G * KH_COOP_WAVES);
                 if (err != hipSuccess) return err;
                 e->owned.push_back(dst);
                 kh_coop_permute_kernel<<<(unsigned)((elems + 255) / 256), 256>>>(src, dst, e->N, e->coop_G, e->coop_ks, e->coop_cols);
+                kh_coop_mask_kernel<<<e->coop_G * KH_COOP_WAVES, 64>>>(dst, (unsigned int *)(dst + elems), e->coop_ks);
                 it = perm_of.emplace(src, dst).first;
             }
             *out = it->second;
@@ -681,7 +687,7 @@ static KhCoopArgs coop_args(const kh_engine *e, bool backward) {
 template <int MAXKS, int COLS>
 static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
                              cplx *out, int direction, hipStream_t st) {
-    const int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS>, kh_coop_lds_bytes(COLS == 4 ? 16 : 15, COLS));
+    const int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS>, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
@@ -695,7 +701,7 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
                               hipStream_t st) {
     const void *func = u.sigma != nullptr ? (const void *)kh_coop_forward_update<MAXKS, COLS, true>
                                           : (const void *)kh_coop_forward_update<MAXKS, COLS, false>;
-    const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(COLS == 4 ? 16 : 15, COLS));
+    const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
@@ -723,7 +729,10 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     } else if (e->kind_store == KIND_TILE_RPT1) {
         rc = dispatch_tile_store<1>(e, p, pulses, in, store, out, direction, st);
     } else if (e->kind_store == KIND_COOP) {
-        if (e->coop_cols == 4)
+        if (e->coop_cols == 2)
+            rc = e->coop_ks <= 8 ? launch_coop_store<8, 2>(e, p, pulses, in, store, out, direction, st)
+                                 : launch_coop_store<16, 2>(e, p, pulses, in, store, out, direction, st);
+        else if (e->coop_cols == 4)
             rc = e->coop_ks <= 8 ? launch_coop_store<8, 4>(e, p, pulses, in, store, out, direction, st)
                                  : launch_coop_store<16, 4>(e, p, pulses, in, store, out, direction, st);
         else
@@ -835,7 +844,9 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         } else
             rc = launch_persistent(kh_q2_forward_update<false, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_COOP && !stepwise) {
-        if (e->coop_cols == 4)
+        if (e->coop_cols == 2)
+            rc = e->coop_ks <= 8 ? launch_coop_update<8, 2>(e, p, u, ex, st) : launch_coop_update<16, 2>(e, p, u, ex, st);
+        else if (e->coop_cols == 4)
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 4>(e, p, u, ex, st) : launch_coop_update<16, 4>(e, p, u, ex, st);
         else
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 16>(e, p, u, ex, st) : launch_coop_update<16, 16>(e, p, u, ex, st);

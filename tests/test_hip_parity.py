@@ -224,7 +224,7 @@ def test_objective_propagate_on_device():
 SECOND_ORDER_CASES = [
     ('c3', None), ('c5_n16', None), ('c3', 'mini'), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
     ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c2l', None),
-    ('c4_d9', None), ('shared_n96_L2', None), ('c3', 'coop'), ('shared_n96_L2', 'coop16cols'),
+    ('c4_d9', None), ('shared_n96_L2', None), ('c3', 'coop'), ('shared_n96_L2', 'coop16cols'), ('shared_n96_L2', 'coop2cols'), ('c4_d9', 'coop2cols'),
 ]
 
 
@@ -238,8 +238,8 @@ def test_second_order_update_sweep(name, kernel, monkeypatch):
     spec = SMALL[name]()
     prob = spec_to_oracle(spec)
     gp, S, lam = oracle_controls(spec)
-    if kernel == 'coop16cols':  # the cooperative kernels with 16 (instead of 4) objectives per workgroup
-        monkeypatch.setenv('KH_COOP_COLS', '16')
+    if kernel in ('coop16cols', 'coop2cols'):  # the cooperative kernels with 16 / 2 (instead of 4) objectives per workgroup
+        monkeypatch.setenv('KH_COOP_COLS', kernel[4:-4])
     elif kernel is not None:
         monkeypatch.setenv('KH_KERNEL', kernel)
     eng = _engine(spec)
@@ -443,11 +443,11 @@ def _optimize_on_device(spec, iters, **kw):
         iter_stop=iters, store_all_pulses=True, **kw)
 
 
-@pytest.mark.parametrize('cols', ['4', '16'])
+@pytest.mark.parametrize('cols', ['2', '4', '16'])
 @pytest.mark.parametrize('name', ['ref_c2_liouville', 'ref_c3_iswap', 'ref_c4_small'])
 def test_cooperative_kernels_vs_reference_loop_goldens(name, cols, monkeypatch):
     """The shared-operator matrix-core kernels (forced onto the small gate problems whose
-    objectives share one operator list; 4 and 16 objectives per workgroup) vs the
+    objectives share one operator list; 2, 4 and 16 objectives per workgroup) vs the
     reference's own loop."""
     monkeypatch.setenv('KH_KERNEL', 'coop')
     monkeypatch.setenv('KH_COOP_COLS', cols)
