@@ -48,6 +48,7 @@ struct KhCoopArgs {
     int ks;                   // k-steps (of 4 columns) per wave: 32 * ks >= N
     int first_poll_delay;     // s_sleep units (64 cycles) before a round's first fetch
     int xcd_rows;             // > 0: one-dimensional grid of 8 * xcd_rows blocks, block b = 8 g + y (see kh_coop_place)
+    int local;                // (set in the kernel after kh_coop_check_placement: a wave-uniform copy of KhCoopLds::local)
     unsigned int *xcc;        // [Y * G] XCC id + 1 of every workgroup (placement check, zeroed with vbuf)
     const cplx *const *fops;  // [1 + L] this direction's (shared) operators in fragment order
     const cplx *const *sq;    // one control only: P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 of this direction's
@@ -61,9 +62,9 @@ struct KhCoopLds {
     int abort;
     int local;  // this column group's workgroups all sit on ONE XCD: term blocks are exchanged through its L2
 #ifdef KH_TIMING
-    double tim[7];
+    double tim[12];  // [7] owners' sums, [8] second barrier, [9] between rounds (caller), [10] fragment updates, [11] stamp
 #endif
-    double frag[1];  // [ks][2][KH_COOP_THREADS] operator fragment of the current interval (dynamic size), then
+    __attribute__((aligned(16))) double frag[1];  // [ks][KH_COOP_THREADS] complex operator fragment of the current interval (dynamic size), then
                      // the per-wave partial blocks: [WAVES][8][64] (16 objectives per workgroup: re regs 0-3, im 4-7)
                      // or [WAVES][2][64] (4 objectives: element (row r, column c) of the block at [4 r + c])
 };
@@ -84,11 +85,12 @@ __host__ __device__ inline void kh_coop4_share(int N, int wave, int *start, int 
     *start = wave * base + (wave < extra ? wave : extra);
 }
 
-// A thread's view of the fragment: element q is {re, im} at f[(2 q) T], f[(2 q + 1) T]
+// A thread's view of the fragment: element q is the complex number at f[q T] (one 16-byte LDS access)
 struct KhCoopFrag {
-    double *f;  // s.frag + tid
-    __device__ __forceinline__ double &re(int q) const { return f[(size_t)(2 * q) * KH_COOP_THREADS]; }
-    __device__ __forceinline__ double &im(int q) const { return f[(size_t)(2 * q + 1) * KH_COOP_THREADS]; }
+    cplx *f;  // (cplx *)s.frag + tid
+    __device__ __forceinline__ double &re(int q) const { return f[(size_t)q * KH_COOP_THREADS].x; }
+    __device__ __forceinline__ double &im(int q) const { return f[(size_t)q * KH_COOP_THREADS].y; }
+    __device__ __forceinline__ cplx get(int q) const { return f[(size_t)q * KH_COOP_THREADS]; }
     __device__ __forceinline__ bool nz(int) const { return true; }
 };
 
@@ -99,6 +101,7 @@ struct KhCoopRegFrag {
     unsigned int mask;  // MASKED: bit q clear = slot q is zero in every lane of the wave (its products are skipped)
     __device__ __forceinline__ double re(int q) const { return v[q].x; }
     __device__ __forceinline__ double im(int q) const { return v[q].y; }
+    __device__ __forceinline__ cplx get(int q) const { return v[q]; }
     __device__ __forceinline__ bool nz(int q) const { return !MASKED || ((mask >> q) & 1u) != 0u; }
 };
 
@@ -219,9 +222,8 @@ __device__ __forceinline__ void kh_coop_load_frag(const cplx *op, int g, int wav
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
         if (q < ks) {
-            const cplx v = (src != nullptr && ((mask >> q) & 1u)) ? src[(size_t)q * 64] : c_make(0.0, 0.0);
-            f.re(q) = v.x;
-            f.im(q) = v.y;
+            f.f[(size_t)q * KH_COOP_THREADS] =
+                (src != nullptr && ((mask >> q) & 1u)) ? src[(size_t)q * 64] : c_make(0.0, 0.0);
         }
     }
 }
@@ -236,8 +238,10 @@ __device__ __forceinline__ void kh_coop_axpy_frag(const cplx *op, double eps, in
     for (int q = 0; q < MAXKS; ++q) {
         if (q < ks && ((mask >> q) & 1u)) {
             const cplx v = src[(size_t)q * 64];
-            a.re(q) = fma(eps, v.x, a.re(q));
-            a.im(q) = fma(eps, v.y, a.im(q));
+            cplx t = a.get(q);
+            t.x = fma(eps, v.x, t.x);
+            t.y = fma(eps, v.y, t.y);
+            a.f[(size_t)q * KH_COOP_THREADS] = t;
         }
     }
 }
@@ -266,11 +270,13 @@ __device__ __forceinline__ kh_u64 *kh_coop_slot4(const KhCoopArgs &c, unsigned i
 typedef unsigned int kh_u32x4 __attribute__((ext_vector_type(4)));
 #define KH_CPOL_SC0 1           // workgroup scope (may be served by the L1 / a stale L2 line)
 #define KH_CPOL_SC1 16          // agent scope
-#define KH_CPOL_VOLATILE (1u << 31)
-// two granules (16 bytes) of the lane's element; each granule carries its own tag, so only 8-byte atomicity is used
+// two granules (16 bytes) of the lane's element; each granule carries its own tag, so only 8-byte atomicity is used.
+// (Not marked volatile: the compiler turns that into system scope, sc0 sc1 -- a slower path.  A polling loop puts a
+// compiler barrier, kh_compiler_fence, before every pass instead.)
+__device__ __forceinline__ void kh_compiler_fence() { asm volatile("" ::: "memory"); }
 template <int CPOL>
 __device__ __forceinline__ void kh_coop_load2(__amdgpu_buffer_rsrc_t rsrc, unsigned int byte_off, kh_u64 &a, kh_u64 &b) {
-    const kh_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, (int)(CPOL | KH_CPOL_VOLATILE));
+    const kh_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, CPOL);
     a = (kh_u64)v.x | ((kh_u64)v.y << 32);
     b = (kh_u64)v.z | ((kh_u64)v.w << 32);
 }
@@ -517,11 +523,17 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
     const unsigned int epoch = c.epoch_base + rid;
     int start, count;
     kh_coop4_share(N, wave, &start, &count);
+    count = __builtin_amdgcn_readfirstlane(count);
+    // operator elements of the first group: read from LDS while the block is on its way (the rest, one group ahead
+    // of the matrix-core instructions that use them: left to itself the compiler waits for every read in turn)
+    cplx fq[2][4];  // (two buffers, by group parity)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) fq[0][rb] = f.get(rb);
     const int roff = 4 * ((lane >> 2) & 3) + (lane >> 4);  // this lane's row of a group (column lane & 3)
     constexpr int NGR = COLS == 4 ? 4 : 2;         // granules of a lane's operand element
     constexpr unsigned int GB = COLS == 4 ? 2048u : 1024u;  // bytes of a group in the ring
     kh_u64 g[MAXG][NGR];
-    const long long t0 = wall_clock64();
+    long long t0 = 0;  // (taken when the slow path is entered: s_memrealtime is not free)
 #ifdef KH_TIMING
     const long long tq0 = clock64();
 #endif
@@ -540,7 +552,7 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
         for (int i = 0; i < NGR; ++i) g[j][i] = (kh_u64)epoch << 32;
         if (j < count && row < N) {
             const unsigned int off = ring_off + GB * (start + j);
-            if (s.local) {  // one XCD: its L2 has the producers' stores (agent-scope loads bypass only the L1)
+            if (c.local) {  // one XCD: its L2 has the producers' stores (agent-scope loads bypass only the L1)
                 kh_coop_load2<KH_CPOL_SC1>(rsrc, off, g[j][0], g[j][1]);
                 if constexpr (COLS == 4) kh_coop_load2<KH_CPOL_SC1>(rsrc, off + 1024u, g[j][2], g[j][3]);
             } else {
@@ -562,11 +574,15 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
     const long long tqf = clock64();
     if (tid == 0 && blockIdx.x == 0) s.tim[4] += (double)(tqf - tq0);
 #endif
+#ifdef KH_COOP_X_NOPOLL  // (timing experiment: wrong results)
+    all_fresh = true;
+#endif
     // otherwise: only what was stale, bypassing L2, until everything carries the round's tag
     while (!__all(all_fresh)) {
 #ifdef KH_TIMING
         if (tid == 0 && blockIdx.x == 0) s.tim[6] += 1.0;
 #endif
+        kh_compiler_fence();
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < MAXG; ++j) {
@@ -588,6 +604,7 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
         all_fresh = ok;
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(2);
+        if (spins == 0) t0 = wall_clock64();
         if ((++spins & 63u) == 0) {
             const bool gave_up =
                 (wall_clock64() - t0 > ex.timeout_ticks) ||
@@ -609,12 +626,16 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
 #pragma unroll
         for (int j = 0; j < MAXG; ++j) {
             if (j < count) {
+                if (j + 1 < MAXG) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) fq[(j + 1) & 1][rb] = f.get(4 * (j + 1) + rb);
+                }
                 const double vr = __hiloint2double((int)(unsigned int)(g[j][0] & 0xffffffffull), (int)(unsigned int)(g[j][1] & 0xffffffffull));
                 const double vi = __hiloint2double((int)(unsigned int)(g[j][2] & 0xffffffffull), (int)(unsigned int)(g[j][3] & 0xffffffffull));
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
                     if (!f.nz(4 * j + rb)) continue;
-                    const double fr = f.re(4 * j + rb), fi = f.im(4 * j + rb);
+                    const double fr = fq[j & 1][rb].x, fi = fq[j & 1][rb].y;
                     ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vr, ar[rb], 0, 0, 0);
                     ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fi, -vi, ar[rb], 0, 0, 0);
                     ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, vi, ai[rb], 0, 0, 0);
@@ -643,12 +664,20 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
 #pragma unroll
         for (int j = 0; j < MAXG; ++j) {
             if (j < count) {
+                if (j + 1 < MAXG) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) fq[(j + 1) & 1][rb] = f.get(4 * (j + 1) + rb);
+                }
                 const double v = __hiloint2double((int)(unsigned int)(g[j][0] & 0xffffffffull), (int)(unsigned int)(g[j][1] & 0xffffffffull));
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
                     if (!f.nz(4 * j + rb)) continue;
-                    ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.re(4 * j + rb), v, ar[rb], 0, 0, 0);
-                    ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.im(4 * j + rb), v, ai[rb], 0, 0, 0);
+#ifdef KH_COOP_X_NOMFMA  // (timing experiment: wrong results)
+                    ar[rb] += v * fq[j & 1][rb].x;
+                    continue;
+#endif
+                    ar[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fq[j & 1][rb].x, v, ar[rb], 0, 0, 0);
+                    ai[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(fq[j & 1][rb].y, v, ai[rb], 0, 0, 0);
                 }
             }
         }
@@ -693,7 +722,19 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
             }
         }
     }
+#ifdef KH_TIMING
+    const long long tq4 = clock64();
+#endif
     __syncthreads();  // part[] is free for the next round
+#ifdef KH_TIMING
+    if (tid == 0 && blockIdx.x == 0) {
+        const long long tq5 = clock64();
+        s.tim[7] += (double)(tq4 - tq3);
+        s.tim[8] += (double)(tq5 - tq4);
+        if (s.tim[11] != 0.0) s.tim[9] += (double)tq0 - s.tim[11];
+        s.tim[11] = (double)tq5;
+    }
+#endif
 }
 
 template <int MAXKS, int COLS, class Frag>
@@ -760,7 +801,7 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
                 const cplx t = c_mul(c_make(fre * hj, fim * hj), w);
                 state.x += t.x;
                 state.y += t.y;
-                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, j == m ? state : t, s.local != 0);
+                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, j == m ? state : t, c.local != 0);
             }
             ++rid;
         }
@@ -814,13 +855,25 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
     const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
     const int phases = (m + 1) >> 1;
 #ifndef KH_COOP_X_NOREBUILD  // (timing experiment: wrong results)
+#ifndef KH_COOP_X_NOREBUILD  // (timing experiment: wrong results)
     {
+#ifdef KH_TIMING
+        const long long tr0 = clock64();
+#endif
         const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
         kh_coop_axpy_frag<MAXKS>(c.sq[1], e1, g, wave, lane, c.ks, a, mk.p1);
         kh_coop_axpy_frag<MAXKS>(c.sq[2], e2, g, wave, lane, c.ks, a, mk.p2);
         kh_coop_reg_axpy<MAXKS>(c.fops[1], e1, g, wave, lane, c.ks, areg, mk.h1);
         eps_prev = eps;
+#ifdef KH_TIMING
+        if (tid == 0 && blockIdx.x == 0) {
+            const long long tr1 = clock64();
+            s.tim[10] += (double)(tr1 - tr0);
+            if (s.tim[11] != 0.0) s.tim[11] += (double)(tr1 - tr0);  // (not counted as "between rounds")
+        }
+#endif
     }
+#endif
 #endif
     const KhCoopRegFrag<MAXKS> af = {areg, ~0u};
     for (int sub = 0; sub < nsub; ++sub) {
@@ -840,7 +893,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
                     sacc.x = fma(hn, t2.x, sacc.x);
                     sacc.y = fma(hn, t2.y, sacc.y);
                 }
-                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, last ? sacc : t2, s.local != 0);
+                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, last ? sacc : t2, c.local != 0);
             }
             ++rid;
         }
@@ -851,7 +904,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             const cplx odd = c_mul(c_make(fre, fim), w);
             state.x += odd.x;
             state.y += odd.y;
-            if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, state, s.local != 0);
+            if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, state, c.local != 0);
         }
         ++rid;
     }
@@ -863,33 +916,35 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
 // ---------------------------------------------------------------------------
 template <int MAXKS, int COLS>
 __global__ void __launch_bounds__(KH_COOP_THREADS)
-kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__restrict__ pulses,
+kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double *__restrict__ pulses,
                     const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out,
                     int direction) {
     extern __shared__ __attribute__((aligned(16))) char kh_coop_smem[];
     KhCoopLds &s = *(KhCoopLds *)kh_coop_smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int g, y;
-    if (!kh_coop_place(c, g, y)) return;
+    if (!kh_coop_place(c_in, g, y)) return;
     const int rowbase = g * 16;
     const int N = p.N, nt = p.nt, L = p.L;
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
 #ifdef KH_TIMING
-    if (tid < 7) s.tim[tid] = 0.0;
+    if (tid < 12) s.tim[tid] = 0.0;
 #endif
-    kh_coop_check_placement(c, ex, s, g, y, tid);
+    kh_coop_check_placement(c_in, ex, s, g, y, tid);
+    KhCoopArgs c = c_in;
+    c.local = __builtin_amdgcn_readfirstlane(s.local);
     const int r = tid / COLS, col = tid % COLS, row = rowbase + r, k = y * COLS + col;
     const bool owner_valid = tid < 16 * COLS && row < N;  // (columns beyond K carry zeros)
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
     unsigned int rid = 1;
-    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state, s.local != 0);
+    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state, c.local != 0);
     if (has_state && store != nullptr) store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + row] = state;
     __syncthreads();
     double rounds = 0.0;
     int m_hint = 12;
-    const KhCoopFrag a = {s.frag + tid};
+    const KhCoopFrag a = {(cplx *)s.frag + tid};
     cplx areg[MAXKS];
     double eps_prev = 0.0;
     const KhCoopSqMasks mk = kh_coop_sq_masks(c, g, wave);
@@ -935,7 +990,16 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
             p.stats[1] = s.tim[0] / rounds + 1e6 * (double)(long long)(s.tim[4] / rounds);
             p.stats[2] = s.tim[1] / rounds + 1e6 * (double)(long long)(100.0 * s.tim[5] / rounds);
             p.stats[3] = s.tim[2] / rounds + 1e6 * (double)(long long)(100.0 * s.tim[6] / rounds);
-            p.stats[4] = (double)s.local;
+            p.stats[4] = 0.0;  // KH_TRACE: cumulative cycles per round ...
+            p.stats[5] = s.tim[0] / rounds;
+            p.stats[6] = p.stats[5] + s.tim[1] / rounds;
+            p.stats[7] = p.stats[6] + s.tim[2] / rounds;
+            p.stats[8] = p.stats[7] + s.tim[7] / rounds;
+            p.stats[9] = p.stats[8] + s.tim[8] / rounds;
+            p.stats[10] = p.stats[9] + s.tim[9] / rounds;
+            p.stats[11] = s.tim[10] / (nt - 1);  // ... and the fragment updates per interval
+            p.stats[12] = 1.0 + s.local;
+            p.stats[13] = 0.0;
         }
 #endif
     }
@@ -946,32 +1010,34 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c, KhExchange ex, const double *__
 // ---------------------------------------------------------------------------
 template <int MAXKS, int COLS, bool SO>
 __global__ void __launch_bounds__(KH_COOP_THREADS)
-kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c, KhUpdateArgs u, KhExchange ex) {
+kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchange ex) {
     extern __shared__ __attribute__((aligned(16))) char kh_coop_smem[];
     KhCoopLds &s = *(KhCoopLds *)kh_coop_smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int g, y;
-    if (!kh_coop_place(c, g, y)) return;
+    if (!kh_coop_place(c_in, g, y)) return;
     const int rowbase = g * 16;
-    const int wg = y * c.G + g;  // linear workgroup index of the exchange
+    const int wg = y * c_in.G + g;  // linear workgroup index of the exchange
     const int N = p.N, nt = p.nt, L = p.L;
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
-    kh_coop_check_placement(c, ex, s, g, y, tid);
+    kh_coop_check_placement(c_in, ex, s, g, y, tid);
+    KhCoopArgs c = c_in;
+    c.local = __builtin_amdgcn_readfirstlane(s.local);
     const int r = tid / COLS, col = tid % COLS, row = rowbase + r, k = y * COLS + col;
     const bool owner_valid = tid < 16 * COLS && row < N;
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     const double chi_norm = has_state ? u.chi_norms[k] : 0.0;
     unsigned int rid = 1;
-    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state, s.local != 0);
+    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state, c.local != 0);
     __syncthreads();
     double rounds = 0.0;
     double g_a_loc[KH_COOP_MAX_L];
 #pragma unroll
     for (int l = 0; l < KH_COOP_MAX_L; ++l) g_a_loc[l] = 0.0;
     int m_hint = 12;
-    const KhCoopFrag a = {s.frag + tid};
+    const KhCoopFrag a = {(cplx *)s.frag + tid};
     cplx areg[MAXKS];
     double eps_prev = 0.0;
     const KhCoopSqMasks mk = kh_coop_sq_masks(c, g, wave);

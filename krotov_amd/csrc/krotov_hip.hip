@@ -681,6 +681,7 @@ static KhCoopArgs coop_args(const kh_engine *e, bool backward) {
     c.first_poll_delay = e->coop_poll_delay;
     c.xcd_rows = e->coop_xcd ? e->coop_G : 0;
     c.xcc = e->d_coop_xcc;
+    c.local = 0;
     return c;
 }
 
