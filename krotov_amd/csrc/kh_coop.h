@@ -38,6 +38,26 @@
 
 typedef double kh_d4 __attribute__((ext_vector_type(4)));
 
+// Owner threads.  COLS = 16 / 4: thread tid < 16 COLS owns element (row tid / COLS, column tid % COLS) of the block.
+// COLS = 2: the owners are spread over all waves -- wave w, lane 16 j owns row 2 w + j / 2, column j % 2 -- so that the
+// cross-wave sum of a round is ONE LDS read per lane and a sum over 8 neighbouring lanes (kh_coop_round4) instead of
+// sixteen dependent reads in one wave.
+template <int COLS>
+__device__ __forceinline__ bool kh_coop_is_owner(int tid) {
+    if constexpr (COLS == 2) return (tid & 15) == 0;
+    return tid < 16 * COLS;
+}
+template <int COLS>
+__device__ __forceinline__ void kh_coop_owner_element(int tid, int &r, int &col) {
+    if constexpr (COLS == 2) {
+        r = 2 * (tid >> 6) + ((tid >> 5) & 1);
+        col = (tid >> 4) & 1;
+    } else {
+        r = tid / COLS;
+        col = tid % COLS;
+    }
+}
+
 struct KhCoopArgs {
     kh_u64 *vbuf;             // cols = 16: [KH_COOP_RING][Y][G*16][4][16] granules; cols = 4: [KH_COOP_RING][Y][G]
                               // [2][64][2], a 16-row group in the CONSUMER's lane order (kh_coop_slot4)
@@ -56,7 +76,7 @@ struct KhCoopArgs {
 };
 
 struct KhCoopLds {
-    double red[2][4][KH_COOP_MAX_L];       // owner waves' pieces of the update sums, by interval parity
+    double red[2][KH_COOP_WAVES][KH_COOP_MAX_L];  // owner waves' pieces of the update sums, by interval parity
     double D[2][KH_COOP_MAX_L + 1];        // reduced sums + ok flag, by interval parity
     double deg[KH_MAX_DEGREE + 2];
     int abort;
@@ -69,9 +89,10 @@ struct KhCoopLds {
                      // or [WAVES][2][64] (4 objectives: element (row r, column c) of the block at [4 r + c])
 };
 
+#define KH_COOP_PART2 66  // cols = 2: a wave's 64 partial values, padded (the cross-wave read strides over waves)
 __host__ __device__ inline size_t kh_coop_lds_bytes(int ks, int cols = KH_COOP_COLS) {
     return sizeof(KhCoopLds) + sizeof(double) * 2 * (size_t)ks * KH_COOP_THREADS +
-           sizeof(double) * KH_COOP_WAVES * (cols <= 4 ? 2 : 8) * 64;
+           sizeof(double) * KH_COOP_WAVES * (cols == 2 ? 2 * KH_COOP_PART2 : cols == 4 ? 2 * 64 : 8 * 64);
 }
 __device__ __forceinline__ double *kh_coop_part(KhCoopLds &s, int ks) { return s.frag + 2 * (size_t)ks * KH_COOP_THREADS; }
 
@@ -286,6 +307,9 @@ __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned in
                                                 cplx v, bool local = false) {
     const kh_u64 tag = (kh_u64)(c.epoch_base + rid) << 32;
     const kh_u64 re = (kh_u64)__double_as_longlong(v.x), im = (kh_u64)__double_as_longlong(v.y);
+#ifdef KH_COOP_X_NOSTORE
+    if (rid > 1) return;
+#endif
     if (c.cols == 2) {  // (a group is 1 KiB: [lane][2 granules], lane column n = re of objective n / im of objective n - 2)
         kh_u64 *g = c.vbuf + kh_coop_group4(c, rid, y, row >> 4) / 2 + 2 * kh_coop4_lane(row & 15, col);
         if (local) {
@@ -519,7 +543,8 @@ template <int MAXKS, int COLS, class Frag>
 __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y, int N,
                                                const Frag &f, KhCoopLds &s, int tid, int wave, int lane, cplx &w) {
     constexpr int MAXG = MAXKS / 4;  // groups per wave
-    double *part = kh_coop_part(s, c.ks);
+    // (2 objectives: double-buffered by round parity -- the next round's barrier orders the reuse)
+    double *part = kh_coop_part(s, c.ks) + (COLS == 2 ? (rid & 1u) * (KH_COOP_WAVES * KH_COOP_PART2) : 0);
     const unsigned int epoch = c.epoch_base + rid;
     int start, count;
     kh_coop4_share(N, wave, &start, &count);
@@ -550,6 +575,7 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
         const int row = 16 * (start + j) + roff;
 #pragma unroll
         for (int i = 0; i < NGR; ++i) g[j][i] = (kh_u64)epoch << 32;
+#ifndef KH_COOP_X_NOLOAD
         if (j < count && row < N) {
             const unsigned int off = ring_off + GB * (start + j);
             if (c.local) {  // one XCD: its L2 has the producers' stores (agent-scope loads bypass only the L1)
@@ -560,6 +586,7 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
                 if constexpr (COLS == 4) kh_coop_load2<KH_CPOL_SC0>(rsrc, off + 1024u, g[j][2], g[j][3]);
             }
         }
+#endif
     }
     bool all_fresh = true;
 #pragma unroll
@@ -687,7 +714,7 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
             double e = fma(sgn, dpp_move<KH_DPP_XOR2>(ai[rb]), ar[rb]);
             e += dpp_move<KH_DPP_ROR8>(e);
             e += dpp_move<KH_DPP_ROR4>(e);
-            if (((lane >> 2) & 3) == 0) part[wave * 64 + 16 * rb + 4 * (lane >> 4) + (lane & 3)] = e;
+            if (((lane >> 2) & 3) == 0) part[wave * KH_COOP_PART2 + 16 * rb + 4 * (lane >> 4) + (lane & 3)] = e;
         }
     }
 #ifdef KH_TIMING
@@ -713,19 +740,20 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
             }
         }
     } else {
-        if (tid < 32) {  // owner of element (row tid / 2, column tid % 2): re at [4 row + column], im two further
-            const int e = 4 * (tid >> 1) + (tid & 1);
-#pragma unroll
-            for (int wv = 0; wv < KH_COOP_WAVES; ++wv) {
-                w.x += part[wv * 64 + e];
-                w.y += part[wv * 64 + e + 2];
-            }
-        }
+        // element [4 row + n] of the wave vectors (n: re c0, re c1, im c0, im c1).  Lane (group lane >> 3, wave
+        // lane & 7) reads ONE partial value of element 4 (2 wave + group / 4) + (group / 2) % 2 + 2 (group % 2); the
+        // eight waves' values sit in eight neighbouring lanes (sum8), and the im partner of a re group is the next
+        // group, 8 lanes on in the same 16-lane row.  Owners: lanes 0, 16, 32, 48 (kh_coop_owner_element).
+        const int grp = lane >> 3;
+        const int e = 4 * (2 * wave + (grp >> 2)) + ((grp >> 1) & 1) + 2 * (grp & 1);
+        const double v = sum8(part[(lane & 7) * KH_COOP_PART2 + e]);
+        const double partner = dpp_move<KH_DPP_ROR8>(v);
+        if ((lane & 15) == 0) w = c_make(v, partner);
     }
 #ifdef KH_TIMING
     const long long tq4 = clock64();
 #endif
-    __syncthreads();  // part[] is free for the next round
+    if constexpr (COLS != 2) __syncthreads();  // part[] is free for the next round
 #ifdef KH_TIMING
     if (tid == 0 && blockIdx.x == 0) {
         const long long tq5 = clock64();
@@ -796,7 +824,7 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
             cplx w;
             kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
             if (s.abort) return false;  // (raised before the barriers inside kh_coop_round)
-            if (tid < 16 * COLS) {
+            if (kh_coop_is_owner<COLS>(tid)) {
                 const double hj = h / j;
                 const cplx t = c_mul(c_make(fre * hj, fim * hj), w);
                 state.x += t.x;
@@ -879,17 +907,18 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
     for (int sub = 0; sub < nsub; ++sub) {
         cplx sacc = c_make(h * state.x, h * state.y);
         for (int ph = 0; ph < phases; ++ph) {
+            // (the coefficients are fetched before the round, not between its end and the owners' stores; a timed-out
+            // round is noticed after the phases: the later rounds give up at once on the abort flag)
+            const double c2 = f2h2 * kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2];
+            const double hn = ph + 1 < phases ? h * kh_inv_table[2 * ph + 3] : 0.0;
             cplx w;
             kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
-            if (s.abort) return false;
-            if (tid < 16 * COLS) {
-                const double c2 = f2h2 * kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2];
+            if (kh_coop_is_owner<COLS>(tid)) {
                 const cplx t2 = c_make(c2 * w.x, c2 * w.y);
                 state.x += t2.x;
                 state.y += t2.y;
                 const bool last = (ph + 1 == phases);
                 if (!last) {
-                    const double hn = h * kh_inv_table[2 * ph + 3];
                     sacc.x = fma(hn, t2.x, sacc.x);
                     sacc.y = fma(hn, t2.y, sacc.y);
                 }
@@ -900,7 +929,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         cplx w;
         kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, af, s, tid, wave, lane, w);
         if (s.abort) return false;
-        if (tid < 16 * COLS) {
+        if (kh_coop_is_owner<COLS>(tid)) {
             const cplx odd = c_mul(c_make(fre, fim), w);
             state.x += odd.x;
             state.y += odd.y;
@@ -934,8 +963,10 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
     kh_coop_check_placement(c_in, ex, s, g, y, tid);
     KhCoopArgs c = c_in;
     c.local = __builtin_amdgcn_readfirstlane(s.local);
-    const int r = tid / COLS, col = tid % COLS, row = rowbase + r, k = y * COLS + col;
-    const bool owner_valid = tid < 16 * COLS && row < N;  // (columns beyond K carry zeros)
+    int r, col;
+    kh_coop_owner_element<COLS>(tid, r, col);
+    const int row = rowbase + r, k = y * COLS + col;
+    const bool owner_valid = kh_coop_is_owner<COLS>(tid) && row < N;  // (columns beyond K carry zeros)
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
     unsigned int rid = 1;
@@ -1024,8 +1055,10 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     kh_coop_check_placement(c_in, ex, s, g, y, tid);
     KhCoopArgs c = c_in;
     c.local = __builtin_amdgcn_readfirstlane(s.local);
-    const int r = tid / COLS, col = tid % COLS, row = rowbase + r, k = y * COLS + col;
-    const bool owner_valid = tid < 16 * COLS && row < N;
+    int r, col;
+    kh_coop_owner_element<COLS>(tid, r, col);
+    const int row = rowbase + r, k = y * COLS + col;
+    const bool owner_valid = kh_coop_is_owner<COLS>(tid) && row < N;
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     const double chi_norm = has_state ? u.chi_norms[k] : 0.0;
@@ -1070,7 +1103,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
                 kh_coop_load_frag<MAXKS>(c.fops[1 + l], g, wave, lane, c.ks, a);
                 kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
             }
-            if (wave < 4) {  // (lanes that own no element contribute zeros: chi_norm, bra, w are 0 there)
+            if (COLS == 2 || wave < 4) {  // (lanes that own no element contribute zeros: chi_norm, bra, w are 0 there)
                 cplx ov = c_make(0.0, 0.0);
                 c_fma_conj(ov, bra, w);
                 const double piece = sum64(chi_norm * (u.mu_re * ov.y + u.mu_im * ov.x));
@@ -1085,6 +1118,11 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
 #pragma unroll
             for (int l = 0; l < KH_COOP_MAX_L; ++l)
                 part[l] = l < L ? (s.red[par][0][l] + s.red[par][1][l]) + (s.red[par][2][l] + s.red[par][3][l]) : 0.0;
+            if constexpr (COLS == 2) {
+#pragma unroll
+                for (int l = 0; l < KH_COOP_MAX_L; ++l)
+                    if (l < L) part[l] += (s.red[par][4][l] + s.red[par][5][l]) + (s.red[par][6][l] + s.red[par][7][l]);
+            }
             const bool ok = kh_exchange<KH_COOP_MAX_L>(ex, n, wg, L, lane, part, D);
             if (lane == 0) {
 #pragma unroll
