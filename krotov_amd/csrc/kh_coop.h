@@ -867,7 +867,9 @@ __device__ __forceinline__ void kh_coop_sq_restart(const KhCoopArgs &c, const Kh
                                                    int lane, const KhCoopFrag &b, cplx (&areg)[MAXKS],
                                                    double &eps_prev) {
     kh_coop_load_frag<MAXKS>(c.sq[0], g, wave, lane, c.ks, b, mk.p0);
+#ifndef KH_COOP_X_NOAREG
     kh_coop_reg_load<MAXKS>(c.fops[0], g, wave, lane, c.ks, areg, mk.h0);
+#endif
     eps_prev = 0.0;
 }
 
@@ -891,7 +893,9 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
         kh_coop_axpy_frag<MAXKS>(c.sq[1], e1, g, wave, lane, c.ks, a, mk.p1);
         kh_coop_axpy_frag<MAXKS>(c.sq[2], e2, g, wave, lane, c.ks, a, mk.p2);
+#ifndef KH_COOP_X_NOAREG  // (timing experiment: wrong results) no A fragment in registers: the last round uses B
         kh_coop_reg_axpy<MAXKS>(c.fops[1], e1, g, wave, lane, c.ks, areg, mk.h1);
+#endif
         eps_prev = eps;
 #ifdef KH_TIMING
         if (tid == 0 && blockIdx.x == 0) {
@@ -927,7 +931,11 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             ++rid;
         }
         cplx w;
+#ifdef KH_COOP_X_NOAREG
+        kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+#else
         kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, af, s, tid, wave, lane, w);
+#endif
         if (s.abort) return false;
         if (kh_coop_is_owner<COLS>(tid)) {
             const cplx odd = c_mul(c_make(fre, fim), w);
