@@ -107,6 +107,8 @@ struct kh_engine {
     int mm_nio = 2;              // 4-row blocks per wave of that kernel: 2 -> 8 waves (KH_MM_WAVES=4: 4 -> 4 waves)
     bool use_mm = false;         // KH_MM=1: the matrix-core update kernel (kh_tile64mm.h) instead of the vector-FMA one
     double *d_mm_tab = nullptr;  // [KH_MAX_DEGREE+1][KH_MM_TAB_STRIDE] coefficient rows of the two-chain form
+    bool stepwise_only = false;  // more objectives than can be co-resident: kh_forward_update runs one launch per interval
+    double *d_step_partial = nullptr;  // [L] the interval's sums on that path
     bool mini = false;           // kind q2, N <= 16, K <= 8: the one-wave-per-objective kernels (kh_mini.h)
     bool quad = false;           // mini with N <= 4, K <= 4: the whole problem in one wave
     double *d_q2_theta = nullptr, *d_q2_c0 = nullptr, *d_q2_rows = nullptr, *d_ratios = nullptr;  // series tables of the register-tile kernels
@@ -175,7 +177,7 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
     switch (e->kind) {
         case KIND_TILE_RPT2: return "tile64/256";
-        case KIND_TILE_RPT1: return "tile64/512";
+        case KIND_TILE_RPT1: return e->stepwise_only ? "tile64/512 per interval" : "tile64/512";
         case KIND_TILE_Q2: return e->mini ? (e->quad ? "mini4/wave" : "mini16/wave") : "tile64q2/512";
         case KIND_COOP: return "coop16/mfma";
         default: return e->d_csr_fw != nullptr ? "generic/csr" : "generic";
@@ -238,6 +240,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_abort);
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_wg_partial);
+    (void)hipFree(e->d_step_partial);
     (void)hipFree(e->d_coop_vbuf);
     (void)hipFree(e->d_coop_xcc);
     for (void *ptr : e->p2p_opened) (void)hipIpcCloseMemHandle(ptr);
@@ -380,6 +383,17 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     if (tile2_ok && !(force && strcmp(force, "generic") == 0)) {
         e->kind = KIND_TILE_RPT2;
         e->grid_update = e->K;
+    }
+    // More objectives than can be co-resident (so no in-kernel exchange), tile-sized: the register-tile kernel with
+    // ONE LAUNCH PER INTERVAL (the form the sharded sweep uses, kh_update_step) -- every launch re-stages the two
+    // operator tiles of its objectives (128 KiB each, from L2 / the Infinity Cache), which still beats the generic
+    // kernels' re-streaming of the operators for every term by 5x (K = 1024: 207 -> see DESIGN.md us per interval).
+    const bool tile_step_ok = csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && !tile_ok && !tile2_ok &&
+                              e->K > max_wgs && !(getenv("KH_NO_STEPWISE") && atoi(getenv("KH_NO_STEPWISE")));
+    if (tile_step_ok && force == nullptr) {
+        e->kind = KIND_TILE_RPT1;
+        e->grid_update = e->K;
+        e->stepwise_only = true;
     }
     if (tile_ok && !(force && strcmp(force, "generic") == 0)) {
         // two waves per SIMD are needed to keep the fp64 FMA pipe issuing back to back
@@ -598,6 +612,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     KH_HIP_E(hipMalloc(&e->d_stats, sizeof(double) * 68));
     KH_HIP_E(hipMemset(e->d_stats, 0, sizeof(double) * 68));
     KH_HIP_E(hipMalloc(&e->d_wg_partial, sizeof(double) * (size_t)e->grid_update * Lx));
+    KH_HIP_E(hipMalloc(&e->d_step_partial, sizeof(double) * Lx));
     KH_HIP_E(hipDeviceSynchronize());
 #undef KH_HIP_E
     *out = e;
@@ -911,6 +926,20 @@ extern "C" int kh_forward_update(kh_engine *e, const kh_cdouble *chi_store_dev, 
     if (e->L < 1) return kh_fail(KH_ERR_INVALID, "no controls to update");
     if (opt_dev == guess_dev) return kh_fail(KH_ERR_INVALID, "opt_dev must not alias guess_dev");
     hipStream_t st = (hipStream_t)stream;
+    if (e->stepwise_only) {
+        // one launch per interval; on one GPU the "all-reduced" sums are the local ones (kh_reduce_partials has
+        // summed the workgroups' pieces in a fixed order)
+        KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
+        int rc = kh_update_begin(e, chi_store_dev, chi_norms_dev, init_dev, guess_dev, opt_dev, g_a_dev,
+                                 e->d_step_partial, stream);
+        for (int n = 0; rc == KH_OK && n < e->nt - 1; ++n)
+            rc = kh_update_step(e, n, e->d_step_partial, chi_store_dev, chi_norms_dev, shape_dev, lambda_dev, opt_dev,
+                                g_a_dev, e->d_step_partial, stream);
+        if (rc == KH_OK) rc = kh_update_end(e, psi_T_dev, stream);
+        e->last_intervals = e->nt - 1;
+        e->last_wgs = e->grid_update;
+        return rc;
+    }
     KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
     KH_HIP(hipMemcpyAsync(e->d_phi, init_dev, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice, st));
     KhUpdateArgs u =
@@ -1051,6 +1080,8 @@ extern "C" int kh_p2p_create_window(kh_engine *e, int32_t world, int32_t rank, u
     if (world < 1 || rank < 0 || rank >= world) return kh_fail(KH_ERR_INVALID, "bad world/rank %d/%d", rank, world);
     const int Lx = e->L > 0 ? e->L : 1;
     if (world * Lx * 2 > 64) return kh_fail(KH_ERR_UNSUPPORTED, "world * L = %d exceeds the 32 exchange lanes", world * Lx);
+    if (e->stepwise_only)  // (the caller falls back to kh_update_step + an all-reduce per interval)
+        return kh_fail(KH_ERR_UNSUPPORTED, "%d objectives per GPU are not co-resident: no in-kernel exchange", e->K);
     if (e->p2p_window != nullptr) return kh_fail(KH_ERR_INVALID, "window already created");
     e->p2p_world = world;
     e->p2p_rank = rank;

@@ -38,6 +38,10 @@ SMALL = {
     'c5_n33': lambda: configs.config_c5(K=5, N=33, nt=41),
     # more objectives than CUs: two 256-thread workgroups per CU
     'c5_k300': lambda: configs.config_c5(K=300, N=16, nt=21),
+    # more objectives than can be co-resident (one control: > 2 per CU; several controls: > 1 per CU): the update
+    # sweep runs the register-tile kernel with one launch per interval
+    'c5_k600': lambda: configs.config_c5(K=600, N=8, nt=16),
+    'c5_k300_L2': lambda: configs.config_c5(K=300, N=12, nt=16, L=2, distinct=True),
     # objectives sharing one operator list, N > 64: the cooperative matrix-core kernels
     'c4_d9': lambda: configs.config_c4(d=9, nt=41, n_logical=2),
     'c4_d10_k9': lambda: configs.config_c4(d=10, nt=21, n_logical=3),
@@ -92,6 +96,7 @@ def test_sweeps_match_oracle(name):
     quad = small and spec.N <= 4 and spec.K <= 4
     assert (eng.kernel == 'mini4/wave') == quad and (eng.kernel == 'mini16/wave') == (small and not quad)
     assert (eng.kernel == 'tile64/256') == (name == 'c5_k300')
+    assert (eng.kernel == 'tile64/512 per interval') == (name in ('c5_k600', 'c5_k300_L2'))
     assert (eng.kernel == 'coop16/mfma') == (name.startswith('c4_d') and spec.N > 64 or name.startswith('shared'))
     eng.close()
 
