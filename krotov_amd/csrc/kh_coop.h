@@ -709,6 +709,10 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
             }
         }
         const double sgn = (lane & 2) ? 1.0 : -1.0;
+#ifdef KH_COOP_X_NOSUM  // (timing experiment: wrong results) no block sums, no LDS partial sums, no barrier
+        w = c_make(ar[0] + ar[1] + ar[2] + ar[3], ai[0] + ai[1] + ai[2] + ai[3]);
+        return;
+#endif
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             double e = fma(sgn, dpp_move<KH_DPP_XOR2>(ai[rb]), ar[rb]);
@@ -844,8 +848,10 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
 // while the even terms go by, the last B round publishes s instead of a term, and ONE round with the A
 // fragment finishes the step.  ceil(m/2) + 1 rounds (each one cross-workgroup exchange) instead of m; the
 // fragment in LDS is rebuilt twice per step (B, then A) from L2.
-// The fragments are not rebuilt per interval but advanced: B (LDS) += (eps - eps') P1 + (eps^2 - eps'^2) P2 and
-// A (registers) += (eps - eps') H1 -- three table reads per interval instead of five; the caller restarts them from
+// The fragments are not rebuilt per interval but advanced: B (registers: it is the operand of all rounds of the
+// interval but one, and reading it from LDS costs 131 KiB of LDS traffic per round -- 0.5 us, as much as the
+// matrix-core instructions themselves and badly overlapped with them) += (eps - eps') P1 + (eps^2 - eps'^2) P2 and
+// A (LDS: one round per interval) += (eps - eps') H1 -- three table reads per interval instead of five; the caller restarts them from
 // P0 / H0 (kh_coop_sq_restart) every KH_COOP_REFRESH intervals, so rounding cannot drift.
 #define KH_COOP_REFRESH 64
 struct KhCoopSqMasks {
@@ -864,19 +870,17 @@ __device__ __forceinline__ KhCoopSqMasks kh_coop_sq_masks(const KhCoopArgs &c, i
 }
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_sq_restart(const KhCoopArgs &c, const KhCoopSqMasks &mk, int g, int wave,
-                                                   int lane, const KhCoopFrag &b, cplx (&areg)[MAXKS],
+                                                   int lane, const KhCoopFrag &a, cplx (&breg)[MAXKS],
                                                    double &eps_prev) {
-    kh_coop_load_frag<MAXKS>(c.sq[0], g, wave, lane, c.ks, b, mk.p0);
-#ifndef KH_COOP_X_NOAREG
-    kh_coop_reg_load<MAXKS>(c.fops[0], g, wave, lane, c.ks, areg, mk.h0);
-#endif
+    kh_coop_reg_load<MAXKS>(c.sq[0], g, wave, lane, c.ks, breg, mk.p0);
+    kh_coop_load_frag<MAXKS>(c.fops[0], g, wave, lane, c.ks, a, mk.h0);
     eps_prev = 0.0;
 }
 
 template <int MAXKS, int COLS>
 __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, const KhExchange &ex,
                                                        const KhCoopSqMasks &mk, double eps, double &eps_prev, const KhCoopFrag &a,
-                                                       cplx (&areg)[MAXKS],
+                                                       cplx (&breg)[MAXKS],
                                                        cplx &state, unsigned int &rid, KhCoopLds &s, int N, int y,
                                                        int g, int row, int col, bool owner_valid, double fre,
                                                        double fim, double dt, int nsub, int m, int tid, int wave,
@@ -885,17 +889,14 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
     const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
     const int phases = (m + 1) >> 1;
 #ifndef KH_COOP_X_NOREBUILD  // (timing experiment: wrong results)
-#ifndef KH_COOP_X_NOREBUILD  // (timing experiment: wrong results)
     {
 #ifdef KH_TIMING
         const long long tr0 = clock64();
 #endif
         const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
-        kh_coop_axpy_frag<MAXKS>(c.sq[1], e1, g, wave, lane, c.ks, a, mk.p1);
-        kh_coop_axpy_frag<MAXKS>(c.sq[2], e2, g, wave, lane, c.ks, a, mk.p2);
-#ifndef KH_COOP_X_NOAREG  // (timing experiment: wrong results) no A fragment in registers: the last round uses B
-        kh_coop_reg_axpy<MAXKS>(c.fops[1], e1, g, wave, lane, c.ks, areg, mk.h1);
-#endif
+        kh_coop_reg_axpy<MAXKS>(c.sq[1], e1, g, wave, lane, c.ks, breg, mk.p1);
+        kh_coop_reg_axpy<MAXKS>(c.sq[2], e2, g, wave, lane, c.ks, breg, mk.p2);
+        kh_coop_axpy_frag<MAXKS>(c.fops[1], e1, g, wave, lane, c.ks, a, mk.h1);
         eps_prev = eps;
 #ifdef KH_TIMING
         if (tid == 0 && blockIdx.x == 0) {
@@ -906,8 +907,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
 #endif
     }
 #endif
-#endif
-    const KhCoopRegFrag<MAXKS> af = {areg, ~0u};
+    const KhCoopRegFrag<MAXKS> bf = {breg, ~0u};
     for (int sub = 0; sub < nsub; ++sub) {
         cplx sacc = c_make(h * state.x, h * state.y);
         for (int ph = 0; ph < phases; ++ph) {
@@ -916,7 +916,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             const double c2 = f2h2 * kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2];
             const double hn = ph + 1 < phases ? h * kh_inv_table[2 * ph + 3] : 0.0;
             cplx w;
-            kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
+            kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, bf, s, tid, wave, lane, w);
             if (kh_coop_is_owner<COLS>(tid)) {
                 const cplx t2 = c_make(c2 * w.x, c2 * w.y);
                 state.x += t2.x;
@@ -931,11 +931,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             ++rid;
         }
         cplx w;
-#ifdef KH_COOP_X_NOAREG
         kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w);
-#else
-        kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, af, s, tid, wave, lane, w);
-#endif
         if (s.abort) return false;
         if (kh_coop_is_owner<COLS>(tid)) {
             const cplx odd = c_mul(c_make(fre, fim), w);
@@ -984,14 +980,14 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
     double rounds = 0.0;
     int m_hint = 12;
     const KhCoopFrag a = {(cplx *)s.frag + tid};
-    cplx areg[MAXKS];
+    cplx breg[MAXKS];
     double eps_prev = 0.0;
     const KhCoopSqMasks mk = kh_coop_sq_masks(c, g, wave);
 #pragma unroll
-    for (int q = 0; q < MAXKS; ++q) areg[q] = c_make(0.0, 0.0);
+    for (int q = 0; q < MAXKS; ++q) breg[q] = c_make(0.0, 0.0);
     for (int step = 0; step < nt - 1; ++step) {
         const int n = direction > 0 ? step : nt - 2 - step;
-        if (c.sq != nullptr && step % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, areg, eps_prev);
+        if (c.sq != nullptr && step % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
         double eps[KH_COOP_MAX_L];
         double theta = p.op_norms[0];
 #pragma unroll
@@ -1007,7 +1003,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         if (c.sq != nullptr) {
-            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, areg, state, rid, s, N, y, g, row, col,
+            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
                 return;
             rounds += (double)nsub * (((m + 1) >> 1) + 1);
@@ -1079,14 +1075,14 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     for (int l = 0; l < KH_COOP_MAX_L; ++l) g_a_loc[l] = 0.0;
     int m_hint = 12;
     const KhCoopFrag a = {(cplx *)s.frag + tid};
-    cplx areg[MAXKS];
+    cplx breg[MAXKS];
     double eps_prev = 0.0;
     const KhCoopSqMasks mk = kh_coop_sq_masks(c, g, wave);
 #pragma unroll
-    for (int q = 0; q < MAXKS; ++q) areg[q] = c_make(0.0, 0.0);
+    for (int q = 0; q < MAXKS; ++q) breg[q] = c_make(0.0, 0.0);
     for (int n = 0; n < nt - 1; ++n) {
         const int par = n & 1;
-        if (c.sq != nullptr && n % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, areg, eps_prev);
+        if (c.sq != nullptr && n % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
         // co-state (and, second order, previous-iteration state) element of this owner
         cplx bra = has_state ? u.chi_store[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0);
         if constexpr (SO) {
@@ -1102,7 +1098,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
         for (int l = 0; l < KH_COOP_MAX_L; ++l) {
             if (l >= L) break;
             cplx w;
-            if (c.sq != nullptr) {  // (the LDS fragment holds B for the whole sweep: the control operator from registers)
+            if (c.sq != nullptr) {  // (the LDS fragment holds A for the whole sweep: the control operator from registers)
                 cplx hreg[MAXKS];
                 kh_coop_reg_load<MAXKS>(c.fops[1 + l], g, wave, lane, c.ks, hreg, mk.h1);  // (sq: one control, l = 0)
                 const KhCoopRegFrag<MAXKS, true> hf = {hreg, mk.h1};
@@ -1159,7 +1155,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         if (c.sq != nullptr) {
-            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, areg, state, rid, s, N, y, g, row, col,
+            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
                 return;
             rounds += (double)nsub * (((m + 1) >> 1) + 1);

@@ -11,7 +11,7 @@ from krotov_amd.engine import HipKrotovEngine
 spec = configs.config_c4(nt=1001)
 K, N, L = spec.K, spec.N, spec.L
 ops = [[spec.H0[k]] + [spec.Hc[k][l] for l in range(L)] for k in range(K)]
-eng = HipKrotovEngine(ops, np.diff(spec.tlist), is_super=True)
+eng = HipKrotovEngine(ops, np.diff(spec.tlist), is_super=True, theta_max=float(os.environ.get('KH_THETA_MAX', '0')))
 tl = spec.tlist
 pulses = np.array([[spec.controls[l](t + 0.5 * (tl[1] - tl[0]), None) for t in tl[:-1]] for l in range(L)])
 chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
@@ -21,4 +21,5 @@ t0 = time.perf_counter()
 for _ in range(3):
     eng.backward(chi_T, pulses)
 torch.cuda.synchronize()
-print('%s backward %.1f ms' % (eng.kernel, (time.perf_counter() - t0) / 3 * 1e3))
+print('%s backward %.1f ms, %.1f rounds per interval' % (eng.kernel, (time.perf_counter() - t0) / 3 * 1e3,
+                                                        eng.stats()['matvecs'] / (K * (len(tl) - 1))))

@@ -557,13 +557,16 @@ def test_runs_are_bitwise_repeatable():
     assert np.array_equal(np.array(a.tau_vals), np.array(b.tau_vals))
 
 
-def test_edge_cases():
+def test_edge_cases(monkeypatch):
     from krotov_amd.engine import HipKrotovEngine
 
     rng = np.random.default_rng(5)
     # non-uniform dt, control absent from one objective, more objectives than CUs: 300 -> two 256-thread
-    # workgroups per CU (register tiles), 600 -> the generic kernels' persistent loop over objectives
-    for K, kernel in ((300, 'tile64/256'), (600, 'generic')):
+    # workgroups per CU (register tiles), 600 -> the register-tile kernel with one launch per interval, or
+    # (KH_NO_STEPWISE=1) the generic kernels' persistent loop over objectives
+    for K, kernel in ((300, 'tile64/256'), (600, 'tile64/512 per interval'), (600, 'generic')):
+        if kernel == 'generic':
+            monkeypatch.setenv('KH_NO_STEPWISE', '1')
         N, nt = 6, 21
         tl = np.cumsum(np.concatenate([[0.0], rng.uniform(0.01, 0.05, nt - 1)]))
         H0 = [configs.herm(rng, N, 3.0) for _ in range(K)]
@@ -588,6 +591,7 @@ def test_edge_cases():
         assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12
         assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
         eng.close()
+    monkeypatch.delenv('KH_NO_STEPWISE')
     # N = 1 and a large step norm (several Taylor sub-steps)
     ops1 = [[np.array([[2.5 + 0j]]), np.array([[40.0 + 0j]])]]
     eng = HipKrotovEngine(ops1, [0.5, 0.25])
