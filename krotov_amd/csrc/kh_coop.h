@@ -4,26 +4,26 @@
 //
 // With shared operators one Taylor term for all objectives is a genuine dense product
 //     W (N x K)  =  A (N x N)  .  T (N x K),        A = op_0 + sum_l eps_l op_l,
-// so it goes to the fp64 matrix cores: v_mfma_f64_16x16x4_f64, M = 16 rows of A, N = 16 objectives,
-// complex arithmetic as four real products accumulated in two accumulators.
+// so it goes to the fp64 matrix cores: v_mfma_f64_16x16x4_f64 (16 objectives per workgroup) or v_mfma_f64_4x4x4_4b
+// (4 or 2), complex arithmetic as four (two) real products.
 //
-// Decomposition: workgroup (g, y) owns rows [16 g, 16 g + 16) of A and objectives [16 y, 16 y + 16).
-// Its 8 waves split the k range (4 ks values each); the A fragments stay in LDS for a whole time
-// interval (lane-linear: every lane reads back only what it wrote), the 8 partial 16 x 16 blocks
-// are summed through LDS.  Every Taylor term needs the
-// whole previous term, i.e. the blocks of all row workgroups: they are exchanged through a ring of
-// N x 16 blocks in global memory made of epoch-tagged 8-byte granules {epoch:32 | half of a
-// double:32}, written with agent-scope (write-through) atomic stores -- the data is its own
-// "ready" flag, so a round costs ONE memory round trip instead of data + flag.  A workgroup can be
-// at most one round ahead of the slowest reader (it needs everybody's block of round r before it
-// can publish r + 1), so any ring of >= 2 blocks is race free.  The ring is KH_COOP_RING deep so
-// that a block's lines have left the (per-XCD, not cross-XCD coherent) L2 before they are reused:
-// the first fetch of a round then goes through L2 at full bandwidth (workgroup-scope loads; the
-// agent-scope loads that bypass L2 run at ~10 GB/s per CU), and only granules whose tag shows a
-// stale line -- or data that had not landed yet -- are re-fetched with agent scope.
+// Decomposition: workgroup (g, y) owns rows [16 g, 16 g + 16) of A and `cols` objectives (16, 4 or 2: as few as keeps
+// the grid co-resident, and -- with 2 or 4 -- every column group on an XCD of its own, kh_coop_place).  Its 8 waves
+// split the k range; the partial blocks are summed through LDS.  Every term needs the whole previous term, i.e. the
+// blocks of all row workgroups of the column group: they are exchanged through a ring in global memory made of
+// epoch-tagged 8-byte granules {epoch:32 | half of a double:32} -- the data is its own "ready" flag, so a round costs
+// ONE memory round trip instead of data + flag.  A workgroup can be at most one round ahead of the slowest reader (it
+// needs everybody's block of round r before it can publish r + 1), so any ring of >= 2 blocks is race free; the ring is
+// KH_COOP_RING deep so that a block's lines have left the (per-XCD, not cross-XCD coherent) L2 before they are reused.
+// Layouts and scopes: kh_coop_slot (16 objectives), kh_coop_slot4 / kh_coop_publish (4 and 2: the consumer's lane
+// order, 16-byte loads).
 //
-// All workgroups must be co-resident (grid = ceil(N/16) x ceil(K/16) <= number of CUs); spins are
-// bounded by the exchange timeout and raise the engine's abort flag.
+// One control: the series runs on B = A^2 (kh_coop_expm_action_sq): B lives in registers, A in LDS, both advanced
+// from interval to interval instead of rebuilt; operator tables are kept in fragment order with a zero-slot mask
+// (kh_coop_permute_kernel, kh_coop_mask_kernel).  Several controls: term by term on the LDS fragment of A.
+//
+// All workgroups must be co-resident; spins are bounded by the exchange timeout and raise the engine's abort flag.
+// History, measurements and what bounds a round: DESIGN.md section 3.5.
 #pragma once
 
 #include "kh_common.h"
