@@ -190,13 +190,27 @@ __host__ inline void kh_bessel_j(double theta, int kmax, long double *J) {
 
 // tab[m]: largest theta <= 2 the degree-m Chebyshev truncation serves at `tol` (even m; odd m repeat m-1 so
 // that the smallest-degree search never lands on them); c0, rows as above
+//
+// theta_cap: largest theta served by the Chebyshev form (2 for the register-tile kernels, which sub-step at theta <= 1
+// anyway; 4 for the cooperative kernels, where a term costs a cross-workgroup round -- measured on the 400-dim
+// Liouvillian of config 4: the power form still reaches 2e-15 at theta = 4, like Taylor's, with degree 22 instead of 30).
+// delta > 0: the generator f A h is only NEARLY anti-Hermitian -- its Hermitian part is bounded by delta (a weakly
+// damped Liouvillian: 3e-4 against theta = 2.6 in config 4).  Its numerical range then lies in the rectangle
+// [-delta, delta] x i [-theta, theta], inside the ellipse with foci +- i theta through delta, where
+// |T_k| <= cosh(k asinh(delta / theta)); with Crouzeix's constant 1 + sqrt 2 for non-normal matrices the error is at
+// most (1 + sqrt 2) 2 sum_{k > m} |J_k(theta)| cosh(k asinh(delta / theta)).
 __host__ inline void kh_build_real_spectrum_rows(double tol, double *tab /*[KH_MAX_DEGREE+1]*/, double *c0, double *rows,
-                                                 double *ratios) {
+                                                 double *ratios, double theta_cap = 2.0, double delta = 0.0) {
     const int TAIL = 40;
     long double J[KH_MAX_DEGREE + TAIL + 2];
     auto err = [&](double theta, int m) {
         kh_bessel_j(theta, m + TAIL, J);
         long double e = 0.0L;
+        if (delta > 0.0) {
+            const long double eta = asinhl((long double)delta / (long double)theta);
+            for (int k = m + 1; k <= m + TAIL; ++k) e += fabsl(J[k]) * coshl(k * eta);
+            return (double)(2.0L * (1.0L + sqrtl(2.0L)) * e);
+        }
         for (int k = m + 1; k <= m + TAIL; ++k) e += fabsl(J[k]);
         return (double)(2.0L * e);
     };
@@ -209,11 +223,11 @@ __host__ inline void kh_build_real_spectrum_rows(double tol, double *tab /*[KH_M
             tab[m] = tab[m - 1];
             continue;
         }
-        if (taylor_tab[m] >= 2.0) {  // beyond the cap of the Chebyshev form: plain Taylor (rows already there)
+        if (taylor_tab[m] >= theta_cap) {  // beyond the cap of the Chebyshev form: plain Taylor (rows already there)
             tab[m] = taylor_tab[m] > tab[m - 1] ? taylor_tab[m] : tab[m - 1];
             continue;
         }
-        double lo = 0.0, hi = 2.0;
+        double lo = 0.0, hi = theta_cap;
         if (err(hi, m) <= tol) {
             lo = hi;
         } else {

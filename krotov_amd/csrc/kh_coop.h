@@ -71,6 +71,9 @@ struct KhCoopArgs {
     int local;                // (set in the kernel after kh_coop_check_placement: a wave-uniform copy of KhCoopLds::local)
     unsigned int *xcc;        // [Y * G] XCC id + 1 of every workgroup (placement check, zeroed with vbuf)
     const cplx *const *fops;  // [1 + L] this direction's (shared) operators in fragment order
+    const double *ser_theta;  // A^2 chain only: degree thresholds, c_0 and rows {c_{2p+1}/c_{2p}, c_{2p+2}/c_{2p}} of the series
+    const double *ser_c0;     // in use (kh_common.h: Chebyshev form for generators with an (almost) imaginary spectrum),
+    const double *ser_rows;   // or NULL: Taylor
     const cplx *const *sq;    // one control only: P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 of this direction's
                               // operators (A^2 = P0 + eps P1 + eps^2 P2) in fragment order, or NULL: term-by-term series
 };
@@ -79,6 +82,7 @@ struct KhCoopLds {
     double red[2][KH_COOP_WAVES][KH_COOP_MAX_L];  // owner waves' pieces of the update sums, by interval parity
     double D[2][KH_COOP_MAX_L + 1];        // reduced sums + ok flag, by interval parity
     double deg[KH_MAX_DEGREE + 2];
+    double coef[2 * KH_Q2_ROWS + 2];  // the current interval's series rows (kh_coop_expm_action_sq)
     int abort;
     int local;  // this column group's workgroups all sit on ONE XCD: term blocks are exchanged through its L2
 #ifdef KH_TIMING
@@ -888,6 +892,17 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
     const double h = nsub == 1 ? dt : dt / nsub;
     const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
     const int phases = (m + 1) >> 1;
+    // series coefficients of degree m: sum_j c_j (f h A)^j, rows[p] = {c_{2p+1}/c_{2p}, c_{2p+2}/c_{2p}} (p = 0: c_1, c_2)
+    // (copied to LDS once per interval: a scalar load from the table in every phase sat exposed in the round's chain)
+    const bool series = c.ser_rows != nullptr;
+    if (series) {
+        const double *grow = c.ser_rows + (size_t)m * KH_Q2_ROWS * 2;
+        if (tid < 2 * phases) s.coef[tid] = grow[tid];
+        if (tid == 2 * phases) s.coef[tid] = c.ser_c0[m];
+        __syncthreads();
+    }
+    const double *rows = series ? s.coef : nullptr;
+    const double c_0 = series ? s.coef[2 * phases] : 1.0, c_1 = series ? s.coef[0] : 1.0;
 #ifndef KH_COOP_X_NOREBUILD  // (timing experiment: wrong results)
     {
 #ifdef KH_TIMING
@@ -909,14 +924,17 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
 #endif
     const KhCoopRegFrag<MAXKS> bf = {breg, ~0u};
     for (int sub = 0; sub < nsub; ++sub) {
-        cplx sacc = c_make(h * state.x, h * state.y);
+        cplx sacc = c_make(h * c_1 * state.x, h * c_1 * state.y);
+        state = c_make(c_0 * state.x, c_0 * state.y);  // (the published block of this round is the unscaled state)
         for (int ph = 0; ph < phases; ++ph) {
             // (the coefficients are fetched before the round, not between its end and the owners' stores; a timed-out
             // round is noticed after the phases: the later rounds give up at once on the abort flag)
-            const double c2 = f2h2 * kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2];
-            const double hn = ph + 1 < phases ? h * kh_inv_table[2 * ph + 3] : 0.0;
+            // (read before the round, used after it)
+            const double r2 = rows != nullptr ? rows[2 * ph + 1] : kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2];
+            const double r1n = ph + 1 < phases ? (rows != nullptr ? rows[2 * ph + 2] : kh_inv_table[2 * ph + 3]) : 0.0;
             cplx w;
             kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, bf, s, tid, wave, lane, w);
+            const double c2 = f2h2 * r2, hn = h * r1n;
             if (kh_coop_is_owner<COLS>(tid)) {
                 const cplx t2 = c_make(c2 * w.x, c2 * w.y);
                 state.x += t2.x;
@@ -959,7 +977,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
     if (!kh_coop_place(c_in, g, y)) return;
     const int rowbase = g * 16;
     const int N = p.N, nt = p.nt, L = p.L;
-    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = (c_in.sq != nullptr && c_in.ser_theta != nullptr) ? c_in.ser_theta[tid] : p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
 #ifdef KH_TIMING
     if (tid < 12) s.tim[tid] = 0.0;
@@ -1054,7 +1072,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     const int rowbase = g * 16;
     const int wg = y * c_in.G + g;  // linear workgroup index of the exchange
     const int N = p.N, nt = p.nt, L = p.L;
-    if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.deg_theta[tid];
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = (c_in.sq != nullptr && c_in.ser_theta != nullptr) ? c_in.ser_theta[tid] : p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
     kh_coop_check_placement(c_in, ex, s, g, y, tid);
     KhCoopArgs c = c_in;

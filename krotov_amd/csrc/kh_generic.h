@@ -481,6 +481,31 @@ __global__ void kh_adjoint_sign_kernel(const cplx *const *__restrict__ ops, cons
     }
 }
 
+// max over the drift operators of || (A + sign A^dagger) / 2 ||_F^2  (sign = +1: Hermitian part, -1: anti-Hermitian
+// part) -> *out (bits of a non-negative double, atomicMax); one workgroup per operator
+__global__ void kh_herm_defect_kernel(const cplx *const *__restrict__ ops, const cplx *const *__restrict__ ops_adj,
+                                      int nops, int Lp1, int N, double sign, unsigned long long *__restrict__ out) {
+    __shared__ double red[256];
+    for (int i = blockIdx.x * Lp1; i < nops; i += gridDim.x * Lp1) {
+        double acc = 0.0;
+        if (ops[i] != nullptr) {
+            const cplx *a = ops[i], *b = ops_adj[i];
+            for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
+                const double re = 0.5 * (a[idx].x + sign * b[idx].x), im = 0.5 * (a[idx].y + sign * b[idx].y);
+                acc += re * re + im * im;
+            }
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(red[0]));
+        __syncthreads();
+    }
+}
+
 // out[c][r] = conj(in[r][c]); 32x32 tiles through LDS
 __global__ void kh_adjoint_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, int N) {
     __shared__ cplx tile[32][33];

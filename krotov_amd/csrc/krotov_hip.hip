@@ -103,6 +103,9 @@ struct kh_engine {
                                // 16-byte loads per lane there: an early, stale pass costs little -- measured 0 best)
     double adj_sign = 0.0;  // +1 / -1: every control operator equals +/- its adjoint exactly (else 0)
     bool real_spectrum = false;  // every operator Hermitian (bit for bit) and f = -+i
+    double imag_defect = -1.0;   // >= 0: bound on the Hermitian part of f A dt when the controls' f H_l are exactly
+                                 // anti-Hermitian (|| . ||_F of the drift's part x max dt); < 0: not of that kind
+    bool coop_series = false;    // the cooperative kernels run the Chebyshev-form series (kh_common.h)
     bool hermitian = false;      // the same, whichever series tables are in use (KH_TAYLOR): kh_tile64mm.h
     int mm_nio = 2;              // 4-row blocks per wave of that kernel: 2 -> 8 waves (KH_MM_WAVES=4: 4 -> 4 waves)
     bool use_mm = false;         // KH_MM=1: the matrix-core update kernel (kh_tile64mm.h) instead of the vector-FMA one
@@ -335,9 +338,32 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         // every generator Hermitian and f = -+i: real spectrum (the q2 kernels' shorter series, kh_common.h)
         e->real_spectrum = flags[0] == 0 && flags[2] == 0 && !e->is_super;
         e->hermitian = e->real_spectrum;
+        {   // f A anti-Hermitian up to a small Hermitian part of the drift (a weakly damped Liouvillian; a Hamiltonian
+            // with a small anti-Hermitian part): the shorter series of kh_common.h applies with a margin
+            const bool controls_ok = e->is_super ? flags[1] == 0 : flags[0] == 0;
+            if (controls_ok) {
+                unsigned long long *d_max = nullptr, bits = 0;
+                KH_HIP_E(hipMalloc(&d_max, sizeof(bits)));
+                hipError_t err2 = hipMemset(d_max, 0, sizeof(bits));
+                if (err2 == hipSuccess) {
+                    kh_herm_defect_kernel<<<(unsigned)(e->K < 1024 ? e->K : 1024), 256>>>(
+                        e->d_ops_fw, e->d_ops_bw, (int)nops, 1 + e->L, e->N, e->is_super ? 1.0 : -1.0, d_max);
+                    err2 = hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost);
+                }
+                (void)hipFree(d_max);
+                KH_HIP_E(err2);
+                double fro2, dt_max = 0.0;
+                memcpy(&fro2, &bits, sizeof(fro2));
+                for (int n = 0; n < e->nt - 1; ++n) dt_max = pr->dt[n] > dt_max ? pr->dt[n] : dt_max;
+                e->imag_defect = sqrt(fro2) * dt_max;
+            }
+        }
         if (const char *d = getenv("KH_MM")) e->use_mm = atoi(d) != 0;
         if (const char *d = getenv("KH_TAYLOR"))  // A/B switch: plain Taylor coefficients everywhere
-            if (atoi(d) != 0) e->real_spectrum = false;
+            if (atoi(d) != 0) {
+                e->real_spectrum = false;
+                e->imag_defect = -1.0;
+            }
         if (const char *d = getenv("KH_NO_ADJ"))  // A/B switch: keep <chi|H phi> on the forward side
             if (atoi(d) != 0) e->adj_sign = 0.0;
     }
@@ -546,7 +572,12 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     {  // (every kernel family but the cooperative one reads the series tables)
         std::vector<double> tab(KH_MAX_DEGREE + 1), c0(KH_MAX_DEGREE + 1), rows((size_t)(KH_MAX_DEGREE + 1) * KH_Q2_ROWS * 2),
             ratios((size_t)(KH_MAX_DEGREE + 1) * KH_RATIO_STRIDE);
-        if (e->real_spectrum) {
+        // the cooperative kernels (A^2 chain, one control): a term is a cross-workgroup round, so the Chebyshev form
+        // is used up to theta = 4 and also for generators that are anti-Hermitian only up to a small defect
+        e->coop_series = e->kind == KIND_COOP && coop_sq && e->imag_defect >= 0.0 && e->imag_defect <= 0.05;
+        if (e->coop_series) {
+            kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data(), 4.0, e->imag_defect);
+        } else if (e->real_spectrum) {
             kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data());
         } else {
             kh_build_degree_table(e->tol, tab.data());
@@ -697,6 +728,9 @@ static KhCoopArgs coop_args(const kh_engine *e, bool backward) {
     c.xcd_rows = e->coop_xcd ? e->coop_G : 0;
     c.xcc = e->d_coop_xcc;
     c.local = 0;
+    c.ser_theta = e->coop_series ? e->d_q2_theta : nullptr;
+    c.ser_c0 = e->coop_series ? e->d_q2_c0 : nullptr;
+    c.ser_rows = e->coop_series ? e->d_q2_rows : nullptr;
     return c;
 }
 
