@@ -685,6 +685,10 @@ def _two_rank_spec(case):
         return spec
     if case == 'c3':  # small problem: the one-wave-per-objective kernels, 2 + 2 objectives
         return configs.config_c3(nt=301)
+    if case == 'k1100':  # 550 objectives per rank: not co-resident, so no in-kernel exchange -- the peer windows
+        spec = configs.config_c5(K=1100, N=6, nt=13, L=1)  # are refused and every interval is a launch + all-reduce
+        spec.chi = 'sm'
+        return spec
     return configs.config_c4(d=9, nt=41, n_logical=3)  # N = 81, K = 9 -> 5 + 4 objectives
 
 
@@ -731,7 +735,7 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so'])
+@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'k1100'])
 def test_two_ranks_sharded_on_one_gpu(case):
     import socket
 
@@ -757,15 +761,17 @@ def test_two_ranks_sharded_on_one_gpu(case):
         ref = oracle_optimize(spec, 2, sigma=SigmaA(0.0, 2e-3))
     else:
         ref = oracle_optimize(spec, 2)
-    tol = 1e-12 if case in ('c5', 'c3') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
+    tol = 1e-12 if case in ('c5', 'c3', 'k1100') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
     for _, pulses, tau, used_p2p, kernel in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
-        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave'}.get(case, 'coop16/mfma')
+        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/512 per interval'}.get(case, 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
     # the path this test is here for: the sums crossed the ranks inside the persistent kernels, through the
     # peer-mapped windows -- not through the per-interval fallback
-    if os.environ.get('KH_P2P', '1') != '0':
+    if case == 'k1100':
+        assert not any(o[3] for o in out)
+    elif os.environ.get('KH_P2P', '1') != '0':
         assert all(o[3] for o in out), "peer-window exchange was not used: %r" % ([o[3] for o in out],)
 
 
