@@ -1145,7 +1145,12 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
                 for (int l = 0; l < KH_COOP_MAX_L; ++l)
                     if (l < L) part[l] += (s.red[par][4][l] + s.red[par][5][l]) + (s.red[par][6][l] + s.red[par][7][l]);
             }
+#ifdef KH_COOP_X_NOEXCH  // (timing experiment: wrong results) the workgroup's own sums only
+            const bool ok = true;
+            for (int l = 0; l < KH_COOP_MAX_L; ++l) D[l] = part[l];
+#else
             const bool ok = kh_exchange<KH_COOP_MAX_L>(ex, n, wg, L, lane, part, D);
+#endif
             if (lane == 0) {
 #pragma unroll
                 for (int l = 0; l < KH_COOP_MAX_L; ++l) s.D[par][l] = D[l];

@@ -15,7 +15,7 @@ eng = HipKrotovEngine(ops, np.diff(spec.tlist), is_super=True, theta_max=float(o
 tl = spec.tlist
 pulses = np.array([[spec.controls[l](t + 0.5 * (tl[1] - tl[0]), None) for t in tl[:-1]] for l in range(L)])
 chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
-eng.backward(chi_T, pulses)
+chi = eng.backward(chi_T, pulses)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(3):
@@ -23,3 +23,11 @@ for _ in range(3):
 torch.cuda.synchronize()
 print('%s backward %.1f ms, %.1f rounds per interval' % (eng.kernel, (time.perf_counter() - t0) / 3 * 1e3,
                                                         eng.stats()['matvecs'] / (K * (len(tl) - 1))))
+if os.environ.get('KH_WITH_UPDATE'):  # (only with builds whose pulses stay bounded)
+    S = np.ones((L, len(tl) - 1)); lam = np.full(L, 1e3); norms = np.full(K, 1.0 / (2 * K))
+    eng.forward_update(chi, norms, spec.init, pulses, S, lam); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.forward_update(chi, norms, spec.init, pulses, S, lam)
+    torch.cuda.synchronize()
+    print('update %.1f ms' % ((time.perf_counter() - t0) / 3 * 1e3))
