@@ -579,6 +579,10 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data(), 4.0, e->imag_defect);
         } else if (e->real_spectrum) {
             kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data());
+        } else if (e->imag_defect > 0.0 && e->imag_defect <= 0.05 && !(getenv("KH_NEAR_IMAG") && atoi(getenv("KH_NEAR_IMAG")) == 0)) {
+            // the same form, with the margin for the Hermitian defect, for the other kernel families (weakly damped
+            // Liouvillians, Hamiltonians with a small anti-Hermitian part); KH_NEAR_IMAG=0: Taylor (A/B switch)
+            kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data(), 2.0, e->imag_defect);
         } else {
             kh_build_degree_table(e->tol, tab.data());
             kh_build_taylor_rows(c0.data(), rows.data(), ratios.data());
