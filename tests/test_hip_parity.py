@@ -189,6 +189,43 @@ def test_q2_real_spectrum_series_vs_taylor(name, monkeypatch):
     assert issued[0] <= issued[1]
 
 
+@pytest.mark.parametrize('name', ['c2l', 'c4_d5', 'c4_d9', 'c4_d10_k9'])
+def test_near_imaginary_spectrum_series_vs_taylor(name, monkeypatch):
+    """Weakly damped Liouvillians: f A is anti-Hermitian up to a small Hermitian part of the drift, which the engine
+    measures; the Chebyshev-form series then applies with a margin (kh_common.h; register-tile, one-wave and -- up
+    to theta = 4 -- cooperative kernels).  KH_TAYLOR=1 keeps Taylor.  Both match the oracle and each other; the
+    shorter series issues fewer products where the degree table has room for it."""
+    spec = SMALL[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    # (||H_1|| ~ 1e2 and lambda_a = 1 in the transmon cases: keep the updated pulses O(1), as in
+    # test_second_order_update_sweep, so that the problem stays well conditioned)
+    norms = np.full(spec.K, 0.37 * (0.02 if name.startswith('c4_d') else 1.0))
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    tol = 1e-11 if name.startswith('c4_d') else 1e-12
+    out, issued = [], []
+    for taylor in ('0', '1'):
+        monkeypatch.setenv('KH_TAYLOR', taylor)
+        eng = _engine(spec)
+        chi = eng.backward(chi_T, pulses)
+        assert np.abs(chi.cpu().numpy() - ref_chi).max() < tol
+        opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+        eng.check()
+        assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < tol * scale
+        assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < tol
+        out.append(opt.cpu().numpy())
+        issued.append(eng.stats()['matvecs'])
+        eng.close()
+    assert np.abs(out[0] - out[1]).max() < 10 * tol * scale
+    assert issued[0] <= issued[1]
+    if name in ('c4_d9', 'c4_d10_k9'):  # (cooperative kernels: the form reaches to theta = 4)
+        assert issued[0] < issued[1]
+
+
 def test_objective_propagate_on_device():
     """Objective.propagate with the GPU propagator = ONE forward sweep with storage; same states and expectation
     values as the host loop over a NumPy propagator (Hilbert space and a Liouvillian acting on a density matrix)."""
