@@ -236,19 +236,34 @@ __device__ __forceinline__ void kh_coop_check_placement(const KhCoopArgs &c, con
 }
 
 // this lane's elements of row block g of a fragment-ordered operator (NULL: zero operator)
-__device__ __forceinline__ const cplx *kh_coop_frag_src(const cplx *op, int g, int wave, int lane, int ks) {
-    return op == nullptr ? nullptr : op + ((size_t)(g * KH_COOP_WAVES + wave) * ks) * 64 + lane;
+// (The table pointers come out of a pointer table in memory, so the compiler knows no address space for them and
+// would read the tables with FLAT loads -- which also count against the LDS counter and so serialise with the LDS
+// traffic of a fragment update.  They are global memory: say so.)
+typedef double kh_d2 __attribute__((ext_vector_type(2)));
+struct KhCoopSrc {
+    const __attribute__((address_space(1))) kh_d2 *p;
+    __device__ __forceinline__ bool null() const { return p == nullptr; }
+    __device__ __forceinline__ cplx operator[](size_t i) const {
+        const kh_d2 v = p[i];
+        return c_make(v.x, v.y);
+    }
+};
+__device__ __forceinline__ KhCoopSrc kh_coop_frag_src(const cplx *op, int g, int wave, int lane, int ks) {
+    KhCoopSrc r;
+    r.p = op == nullptr ? nullptr
+                        : (const __attribute__((address_space(1))) kh_d2 *)(op + ((size_t)(g * KH_COOP_WAVES + wave) * ks) * 64 + lane);
+    return r;
 }
 
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_load_frag(const cplx *op, int g, int wave, int lane, int ks,
                                                   const KhCoopFrag &f, unsigned int mask = ~0u) {
-    const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
+    const KhCoopSrc src = kh_coop_frag_src(op, g, wave, lane, ks);
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
         if (q < ks) {
             f.f[(size_t)q * KH_COOP_THREADS] =
-                (src != nullptr && ((mask >> q) & 1u)) ? src[(size_t)q * 64] : c_make(0.0, 0.0);
+                (!src.null() && ((mask >> q) & 1u)) ? src[(size_t)q * 64] : c_make(0.0, 0.0);
         }
     }
 }
@@ -257,8 +272,8 @@ __device__ __forceinline__ void kh_coop_load_frag(const cplx *op, int g, int wav
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_axpy_frag(const cplx *op, double eps, int g, int wave, int lane, int ks,
                                                   const KhCoopFrag &a, unsigned int mask = ~0u) {
-    const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
-    if (src == nullptr) return;
+    const KhCoopSrc src = kh_coop_frag_src(op, g, wave, lane, ks);
+    if (src.null()) return;
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
         if (q < ks && ((mask >> q) & 1u)) {
@@ -787,16 +802,16 @@ __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExcha
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_reg_load(const cplx *op, int g, int wave, int lane, int ks, cplx (&r)[MAXKS],
                                                  unsigned int mask = ~0u) {
-    const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
+    const KhCoopSrc src = kh_coop_frag_src(op, g, wave, lane, ks);
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q)
-        r[q] = (q < ks && src != nullptr && ((mask >> q) & 1u)) ? src[(size_t)q * 64] : c_make(0.0, 0.0);
+        r[q] = (q < ks && !src.null() && ((mask >> q) & 1u)) ? src[(size_t)q * 64] : c_make(0.0, 0.0);
 }
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_reg_axpy(const cplx *op, double eps, int g, int wave, int lane, int ks,
                                                  cplx (&r)[MAXKS], unsigned int mask = ~0u) {
-    const cplx *src = kh_coop_frag_src(op, g, wave, lane, ks);
-    if (src == nullptr) return;
+    const KhCoopSrc src = kh_coop_frag_src(op, g, wave, lane, ks);
+    if (src.null()) return;
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) {
         if (q < ks && ((mask >> q) & 1u)) {
