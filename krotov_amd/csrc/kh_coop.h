@@ -34,6 +34,9 @@
 #define KH_COOP_COLS 16     // MFMA N: a workgroup handles c.cols <= 16 objectives (the rest of the tile is zero)
 // owner threads: tid < 16 COLS owns element (row tid / COLS, column tid % COLS) of the block (one wave for COLS = 4)
 #define KH_COOP_RING 32      // blocks in the exchange ring
+#ifndef KH_COOP_CHUNK
+#define KH_COOP_CHUNK 4     // slots whose loads are in flight together in a fragment update (MAXKS is a multiple)
+#endif
 #define KH_COOP_MAX_L 2     // controls (the update-sum exchange keeps 16 registers per control in flight)
 
 typedef double kh_d4 __attribute__((ext_vector_type(4)));
@@ -274,14 +277,24 @@ __device__ __forceinline__ void kh_coop_axpy_frag(const cplx *op, double eps, in
                                                   const KhCoopFrag &a, unsigned int mask = ~0u) {
     const KhCoopSrc src = kh_coop_frag_src(op, g, wave, lane, ks);
     if (src.null()) return;
+    // in chunks of four slots, loads (table and LDS) before uses -- see kh_coop_reg_axpy
 #pragma unroll
-    for (int q = 0; q < MAXKS; ++q) {
-        if (q < ks && ((mask >> q) & 1u)) {
-            const cplx v = src[(size_t)q * 64];
-            cplx t = a.get(q);
-            t.x = fma(eps, v.x, t.x);
-            t.y = fma(eps, v.y, t.y);
-            a.f[(size_t)q * KH_COOP_THREADS] = t;
+    for (int c0 = 0; c0 < MAXKS; c0 += 4) {
+        if (c0 < ks && ((mask >> c0) & 0xfu) != 0u) {
+            cplx v[4], t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = src[(size_t)(c0 + j < ks ? c0 + j : ks - 1) * 64];
+                t[j] = a.get(c0 + j < MAXKS ? c0 + j : MAXKS - 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (c0 + j < ks) {
+                    t[j].x = fma(eps, v[j].x, t[j].x);
+                    t[j].y = fma(eps, v[j].y, t[j].y);
+                    a.f[(size_t)(c0 + j) * KH_COOP_THREADS] = t[j];
+                }
+            }
         }
     }
 }
@@ -812,12 +825,24 @@ __device__ __forceinline__ void kh_coop_reg_axpy(const cplx *op, double eps, int
                                                  cplx (&r)[MAXKS], unsigned int mask = ~0u) {
     const KhCoopSrc src = kh_coop_frag_src(op, g, wave, lane, ks);
     if (src.null()) return;
+    // Slots are read in chunks of KH_COOP_CHUNK: all loads of a chunk are issued before the first is used.  One slot at
+    // a time -- what a per-slot mask test compiles to, every load in a basic block of its own -- exposes the full L2
+    // latency once per slot: 16 x 0.3 us = the 4.8 us per interval the dense table read used to cost (the L2 hit rate
+    // is 97 %, the traffic 21 GB/s per CU: neither bandwidth nor misses).  A chunk is skipped if all its slots are zero
+    // (tables are zero-padded to whole chunks; zero slots inside a chunk are read and add nothing).
 #pragma unroll
-    for (int q = 0; q < MAXKS; ++q) {
-        if (q < ks && ((mask >> q) & 1u)) {
-            const cplx v = src[(size_t)q * 64];
-            r[q].x = fma(eps, v.x, r[q].x);
-            r[q].y = fma(eps, v.y, r[q].y);
+    for (int c0 = 0; c0 < MAXKS; c0 += KH_COOP_CHUNK) {
+        if (c0 < ks && ((mask >> c0) & ((1u << KH_COOP_CHUNK) - 1u)) != 0u) {
+            cplx v[KH_COOP_CHUNK];
+#pragma unroll
+            for (int j = 0; j < KH_COOP_CHUNK; ++j)  // (slots >= ks do not exist: clamped address, value dropped)
+                v[j] = src[(size_t)(c0 + j < ks ? c0 + j : ks - 1) * 64];
+#pragma unroll
+            for (int j = 0; j < KH_COOP_CHUNK; ++j) {
+                if (c0 + j >= ks) v[j] = c_make(0.0, 0.0);
+                r[c0 + j].x = fma(eps, v[j].x, r[c0 + j].x);
+                r[c0 + j].y = fma(eps, v[j].y, r[c0 + j].y);
+            }
         }
     }
 }
@@ -924,9 +949,13 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         const long long tr0 = clock64();
 #endif
         const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
+#ifndef KH_COOP_X_NOP1  // (timing experiment: wrong results)
         kh_coop_reg_axpy<MAXKS>(c.sq[1], e1, g, wave, lane, c.ks, breg, mk.p1);
+#endif
+#ifndef KH_COOP_X_NOP2H1
         kh_coop_reg_axpy<MAXKS>(c.sq[2], e2, g, wave, lane, c.ks, breg, mk.p2);
         kh_coop_axpy_frag<MAXKS>(c.fops[1], e1, g, wave, lane, c.ks, a, mk.h1);
+#endif
         eps_prev = eps;
 #ifdef KH_TIMING
         if (tid == 0 && blockIdx.x == 0) {
