@@ -1,5 +1,7 @@
+#!/bin/bash
+# usage: scripts/collect_c4_l2.sh <tag>   (run on the GPU box via gpurun) -> gpurun_out/<tag>/...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r02_v4/c4_l2
+OUT=$R/gpurun_out/${1:-r02}/c4_l2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $OUT/a -o b -- python $R/bench.py --workload c4 --no-cpu-baseline --steps 1 --warmup 1 > $OUT/a.log 2>&1

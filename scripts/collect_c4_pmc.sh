@@ -1,6 +1,8 @@
+#!/bin/bash
+# usage: scripts/collect_c4_pmc.sh <tag>   (run on the GPU box via gpurun) -> gpurun_out/<tag>/...
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r02_v3/c4_pmc
+OUT=$R/gpurun_out/${1:-r02}/c4_pmc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES"; do
