@@ -143,6 +143,14 @@ struct KhCoopRegFrag {
 // columns and the row group rb -- row 16 g + 4 rb + (lane & 3), column 16 (start + gi) + 4 ((lane >> 2) & 3) +
 // (lane >> 4).  The vector block of a group then IS the B operand as loaded (one element per lane, no replication
 // across blocks, no ds_bpermute): see kh_coop_round.
+// Row block g starts at g * kh_coop_table_stride(ks): the fragment size plus KH_COOP_TABLE_PAD elements, so that the
+// row blocks -- read by the workgroups of an XCD at the same moment, same (wave, slot) offset -- do not start a
+// power of two apart and fall onto one L2 channel each.
+#ifndef KH_COOP_TABLE_PAD
+#define KH_COOP_TABLE_PAD 272  // 4096 + 256 bytes
+#endif
+__host__ __device__ inline size_t kh_coop_table_stride(int ks) { return (size_t)KH_COOP_WAVES * ks * 64 + KH_COOP_TABLE_PAD; }
+__host__ __device__ inline size_t kh_coop_table_elems(int G, int ks) { return (size_t)G * kh_coop_table_stride(ks); }
 __global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, int N, int G, int ks,
                                        int cols) {
     const size_t total = (size_t)G * KH_COOP_WAVES * ks * 64;
@@ -161,7 +169,8 @@ __global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__rest
             row = g * 16 + (lane & 15);
             col = (wave * ks + q) * 4 + (lane >> 4);
         }
-        out[idx] = (row < N && col < N) ? in[(size_t)row * N + col] : c_make(0.0, 0.0);
+        out[(size_t)g * kh_coop_table_stride(ks) + (size_t)(wave * ks + q) * 64 + lane] =
+            (row < N && col < N) ? in[(size_t)row * N + col] : c_make(0.0, 0.0);
     }
 }
 
@@ -173,7 +182,8 @@ __global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__rest
 // terms are exact zeros.
 __global__ void kh_coop_mask_kernel(const cplx *__restrict__ tab, unsigned int *__restrict__ mask, int ks) {
     const int lane = threadIdx.x;  // one wave per (row block, wave)
-    const cplx *src = tab + (size_t)blockIdx.x * ks * 64 + lane;
+    const cplx *src = tab + (size_t)(blockIdx.x / KH_COOP_WAVES) * kh_coop_table_stride(ks) +
+                      (size_t)(blockIdx.x % KH_COOP_WAVES) * ks * 64 + lane;
     unsigned int m = 0;
     for (int q = 0; q < ks; ++q) {
         const cplx v = src[(size_t)q * 64];
@@ -181,7 +191,6 @@ __global__ void kh_coop_mask_kernel(const cplx *__restrict__ tab, unsigned int *
     }
     if (lane == 0) mask[blockIdx.x] = m;
 }
-__host__ __device__ inline size_t kh_coop_table_elems(int G, int ks) { return (size_t)G * KH_COOP_WAVES * ks * 64; }
 __device__ __forceinline__ unsigned int kh_coop_frag_mask(const cplx *op, int G, int g, int wave, int ks) {
     if (op == nullptr) return 0u;
     const unsigned int *m = (const unsigned int *)(op + kh_coop_table_elems(G, ks));
@@ -254,7 +263,7 @@ struct KhCoopSrc {
 __device__ __forceinline__ KhCoopSrc kh_coop_frag_src(const cplx *op, int g, int wave, int lane, int ks) {
     KhCoopSrc r;
     r.p = op == nullptr ? nullptr
-                        : (const __attribute__((address_space(1))) kh_d2 *)(op + ((size_t)(g * KH_COOP_WAVES + wave) * ks) * 64 + lane);
+                        : (const __attribute__((address_space(1))) kh_d2 *)(op + (size_t)g * kh_coop_table_stride(ks) + (size_t)wave * ks * 64 + lane);
     return r;
 }
 

@@ -532,7 +532,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     }
     if (e->kind == KIND_COOP) {
         // fragment-ordered copies of the (shared) operators and, for one control, of P0, P1, P2 (kh_coop.h)
-        const size_t elems = (size_t)e->coop_G * KH_COOP_WAVES * e->coop_ks * 64;
+        const size_t elems = kh_coop_table_elems(e->coop_G, e->coop_ks);  // (row blocks padded apart: kh_coop_table_stride)
+        const size_t frag_elems = (size_t)e->coop_G * KH_COOP_WAVES * e->coop_ks * 64;
         std::map<const void *, const cplx *> perm_of;
         auto permuted = [&](const cplx *src, const cplx **out) -> hipError_t {
             *out = nullptr;
@@ -544,7 +545,11 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                 const hipError_t err = hipMalloc(&dst, sizeof(cplx) * elems + sizeof(unsigned int) * e->coop_G * KH_COOP_WAVES);
                 if (err != hipSuccess) return err;
                 e->owned.push_back(dst);
-                kh_coop_permute_kernel<<<(unsigned)((elems + 255) / 256), 256>>>(src, dst, e->N, e->coop_G, e->coop_ks, e->coop_cols);
+                {
+                    const hipError_t merr = hipMemset(dst, 0, sizeof(cplx) * elems);
+                    if (merr != hipSuccess) return merr;
+                }
+                kh_coop_permute_kernel<<<(unsigned)((frag_elems + 255) / 256), 256>>>(src, dst, e->N, e->coop_G, e->coop_ks, e->coop_cols);
                 kh_coop_mask_kernel<<<e->coop_G * KH_COOP_WAVES, 64>>>(dst, (unsigned int *)(dst + elems), e->coop_ks);
                 it = perm_of.emplace(src, dst).first;
             }
