@@ -106,12 +106,35 @@ __device__ __forceinline__ void kh_q2_build(const KhQ2Lds &s, int tid, double ep
     }
 }
 
+#define KH_Q2_REFRESH 64
+// The plain sweeps advance resident tiles too, entirely in registers (H1, P1, P2 are there already):
+//   A += (eps - eps') H1,   B += (eps - eps') P1 + (eps^2 - eps'^2) P2
+// and restart from H0, P0 in LDS every KH_Q2_REFRESH intervals: no LDS traffic per interval instead of the 128 KiB
+// a workgroup read to rebuild its two tiles (1 024 cycles of the LDS pipe in front of the first phase).
+__device__ __forceinline__ void kh_q2_restart_lds(const KhQ2Lds &s, int tid, cplx (&a)[8], cplx (&b)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = s.h0[j * KH_Q2_THREADS + tid];
+        b[j] = s.p0[j * KH_Q2_THREADS + tid];
+    }
+}
+__device__ __forceinline__ void kh_q2_advance_reg(double eps, double eps_prev, const cplx (&h1)[8], const cplx (&p1)[8],
+                                                  const cplx (&p2)[8], cplx (&a)[8], cplx (&b)[8]) {
+    const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j].x = fma(e1, h1[j].x, a[j].x);
+        a[j].y = fma(e1, h1[j].y, a[j].y);
+        b[j].x = fma(e2, p2[j].x, fma(e1, p1[j].x, b[j].x));
+        b[j].y = fma(e2, p2[j].y, fma(e1, p1[j].y, b[j].y));
+    }
+}
+
 // The update kernels keep A and B resident and advance them from interval to interval instead:
 //   A += (eps - eps') H1,   B += (eps - eps') P1 + (eps^2 - eps'^2) P2      (P1, P2 from LDS)
 // Only H1, A and B stay in registers (96 VGPRs instead of the 160 of H1, P1, P2, A, B): no spills.  Every
 // KH_Q2_REFRESH intervals A and B restart from H0 and P0 in global memory (eps' = 0), so rounding cannot drift
 // (64 updates: a few ulp of the tiles).
-#define KH_Q2_REFRESH 64
 __device__ __forceinline__ void kh_q2_advance(const KhQ2Lds &s, int tid, double eps, double eps_prev, const cplx (&h1)[8],
                                               cplx (&a)[8], cplx (&b)[8]) {
     const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
@@ -250,7 +273,14 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
 #ifdef KH_TIMING
         long long t_build = 0, t_phases = 0;
 #endif
-        for (int step = 0; step < nt - 1; ++step) {
+        cplx a[8], b[8];
+        double eps_prev = 0.0;
+        for (int step0 = 0; step0 < nt - 1; step0 += KH_Q2_REFRESH) {
+        // (restart outside the interval loop: its body keeps ONE definition of the tiles, see kh_q2_forward_update)
+        kh_q2_restart_lds(s, tid, a, b);
+        eps_prev = 0.0;
+        const int step_stop = step0 + KH_Q2_REFRESH < nt - 1 ? step0 + KH_Q2_REFRESH : nt - 1;
+        for (int step = step0; step < step_stop; ++step) {
 #ifdef KH_TIMING
             const long long tq0 = clock64();
 #endif
@@ -267,8 +297,8 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
                 kh_q2_load_rows(p, s, m, tid);
                 m_rows = m;
             }
-            cplx a[8], b[8];
-            kh_q2_build(s, tid, eps, h1, p1, p2, a, b);
+            kh_q2_advance_reg(eps, eps_prev, h1, p1, p2, a, b);
+            eps_prev = eps;
             cplx *store_in =
                 store == nullptr ? nullptr : store + ((size_t)k * nt + (direction > 0 ? n : n + 1)) * N;
 #ifdef KH_TIMING
@@ -280,6 +310,7 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
 #ifdef KH_TIMING
             t_phases += clock64() - tq1;
 #endif
+        }
         }
 #ifdef KH_TIMING
         if (tid == 0 && k == 0 && p.stats != nullptr) {
