@@ -18,7 +18,10 @@ N ranks (``"scaling": "strong"``: 256/N per GPU), the L update sums crossing the
 GPUs once per time interval (peer-mapped windows inside the persistent kernels, or
 one RCCL all-reduce).  The same JSON line carries a second measurement under
 ``"weak"``: 256 objectives PER GPU (``--scaling weak`` makes that one the headline
-instead).  At N = 1 the two coincide.
+instead).  At N = 1 the two coincide, and the line also carries, under ``"config4"``, three
+iterations of BASELINE config 4 (16 density matrices under one 400-dim Liouvillian: the
+cooperative fp64 matrix-core kernels) measured after the headline -- not part of
+``value`` (``--no-config4`` skips it; ``--workload c4`` makes it the line itself).
 """
 import argparse
 import gc
@@ -160,6 +163,9 @@ def main():
                     help='strong (default): --K objectives in total over all GPUs = BASELINE config 5; weak: --K per GPU. '
                          'The other one is measured too and reported under "weak" / "strong" of the same line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-config4', action='store_true',
+                    help='skip the short run of BASELINE config 4 (the one matrix-core workload) that the default '
+                         'single-GPU line carries under "config4"')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the multi-GPU code path (stepwise sweep + RCCL all-reduce per interval) even on 1 rank')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -360,6 +366,25 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+        if world == 1 and args.workload == 'c5' and not args.no_config4 and args.K == 256 and args.N == 64:
+            # BASELINE config 4 (16 density matrices under one 400-dim Liouvillian: the cooperative fp64 MFMA kernels),
+            # three iterations after the headline measurement, in this process (a second process on the GPU while this
+            # one holds its context measured 2x slower): so that the default line -- the one the driver records -- also
+            # carries a number for the one workload whose propagator is a dense product.  Not part of `value`.
+            saved = (args.workload, args.K, args.N, args.nt, args.L, args.steps, args.warmup, args.no_cpu_baseline)
+            try:
+                args.workload, args.steps, args.warmup = 'c4', 3, 1
+                line = measure('strong')
+                out['config4'] = {
+                    'workload': line['config']['workload'], 'ms_per_step': line['ms_per_step'], 'value': line['value'],
+                    'unit': line['unit'], 'steps': line['steps'], 'kernel': line['config']['kernel'],
+                    'roofline': {k: line['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac')},
+                    'kernels': {k: line['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')
+                                if k in line['kernels']}}
+            except Exception as exc:  # (the headline line must not depend on it)
+                out['config4'] = {'error': repr(exc)[:200]}
+            finally:
+                (args.workload, args.K, args.N, args.nt, args.L, args.steps, args.warmup, args.no_cpu_baseline) = saved
         print(json.dumps(out))
     if group is not None:
         torch.distributed.barrier()
