@@ -726,6 +726,8 @@ def _two_rank_spec(case):
         spec = configs.config_c5(K=1100, N=6, nt=13, L=1)  # are refused and every interval is a launch + all-reduce
         spec.chi = 'sm'
         return spec
+    if case == 'c4k25':  # 13 + 12 objectives per rank: two objectives per cooperative workgroup (7 + 6 column groups)
+        return configs.config_c4(d=9, nt=31, n_logical=5)
     return configs.config_c4(d=9, nt=41, n_logical=3)  # N = 81, K = 9 -> 5 + 4 objectives
 
 
@@ -772,7 +774,7 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'k1100'])
+@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'c4k25', 'k1100'])
 def test_two_ranks_sharded_on_one_gpu(case):
     import socket
 
