@@ -85,6 +85,8 @@ SYMBOLS = {
     'kh_debug_occupy': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_double, _P]),
     'kh_series_tables': (ctypes.c_int, [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double)]),
+    'kh_series_tables_defect': (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None

@@ -1265,6 +1265,16 @@ extern "C" int kh_series_tables(int32_t real_spectrum, double tol, double *theta
     return KH_OK;
 }
 
+extern "C" int kh_series_tables_defect(double tol, double theta_cap, double defect, double *theta, double *ratios) {
+    if (theta == nullptr || ratios == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
+    if (!(theta_cap > 0.0) || theta_cap > 4.0 || !(defect >= 0.0))
+        return kh_fail(KH_ERR_INVALID, "theta_cap must be in (0, 4], defect >= 0");
+    if (!(tol > 0.0)) tol = ldexp(1.0, -53);
+    std::vector<double> c0(KH_MAX_DEGREE + 1), rows((size_t)(KH_MAX_DEGREE + 1) * KH_Q2_ROWS * 2);
+    kh_build_real_spectrum_rows(tol, theta, c0.data(), rows.data(), ratios, theta_cap, defect);
+    return KH_OK;
+}
+
 // holds one CU per workgroup (all of its LDS) until `ticks` of the 100 MHz wall clock have passed
 __global__ void __launch_bounds__(512) kh_occupy_kernel(long long ticks, int *sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

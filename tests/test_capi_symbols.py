@@ -102,3 +102,63 @@ def test_series_tables_evaluate_the_exponential():
         # the Taylor polynomial of the same degree is NOT good enough at this norm
         taylor = sum(np.linalg.matrix_power(-1j * A, j) @ v / scipy.special.factorial(j) for j in range(m + 1))
         assert np.linalg.norm(taylor - scipy.linalg.expm(-1j * A) @ v) > 3e-15, m
+
+
+def test_series_tables_with_hermitian_defect():
+    """kh_series_tables_defect (host code, no GPU): the Chebyshev-form tables an engine builds for a generator that is
+    anti-Hermitian only up to a small Hermitian part (weakly damped Liouvillians), up to theta = 4 for the cooperative
+    kernels.  With defect 0 and cap 2 they are the real-spectrum tables; a defect costs at most a little theta per
+    degree; and -- the point -- for a NON-NORMAL matrix A = S + D with S anti-Hermitian, ||S|| = theta[m] (as far as
+    D leaves room) and a Hermitian-part norm within the defect, the degree-m polynomial evaluated the way the
+    kernels do (A^2 chain + one product with A) reproduces expm(A) v to the rounding level Taylor itself reaches
+    there, where the Taylor polynomial of the same degree is far off."""
+    import ctypes
+
+    import numpy as np
+    import scipy.linalg
+
+    lib = _lib.load()
+
+    def tables(cap, defect):
+        th, ra = (ctypes.c_double * 65)(), (ctypes.c_double * (65 * 65))()
+        assert lib.kh_series_tables_defect(0.0, cap, defect, th, ra) == 0
+        return np.array(th), np.array(ra).reshape(65, 65)
+
+    th_ref, ra_ref = (ctypes.c_double * 65)(), (ctypes.c_double * (65 * 65))()
+    assert lib.kh_series_tables(1, 0.0, th_ref, ra_ref) == 0
+    t0, r0 = tables(2.0, 0.0)
+    assert np.array_equal(t0, np.array(th_ref)) and np.array_equal(r0, np.array(ra_ref).reshape(65, 65))
+    assert lib.kh_series_tables_defect(0.0, 5.0, 0.0, th_ref, ra_ref) == -1
+    defect = 3e-3
+    tc, rc = tables(4.0, defect)
+    assert np.all(np.diff(tc) >= 0)
+    even = np.arange(8, 23, 2)
+    t_cap4 = tables(4.0, 0.0)[0]
+    assert np.all(tc[even] <= t_cap4[even]) and np.all(tc[even] > 0.9 * t_cap4[even])  # the margin is small
+    degree = lambda tab, th: int(np.argmax(tab >= th))  # noqa: E731
+    assert degree(tc, 2.7) == 20  # (BASELINE config 4: Taylor needs 24)
+    rng = np.random.default_rng(11)
+    N = 40
+    G = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    S = (G - G.conj().T) / 2
+    S /= np.linalg.norm(S, 2)
+    D = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))  # non-normal perturbation
+    D *= 0.5 * defect / np.linalg.norm((D + D.conj().T) / 2, 2)          # Hermitian part well inside the defect
+    v = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    v /= np.linalg.norm(v)
+    for m in (12, 16, 20, 22):
+        A = S * (tc[m] - np.linalg.norm(D, 2)) + D
+        assert np.linalg.norm(A, 2) <= tc[m] and np.linalg.norm((A + A.conj().T) / 2, 2) <= defect
+        c = np.cumprod(np.concatenate([[rc[m, 0], rc[m, 1] / rc[m, 0]], rc[m, 2:m + 1]]))  # c_0 .. c_m
+        B = A @ A
+        state, term, s = c[0] * v, c[0] * v, c[1] * v
+        for p in range(m // 2):
+            term = (c[2 * p + 2] / c[2 * p]) * (B @ term)
+            state = state + term
+            if 2 * p + 3 <= m:
+                s = s + (c[2 * p + 3] / c[2 * p + 2]) * term
+        state = state + A @ s
+        exact = scipy.linalg.expm(A) @ v
+        assert np.linalg.norm(state - exact) < 4e-15, (m, np.linalg.norm(state - exact))
+        taylor = sum(np.linalg.matrix_power(A, j) @ v / scipy.special.factorial(j) for j in range(m + 1))
+        assert np.linalg.norm(taylor - exact) > 1e-14, m
