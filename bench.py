@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one Krotov iteration of the BASELINE.json headline configuration
-(robustness ensemble: 256 objectives per GPU, Hilbert dimension 64, 4000 time
+(robustness ensemble: 256 objectives IN TOTAL, Hilbert dimension 64, 4000 time
 steps, L=1 control, complex128) through ``krotov_amd.optimize_pulses`` with
 ``propagator=krotov_amd.propagators.expm``: chi construction -> backward sweep
 storing chi(t_n) -> forward sweep with sequential pulse update -> tau, exactly
@@ -12,16 +12,28 @@ the bracket the reference times per iteration (optimize.py:396 -> 510).  Inputs
 are synthetic (``krotov_amd.configs.config_c5``) and resident in HBM before the
 timed region.  One JSON line is printed by rank 0.
 
-For N > 1 the driver launches this file under ``torch.distributed.run``.  The
-headline line is BASELINE config 5 itself: 256 objectives IN TOTAL sharded over the
-N ranks (``"scaling": "strong"``: 256/N per GPU), the L update sums crossing the
-GPUs once per time interval (peer-mapped windows inside the persistent kernels, or
-one RCCL all-reduce).  The same JSON line carries a second measurement under
-``"weak"``: 256 objectives PER GPU (``--scaling weak`` makes that one the headline
-instead).  At N = 1 the two coincide, and the line also carries, under ``"config4"``, three
-iterations of BASELINE config 4 (16 density matrices under one 400-dim Liouvillian: the
-cooperative fp64 matrix-core kernels) measured after the headline -- not part of
-``value`` (``--no-config4`` skips it; ``--workload c4`` makes it the line itself).
+For N > 1 there is one rank per GPU.  Either a launcher provides them
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- plain
+``python bench.py --gpus N`` with no WORLD_SIZE -- this file starts the N ranks
+itself (``torch.distributed.run`` on 127.0.0.1 with a free port) and exits with
+their return code.  The headline line is BASELINE config 5 itself: 256 objectives
+IN TOTAL sharded over the N ranks (``"scaling": "strong"``: 256/N per GPU), the
+L update sums crossing the GPUs once per time interval inside the persistent
+kernels (peer-mapped windows over xGMI).  The same JSON line carries
+* ``"weak"``: 256 objectives PER GPU (``--scaling weak`` makes that one the
+  headline instead),
+* ``"rccl"``: the strong-scaling job again with the north star's transport, one
+  RCCL all-reduce of the L sums per time interval (``KH_P2P=0``; HIP-graph replay
+  of the interval loop), a few iterations,
+* ``"n_ranks_seen"``: ``torch.distributed.get_world_size()``.
+At N = 1 the line carries instead, measured after the headline and not part of
+``value``: ``"config4"`` (three iterations of BASELINE config 4, 16 density
+matrices under one 400-dim Liouvillian: the cooperative fp64 matrix-core
+kernels; ``--no-config4`` skips it, ``--workload c4`` makes it the line itself)
+and the two variants SURVEY.md 8d asks for, ``"L4"`` (four controls) and
+``"distinct"`` (256 distinct random drifts), three iterations each
+(``--no-variants`` skips them).
 """
 import argparse
 import gc
@@ -96,7 +108,7 @@ def cpu_baseline(args):
     pilots = {}
     for P in candidates:
         K_p = min(args.K, 2 * P)
-        rp = cb.timed_iteration(configs.config_c5(K=K_p, N=args.N, nt=31, L=args.L, distinct=args.distinct), processes=P)
+        rp = cb.timed_iteration(configs.config_c5(K=K_p, N=args.N, nt=121, L=args.L, distinct=args.distinct), processes=P)
         pilots[P] = rp['props'] / rp['seconds']
     P = max(pilots, key=pilots.get)
     K_s = min(args.K, 2 * P)
@@ -114,6 +126,10 @@ def cpu_baseline(args):
                   '(dt unchanged), NumPy oracle in reference-structured mode: dense expm per objective per '
                   'step (SciPy if present), 1 BLAS thread per process, %d processes; %.1f s' % (
                       K_s, nt_s, r['processes'], r['seconds']),
+        'backward_seconds': r['backward_seconds'],
+        'update_seconds': r['update_seconds'],
+        'backward_props_per_s': 0.5 * r['props'] / r['backward_seconds'],
+        'update_props_per_s': 0.5 * r['props'] / r['update_seconds'],
         'seconds_per_prop_single_core': t_prop,
         'seconds_per_prop_in_the_sample': r['seconds'] * r['processes'] / r['props'],
         'host_cores_visible': cores,
@@ -122,7 +138,8 @@ def cpu_baseline(args):
         'expm': 'scipy.linalg.expm %s' % _scipy_version() if _scipy_version() else "oracle's own Pade-13 (NumPy)",
         'note': 'per-core cost in the sample vs alone: what P processes sharing the memory system and one '
                 'synchronisation per time interval (the reference\'s parallel_map_fw_prop_step structure) cost on '
-                'top of the arithmetic; scripts/cpu_probe.py prints the pieces on the box',
+                'top of the arithmetic (backward_props_per_s: the sweep with no per-interval synchronisation; '
+                'update_props_per_s: the one with it); scripts/cpu_probe.py prints the pieces on the box',
     }
 
 
@@ -143,6 +160,23 @@ def _scipy_version():
         return scipy.__version__
     except Exception:
         return None
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: run this very command line under
+    ``torch.distributed.run`` (one rank per GPU, rendezvous on 127.0.0.1, a free port) and return its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -166,6 +200,10 @@ def main():
     ap.add_argument('--no-config4', action='store_true',
                     help='skip the short run of BASELINE config 4 (the one matrix-core workload) that the default '
                          'single-GPU line carries under "config4"')
+    ap.add_argument('--no-variants', action='store_true',
+                    help='skip the short L=4 and distinct-drift runs the default single-GPU line carries under "L4" / "distinct"')
+    ap.add_argument('--no-rccl-leg', action='store_true',
+                    help='multi-rank runs: skip the extra measurement with one RCCL all-reduce per time interval ("rccl")')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the multi-GPU code path (stepwise sweep + RCCL all-reduce per interval) even on 1 rank')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -178,10 +216,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    local_rank = local_rank % max(1, torch.cuda.device_count())  # (testing: several ranks on one GPU)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # no launcher: start one rank per GPU ourselves and hand their verdict on (rank 0 prints the JSON line)
+        sys.exit(self_launch(args.gpus))
+    if world != args.gpus and rank == 0:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d; measuring on %d rank(s)' % (args.gpus, world, world),
+              file=sys.stderr)
+    n_dev = max(1, torch.cuda.device_count())
+    local_rank = local_rank % n_dev  # (testing: several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1 or args.force_dist:
@@ -194,7 +236,9 @@ def main():
             os.environ.setdefault('WORLD_SIZE', '1')
 
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        backend = os.environ.get('KH_DIST_BACKEND', 'nccl')  # 'gloo' only for single-GPU testing
+        # RCCL refuses two ranks on one device: with fewer GPUs than ranks (a test set-up) the host-side
+        # collectives go through gloo; the in-kernel peer windows do not care
+        backend = os.environ.get('KH_DIST_BACKEND', 'nccl' if n_dev >= world else 'gloo')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
@@ -312,7 +356,7 @@ def main():
                     'parallelism': 'objectives sharded over %d GPU(s); per time step the L update sums cross the '
                                    'GPUs %s' % (world, 'inside the persistent kernel (peer-mapped windows over xGMI)'
                                                 if getattr(eng, '_p2p_used', False) else
-                                                ('by one RCCL all-reduce' if world > 1 or args.force_dist else '(single GPU: in-kernel exchange)')),
+                                                ('by one %s all-reduce per time step' % ('RCCL' if torch.distributed.get_backend(group) == 'nccl' else torch.distributed.get_backend(group) + ' (test set-up: fewer GPUs than ranks)') if group is not None else '(single GPU: in-kernel exchange)')),
                     'kernel': eng.kernel,
                 },
                 'roofline': {
@@ -354,38 +398,74 @@ def main():
             return out
         return None
 
+    def leg(scaling='strong', env=None, **overrides):
+        """A short extra measurement in this process with some arguments (and environment switches) changed;
+        everything is put back afterwards.  Returns the reduced record that goes into the headline line."""
+        saved = {k: getattr(args, k) for k in ('workload', 'K', 'N', 'nt', 'L', 'distinct', 'steps', 'warmup',
+                                                'no_cpu_baseline')}
+        saved_env = {k: os.environ.get(k) for k in (env or {})}
+        try:
+            for k, v in overrides.items():
+                setattr(args, k, v)
+            os.environ.update(env or {})
+            line = measure(scaling)
+            if line is None:
+                return None
+            rec = {
+                'workload': line['config']['workload'], 'ms_per_step': line['ms_per_step'], 'value': line['value'],
+                'unit': line['unit'], 'steps': line['steps'], 'kernel': line['config']['kernel'],
+                'parallelism': line['config']['parallelism'],
+                'roofline': {k: line['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac')},
+                'kernels': {k: line['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')
+                            if k in line['kernels']}}
+            return rec
+        except Exception as exc:  # (the headline line must not depend on a side measurement)
+            if world > 1:
+                raise  # ... but ranks must not part ways
+            return {'error': repr(exc)[:200]}
+        finally:
+            for k, v in saved.items():
+                setattr(args, k, v)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
     other = 'weak' if args.scaling == 'strong' else 'strong'
     out = measure(args.scaling)
     second = measure(other) if world > 1 and args.workload == 'c5' else None
+    rccl = None
+    if (world > 1 or args.force_dist) and args.workload == 'c5' and not args.no_rccl_leg:
+        # the north star's transport: one RCCL all-reduce of the L update sums per time interval (kh_update_begin /
+        # step_dev / end with HIP-graph replay) instead of the peer windows inside the persistent kernel
+        rccl = leg('strong', env={'KH_P2P': '0'}, steps=min(args.steps, 3), warmup=1)
     if rank == 0:
+        out['n_ranks_seen'] = torch.distributed.get_world_size() if group is not None else 1
         if second is not None:
             # the same job with the other partitioning of the objectives (see the module docstring)
             out[other] = {k: second[k] for k in ('value', 'unit', 'iterations_per_sec', 'ms_per_step', 'scaling')}
             out[other]['objectives'] = second['config']['objectives']
             out[other]['kernels'] = {k: second['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')}
+        if rccl is not None:
+            out['rccl'] = rccl
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
-        if world == 1 and args.workload == 'c5' and not args.no_config4 and args.K == 256 and args.N == 64:
+    headline_shape = args.workload == 'c5' and args.K == 256 and args.N == 64 and args.L == 1 and not args.distinct
+    if world == 1 and group is None and headline_shape:
+        if not args.no_config4:
             # BASELINE config 4 (16 density matrices under one 400-dim Liouvillian: the cooperative fp64 MFMA kernels),
             # three iterations after the headline measurement, in this process (a second process on the GPU while this
             # one holds its context measured 2x slower): so that the default line -- the one the driver records -- also
             # carries a number for the one workload whose propagator is a dense product.  Not part of `value`.
-            saved = (args.workload, args.K, args.N, args.nt, args.L, args.steps, args.warmup, args.no_cpu_baseline)
-            try:
-                args.workload, args.steps, args.warmup = 'c4', 3, 1
-                line = measure('strong')
-                out['config4'] = {
-                    'workload': line['config']['workload'], 'ms_per_step': line['ms_per_step'], 'value': line['value'],
-                    'unit': line['unit'], 'steps': line['steps'], 'kernel': line['config']['kernel'],
-                    'roofline': {k: line['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac')},
-                    'kernels': {k: line['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')
-                                if k in line['kernels']}}
-            except Exception as exc:  # (the headline line must not depend on it)
-                out['config4'] = {'error': repr(exc)[:200]}
-            finally:
-                (args.workload, args.K, args.N, args.nt, args.L, args.steps, args.warmup, args.no_cpu_baseline) = saved
-        print(json.dumps(out))
+            out['config4'] = leg(workload='c4', steps=3, warmup=1)
+        if not args.no_variants:
+            # SURVEY.md 8d: "L=1 (also report L=4)" and "a second variant with K distinct random H0_k"
+            out['L4'] = leg(L=4, steps=3, warmup=1)
+            out['distinct'] = leg(distinct=True, steps=3, warmup=1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if group is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -12,7 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libkrotov_hip.so')
 
 KH_OK = 0
+KH_ERR_INVALID = -1
+KH_ERR_HIP = -2
+KH_ERR_UNSUPPORTED = -3
 KH_ERR_TIMEOUT = -4
+KH_ERR_NOMEM = -5
 
 
 class kh_problem(ctypes.Structure):
@@ -120,10 +124,14 @@ def load():
 
 
 class KrotovHipError(RuntimeError):
-    pass
+    """An entry point of libkrotov_hip.so returned ``code`` (one of the ``KH_ERR_*`` values)."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
 
 
 def check(rc):
     if rc != KH_OK:
         msg = load().kh_last_error().decode('utf-8', 'replace')
-        raise KrotovHipError("libkrotov_hip error %d: %s" % (rc, msg))
+        raise KrotovHipError("libkrotov_hip error %d: %s" % (rc, msg), rc)

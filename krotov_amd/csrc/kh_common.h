@@ -195,10 +195,24 @@ __host__ inline void kh_bessel_j(double theta, int kmax, long double *J) {
 // anyway; 4 for the cooperative kernels, where a term costs a cross-workgroup round -- measured on the 400-dim
 // Liouvillian of config 4: the power form still reaches 2e-15 at theta = 4, like Taylor's, with degree 22 instead of 30).
 // delta > 0: the generator f A h is only NEARLY anti-Hermitian -- its Hermitian part is bounded by delta (a weakly
-// damped Liouvillian: 3e-4 against theta = 2.6 in config 4).  Its numerical range then lies in the rectangle
-// [-delta, delta] x i [-theta, theta], inside the ellipse with foci +- i theta through delta, where
-// |T_k| <= cosh(k asinh(delta / theta)); with Crouzeix's constant 1 + sqrt 2 for non-normal matrices the error is at
-// most (1 + sqrt 2) 2 sum_{k > m} |J_k(theta)| cosh(k asinh(delta / theta)).
+// damped Liouvillian: 3e-4 against theta = 2.6 in config 4).  Its numerical range then lies in the strip
+// |Re z| <= delta intersected with the disk |z| <= theta; in the variable w = z / (i theta) of the Chebyshev series
+// that is {|Im w| <= d, |w| <= 1}, d = delta / theta, whose points farthest from the segment [-1, 1] -- in the
+// sense of the Bernstein ellipses with foci +-1 -- are the corners w* = sqrt(1 - d^2) +- i d (on the arc the sum of
+// the distances to the foci, 2 sin(phi/2) + 2 cos(phi/2), grows with phi; on the flat edges it is convex and even).
+// On the ellipse through w*,  |T_k| <= cosh(k eta)  with  eta = log |w* + sqrt(w*^2 - 1)| ~ sqrt(d)  (NOT
+// asinh(d) ~ d, the semi-minor axis alone: an earlier version used that and was ~5x over the tolerance at
+// delta = 0.05), and with Crouzeix's constant 1 + sqrt 2 for non-normal matrices the error is at most
+// (1 + sqrt 2) 2 sum_{k > m} |J_k(theta)| cosh(k eta).
+__host__ inline long double kh_bernstein_eta(long double d) {
+    // w = a + i d, a = sqrt(1 - d^2);  w^2 - 1 = -2 d^2 + 2 i a d;  principal square root by hand (long double)
+    const long double a = sqrtl(fmaxl(0.0L, 1.0L - d * d));
+    const long double xr = -2.0L * d * d, xi = 2.0L * a * d;
+    const long double r = sqrtl(xr * xr + xi * xi);
+    const long double sr = sqrtl(fmaxl(0.0L, 0.5L * (r + xr))), si = sqrtl(fmaxl(0.0L, 0.5L * (r - xr)));  // (xi >= 0)
+    const long double p = hypotl(a + sr, d + si), q = hypotl(a - sr, d - si);
+    return logl(p > q ? p : q);
+}
 __host__ inline void kh_build_real_spectrum_rows(double tol, double *tab /*[KH_MAX_DEGREE+1]*/, double *c0, double *rows,
                                                  double *ratios, double theta_cap = 2.0, double delta = 0.0) {
     const int TAIL = 40;
@@ -207,7 +221,8 @@ __host__ inline void kh_build_real_spectrum_rows(double tol, double *tab /*[KH_M
         kh_bessel_j(theta, m + TAIL, J);
         long double e = 0.0L;
         if (delta > 0.0) {
-            const long double eta = asinhl((long double)delta / (long double)theta);
+            const long double d = (long double)delta / (long double)theta;
+            const long double eta = d < 1.0L ? kh_bernstein_eta(d) : 1e3L;  // (d >= 1: no such form; the bound fails)
             for (int k = m + 1; k <= m + TAIL; ++k) e += fabsl(J[k]) * coshl(k * eta);
             return (double)(2.0L * (1.0L + sqrtl(2.0L)) * e);
         }
@@ -420,52 +435,6 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
         }
         out[l] = (l < L) ? sum64(acc) : 0.0;
     }
-    return true;
-}
-
-// The gather for ONE control, spread over the WAVES waves of the workgroup and split in two halves: every wave
-// takes 256 / WAVES slots, one slot (two granules) per lane.  kh_gather_part_begin issues the loads -- they are in
-// flight while the caller does other work -- and kh_gather_part_end checks them, polls on if a producer was late,
-// and returns the wave's partial sum (lanes in a fixed order).  The caller adds the WAVES partial sums in wave
-// order after a barrier, so every workgroup derives the bit-identical total.  At most 256 workgroups.
-struct KhGatherPart {
-    kh_u64 a, b;
-};
-template <int WAVES>
-__device__ __forceinline__ void kh_gather_part_begin(const KhExchange &ex, int parity, unsigned int epoch, int wave,
-                                                     int lane, KhGatherPart &g) {
-    constexpr int SPW = 256 / WAVES;
-    const kh_u64 *base = ex.slots + (size_t)parity * ex.G * 2;
-    const int wg = wave * SPW + lane;
-    const bool live = lane < SPW && wg < ex.G;
-    const int wgc = live ? wg : 0;  // (branch-free: idle lanes re-read slot 0 and substitute the neutral granule)
-    const kh_u64 va = __hip_atomic_load(base + (size_t)wgc * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const kh_u64 vb = __hip_atomic_load(base + (size_t)wgc * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    g.a = live ? va : (kh_u64)epoch << 32;
-    g.b = live ? vb : (kh_u64)epoch << 32;
-}
-template <int WAVES>
-__device__ __forceinline__ bool kh_gather_part_end(const KhExchange &ex, int parity, unsigned int epoch, int wave, int lane,
-                                                   KhGatherPart g, double *partial) {
-    const long long t0 = wall_clock64();
-    unsigned int spins = 0;
-    for (;;) {
-        const bool ok = ((unsigned int)(g.a >> 32) == epoch) && ((unsigned int)(g.b >> 32) == epoch);
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 255u) == 0) {  // wave-uniform
-            const bool gave_up =
-                (wall_clock64() - t0 > ex.timeout_ticks) ||
-                (__hip_atomic_load(ex.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
-            if (__any(gave_up)) {
-                if (lane == 0) __hip_atomic_store(ex.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-        kh_gather_part_begin<WAVES>(ex, parity, epoch, wave, lane, g);
-    }
-    const kh_u64 bits = ((g.a & 0xffffffffull) << 32) | (g.b & 0xffffffffull);
-    *partial = sum64(__longlong_as_double((long long)bits));  // (idle lanes hold +0.0)
     return true;
 }
 

@@ -460,13 +460,17 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     long long t_ex = 0, t_prop = 0, t_part = 0;
     const long long t_all0 = clock64();
 #endif
-    for (int nr = u.n_begin; nr < u.n_end; nr += KH_Q2_REFRESH) {
+    for (int nr = u.n_begin, n_stop; nr < u.n_end; nr = n_stop) {
     // restart A = H0, B = P0 from global memory (outside the interval loop: the loop body keeps one definition of
-    // the tiles, which the register allocator needs to keep them in place)
+    // the tiles, which the register allocator needs to keep them in place).  Restart points are ABSOLUTE interval
+    // indices (multiples of KH_Q2_REFRESH, plus the launch's first interval), so a sweep cut into several launches
+    // restarts where the single launch does.  Rounding: an advanced tile carries an absolute error of a few
+    // ulp(max |eps|^2 |P2|) over the window -- relative to the LARGEST pulse value of the window, not the current one.
     kh_q2_load_tile(ops_k[0], N, wave, lane, a);
     kh_q2_load_tile(sq_k[0], N, wave, lane, b);
     eps_prev = 0.0;
-    const int n_stop = nr + KH_Q2_REFRESH < u.n_end ? nr + KH_Q2_REFRESH : u.n_end;
+    n_stop = (nr / KH_Q2_REFRESH + 1) * KH_Q2_REFRESH;
+    n_stop = n_stop < u.n_end ? n_stop : u.n_end;
     for (int n = nr; n < n_stop; ++n) {
         const int par = n & 1;
         if constexpr (!ADJ) {

@@ -22,7 +22,6 @@
 #include "kh_generic.h"
 #include "kh_tile64.h"
 #include "kh_tile64q2.h"
-#include "kh_tile64mm.h"
 #include "kh_coop.h"
 #include "kh_mini.h"
 
@@ -106,10 +105,6 @@ struct kh_engine {
     double imag_defect = -1.0;   // >= 0: bound on the Hermitian part of f A dt when the controls' f H_l are exactly
                                  // anti-Hermitian (|| . ||_F of the drift's part x max dt); < 0: not of that kind
     bool coop_series = false;    // the cooperative kernels run the Chebyshev-form series (kh_common.h)
-    bool hermitian = false;      // the same, whichever series tables are in use (KH_TAYLOR): kh_tile64mm.h
-    int mm_nio = 2;              // 4-row blocks per wave of that kernel: 2 -> 8 waves (KH_MM_WAVES=4: 4 -> 4 waves)
-    bool use_mm = false;         // KH_MM=1: the matrix-core update kernel (kh_tile64mm.h) instead of the vector-FMA one
-    double *d_mm_tab = nullptr;  // [KH_MAX_DEGREE+1][KH_MM_TAB_STRIDE] coefficient rows of the two-chain form
     bool stepwise_only = false;  // more objectives than can be co-resident: kh_forward_update runs one launch per interval
     double *d_step_partial = nullptr;  // [L] the interval's sums on that path
     bool mini = false;           // kind q2, N <= 16, K <= 8: the one-wave-per-objective kernels (kh_mini.h)
@@ -135,10 +130,7 @@ static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
 // partial start, which the bounded in-kernel waits turn into KH_ERR_TIMEOUT and the caller into a repeat of the
 // sweep with one launch per interval (krotov_amd/optimize.py).
 // KH_COOP_LAUNCH=0 keeps plain launches (A/B timing: a cooperative launch costs ~15-20 us of host time).
-static bool g_coop_launch = [] {
-    const char *d = getenv("KH_COOP_LAUNCH");
-    return d == nullptr || atoi(d) != 0;
-}();
+static bool g_coop_launch = true;  // (re-read from the environment by every kh_engine_create)
 
 template <class... Params, class... Args>
 static int launch_persistent(void (*kernel)(Params...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
@@ -229,7 +221,6 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_q2_c0);
     (void)hipFree(e->d_q2_rows);
     (void)hipFree(e->d_ratios);
-    (void)hipFree(e->d_mm_tab);
     (void)hipFree(e->d_csr_fw);
     (void)hipFree(e->d_csr_bw);
     (void)hipFree((void *)e->d_coop_fops_fw);
@@ -337,7 +328,6 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         e->adj_sign = flags[0] == 0 ? 1.0 : (flags[1] == 0 ? -1.0 : 0.0);
         // every generator Hermitian and f = -+i: real spectrum (the q2 kernels' shorter series, kh_common.h)
         e->real_spectrum = flags[0] == 0 && flags[2] == 0 && !e->is_super;
-        e->hermitian = e->real_spectrum;
         {   // f A anti-Hermitian up to a small Hermitian part of the drift (a weakly damped Liouvillian; a Hamiltonian
             // with a small anti-Hermitian part): the shorter series of kh_common.h applies with a margin
             const bool controls_ok = e->is_super ? flags[1] == 0 : flags[0] == 0;
@@ -358,7 +348,6 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                 e->imag_defect = sqrt(fro2) * dt_max;
             }
         }
-        if (const char *d = getenv("KH_MM")) e->use_mm = atoi(d) != 0;
         if (const char *d = getenv("KH_TAYLOR"))  // A/B switch: plain Taylor coefficients everywhere
             if (atoi(d) != 0) {
                 e->real_spectrum = false;
@@ -394,6 +383,10 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     e->kind = KIND_GENERIC;
     const int max_wgs = e->num_cus < 64 * KH_GATHER_CHUNKS ? e->num_cus : 64 * KH_GATHER_CHUNKS;
     e->grid_update = e->K < max_wgs ? e->K : max_wgs;
+    {
+        const char *d = getenv("KH_COOP_LAUNCH");
+        g_coop_launch = d == nullptr || atoi(d) != 0;
+    }
     if (const char *d = getenv("KH_POLL_DELAY")) e->poll_delay = atoi(d);
     if (const char *d = getenv("KH_ADJ_DELAY")) e->adj_poll_delay = atoi(d);
     if (const char *d = getenv("KH_COOP_DELAY")) e->coop_poll_delay = atoi(d);
@@ -600,17 +593,6 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         KH_HIP_E(hipMemcpy(e->d_q2_theta, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
         KH_HIP_E(hipMemcpy(e->d_q2_c0, c0.data(), sizeof(double) * c0.size(), hipMemcpyHostToDevice));
         KH_HIP_E(hipMemcpy(e->d_q2_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
-        if (e->kind == KIND_TILE_Q2 && e->hermitian) {
-            std::vector<double> mm((size_t)(KH_MAX_DEGREE + 1) * KH_MM_TAB_STRIDE);
-            kh_build_mm_tab(c0.data(), rows.data(), mm.data());
-            KH_HIP_E(hipMalloc(&e->d_mm_tab, sizeof(double) * mm.size()));
-            KH_HIP_E(hipMemcpy(e->d_mm_tab, mm.data(), sizeof(double) * mm.size(), hipMemcpyHostToDevice));
-            KH_HIP_E(hipFuncSetAttribute((const void *)kh_mm_forward_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)kh_mm_lds_bytes()));
-            KH_HIP_E(hipFuncSetAttribute((const void *)kh_mm_forward_update<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)kh_mm_lds_bytes()));
-            if (const char *d = getenv("KH_MM_WAVES")) e->mm_nio = atoi(d) == 4 ? 4 : 2;
-        }
     }
     if (e->kind == KIND_TILE_Q2) {
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -743,6 +725,21 @@ static KhCoopArgs coop_args(const kh_engine *e, bool backward) {
     return c;
 }
 
+// The cooperative kernels are launched with one column group per XCD where that is possible: a one-dimensional
+// grid of 8 G blocks of which only G Y do anything (kh_coop_place).  The cooperative-launch validation counts all
+// 8 G of them, so on a device (or partition, or CU mask) with fewer resident workgroups than that the launch is
+// refused although the G Y real ones would fit: the placement is then given up for good (two-dimensional (G, Y)
+// grid, memory-side exchange) and the launch repeated.
+template <class Launch>
+static int launch_coop_placed(kh_engine *e, Launch &&launch) {
+    int rc = launch(e->coop_xcd ? dim3(8 * e->coop_G) : dim3(e->coop_G, e->coop_Y));
+    if (rc == KH_ERR_UNSUPPORTED && e->coop_xcd) {
+        e->coop_xcd = false;
+        rc = launch(dim3(e->coop_G, e->coop_Y));
+    }
+    return rc;
+}
+
 template <int MAXKS, int COLS>
 static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
                              cplx *out, int direction, hipStream_t st) {
@@ -750,9 +747,10 @@ static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *p
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
-    return launch_persistent(kh_coop_sweep_store<MAXKS, COLS>, e->coop_xcd ? dim3(8 * e->coop_G) : dim3(e->coop_G, e->coop_Y), dim3(KH_COOP_THREADS),
-                             kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, direction < 0), exchange_args(e, true), pulses,
-                             in, store, out, direction);
+    return launch_coop_placed(e, [&](dim3 grid) {
+        return launch_persistent(kh_coop_sweep_store<MAXKS, COLS>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
+                                 coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
+    });
 }
 
 template <int MAXKS, int COLS>
@@ -764,10 +762,11 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
-    const dim3 grid = e->coop_xcd ? dim3(8 * e->coop_G) : dim3(e->coop_G, e->coop_Y);
-    if (u.sigma != nullptr)
-        return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
-    return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
+    return launch_coop_placed(e, [&](dim3 grid) {
+        if (u.sigma != nullptr)
+            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
+        return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
+    });
 }
 
 static int sweep_store(kh_engine *e, bool backward, const double *pulses, const cplx *in, cplx *store, cplx *out,
@@ -797,6 +796,12 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         else
             rc = e->coop_ks <= 8 ? launch_coop_store<8, 16>(e, p, pulses, in, store, out, direction, st)
                                  : launch_coop_store<16, 16>(e, p, pulses, in, store, out, direction, st);
+        if (rc == KH_ERR_UNSUPPORTED) {
+            // not even the G x Y grid can be resident at once (fewer CUs than expected): the plain sweeps need no
+            // cross-workgroup exchange at all, so the per-objective generic kernel takes them over from here on
+            e->kind_store = KIND_GENERIC;
+            return sweep_store(e, backward, pulses, in, store, out, st);
+        }
     } else {
         const size_t lds = kh_gen_lds_bytes(e->N);
         rc = ensure_dynamic_lds(e, (const void *)kh_gen_sweep_store, lds);
@@ -882,16 +887,6 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             kh_mini_forward_update<true><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
         else
             kh_mini_forward_update<false><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
-    } else if (e->kind == KIND_TILE_Q2 && !stepwise && u.sigma == nullptr && u.adj_sign == 1.0 && e->hermitian && p.fre == 0.0 && p.fim == -1.0 &&
-               e->use_mm && e->d_mm_tab != nullptr && u.n_begin == 0 && u.n_end == e->nt - 1) {
-        // first order, Hermitian operators: matrix-core kernel with the exchange hidden behind half the series
-        KhExchange exa = ex;
-        exa.first_poll_delay = e->adj_poll_delay;
-        const double *tab = e->d_mm_tab;
-        if (e->mm_nio == 2)
-            rc = launch_persistent(kh_mm_forward_update<2>, dim3(e->K), dim3(KhMm<2>::THREADS), kh_mm_lds_bytes(), st, p, e->d_sq_fw, u, exa, tab);
-        else
-            rc = launch_persistent(kh_mm_forward_update<4>, dim3(e->K), dim3(KhMm<4>::THREADS), kh_mm_lds_bytes(), st, p, e->d_sq_fw, u, exa, tab);
     } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
         const dim3 g(e->K), b(KH_Q2_THREADS);
         if (u.sigma != nullptr)

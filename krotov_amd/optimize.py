@@ -46,6 +46,7 @@ from .conversions import (
     pulse_options_dict_to_list,
 )
 from ._lib import KrotovHipError as _KrotovHipError
+from ._lib import KH_ERR_TIMEOUT as _KH_ERR_TIMEOUT, KH_ERR_UNSUPPORTED as _KH_ERR_UNSUPPORTED
 from .info_hooks import chain
 from .mu import derivative_wrt_pulse
 from .parallelization import serial_map
@@ -507,6 +508,8 @@ class _HipBackend:
         self.last_chi = None
         # device-side exchange over peer-mapped windows (xGMI) when every rank can set it up;
         # otherwise (or after a failed sweep) one RCCL all-reduce per interval
+        self._single_launch_ok = True  # (one GPU) until the single-launch update sweep has failed for good
+        self._single_launch_failures = 0
         self.p2p = False
         if self.world > 1 and os.environ.get('KH_P2P', '1') != '0':
             self.p2p = self.engine.enable_p2p(self.group)
@@ -579,16 +582,27 @@ class _HipBackend:
         lambdas = eng.dev(np.asarray(lambda_vals, dtype=np.float64), t.float64)
         done = False
         if self.group is None:
-            try:
-                opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
-                eng.check()
-                done = True
-            except _KrotovHipError as exc:
-                # the single-launch sweep needs all its workgroups resident at once; if the GPU could not give it that
-                # (CUs held by another stream or process: its in-kernel exchange times out), redo the sweep interval by
-                # interval -- one launch each, nothing waits inside a kernel -- like the sharded path does
-                logging.getLogger('krotov').warning(
-                    "single-launch update sweep failed (%s); repeating it with one launch per interval", exc)
+            if self._single_launch_ok:
+                try:
+                    opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
+                    eng.check()
+                    done = True
+                    self._single_launch_failures = 0
+                except _KrotovHipError as exc:
+                    # the single-launch sweep needs all its workgroups resident at once; if the GPU could not give it
+                    # that (CUs held by another stream or process: its in-kernel exchange times out; or the device
+                    # cannot hold the grid at all), redo the sweep interval by interval -- one launch each, nothing
+                    # waits inside a kernel -- like the sharded path does.  Anything else is a real error.
+                    if exc.code not in (_KH_ERR_TIMEOUT, _KH_ERR_UNSUPPORTED):
+                        raise
+                    self._single_launch_failures += 1
+                    # "cannot be resident" will not change; a co-tenant may go away, but not after three sweeps in a row
+                    if exc.code == _KH_ERR_UNSUPPORTED or self._single_launch_failures >= 3:
+                        self._single_launch_ok = False
+                    logging.getLogger('krotov').warning(
+                        "single-launch update sweep failed (%s); repeating it with one launch per interval%s", exc,
+                        "" if self._single_launch_ok else " (and staying with that form)")
+            if not done:
                 opt, psi_T, g_a = eng.forward_update_sharded(
                     self.chi_store, norms_loc, self.init, guess, shapes, lambdas, lambda x: None, graph_chunk=0)
                 done = True

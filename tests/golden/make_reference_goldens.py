@@ -20,7 +20,7 @@ B. ``ref``     -- the reference's real ``krotov.optimize_pulses`` loop executed
    replaced by empty stub modules (they are not installed), on the seeded
    synthetic inputs of ``krotov_amd.configs``.  Outputs: all pulses, tau_vals.
 
-Usage:  python tests/golden/make_reference_goldens.py [dumps] [ref] [c5full] [second_order]
+Usage:  python tests/golden/make_reference_goldens.py [dumps] [ref] [c5full] [c4full] [second_order]
 
 The reference is BSD-3-Clause (c) 2018-2024 Michael Goerz et al.; the fixtures
 derived from its shipped data keep that attribution (tests/golden/README.md).
@@ -483,6 +483,18 @@ def make_c5_full():
     print('ref_c5_full: %.0fs' % out['seconds'])
 
 
+def make_c4_full():
+    """BASELINE config 4 at full size (16 density matrices, 400-dim Liouvillian,
+    1000 intervals) through the real reference loop: 1 iteration = 3 sweeps *
+    16 * 1000 dense 400x400 ``expm`` (~80 ms each on one core)."""
+    from krotov_amd import configs
+
+    spec = configs.config_c4()
+    out = run_reference(spec, 1)
+    np.savez_compressed(os.path.join(HERE, 'ref_c4_full.npz'), iter_stop=1, **out)
+    print('ref_c4_full: %.0fs' % out['seconds'])
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['dumps', 'ref']
     if 'dumps' in what:
@@ -491,6 +503,8 @@ if __name__ == '__main__':
         make_ref_fixtures()
     if 'c5full' in what:
         make_c5_full()
+    if 'c4full' in what:
+        make_c4_full()
     if 'second_order' in what:
         make_second_order()
     if 'print_table' in what:

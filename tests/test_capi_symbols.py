@@ -134,7 +134,7 @@ def test_series_tables_with_hermitian_defect():
     assert np.all(np.diff(tc) >= 0)
     even = np.arange(8, 23, 2)
     t_cap4 = tables(4.0, 0.0)[0]
-    assert np.all(tc[even] <= t_cap4[even]) and np.all(tc[even] > 0.9 * t_cap4[even])  # the margin is small
+    assert np.all(tc[even] <= t_cap4[even]) and np.all(tc[even] > 0.8 * t_cap4[even])  # the margin is small (eta ~ sqrt(defect / theta))
     degree = lambda tab, th: int(np.argmax(tab >= th))  # noqa: E731
     assert degree(tc, 2.7) == 20  # (BASELINE config 4: Taylor needs 24)
     rng = np.random.default_rng(11)
@@ -162,3 +162,49 @@ def test_series_tables_with_hermitian_defect():
         assert np.linalg.norm(state - exact) < 4e-15, (m, np.linalg.norm(state - exact))
         taylor = sum(np.linalg.matrix_power(A, j) @ v / scipy.special.factorial(j) for j in range(m + 1))
         assert np.linalg.norm(taylor - exact) > 1e-14, m
+
+
+def test_series_tables_defect_bound_at_the_corner_of_the_numerical_range():
+    """The truncation bound behind kh_series_tables_defect must hold at the point of the admissible numerical range
+    that is farthest from the imaginary segment: z = -delta - i sqrt(theta^2 - delta^2), an eigenvalue of a NORMAL
+    (diagonal) generator with |z| = theta and Re z = -delta.  At the largest admitted defect (0.05) the scalar
+    polynomial of every even degree must reproduce exp(z) to the tolerance the tables were built for (2^-53 x a
+    small factor for the rounding of the evaluation itself).  (An earlier bound -- the ellipse through the
+    semi-minor axis delta alone -- was ~5x over at this point.)"""
+    import ctypes
+
+    import numpy as np
+
+    lib = _lib.load()
+    for cap in (2.0, 4.0):
+        for defect in (0.05, 5e-3, 3e-4):
+            th, ra = (ctypes.c_double * 65)(), (ctypes.c_double * (65 * 65))()
+            assert lib.kh_series_tables_defect(0.0, cap, defect, th, ra) == 0
+            th, ra = np.array(th), np.array(ra).reshape(65, 65)
+            checked = 0
+            for m in range(4, 41, 2):
+                theta = th[m]
+                if not (defect < theta < cap) or theta <= th[m - 2]:
+                    continue  # (degree not served by the Chebyshev form at this cap, or no room for the defect)
+                c = np.cumprod(np.concatenate([[ra[m, 0], ra[m, 1] / ra[m, 0]], ra[m, 2:m + 1]])).astype(np.longdouble)
+                z = np.clongdouble(complex(-defect, -np.sqrt(theta * theta - defect * defect)))
+                poly = sum(c[j] * z ** j for j in range(m + 1))
+                exact = np.exp(z)
+                err = abs(complex(poly - exact))
+                # (a) the mathematics behind the threshold theta[m]: truncation error of the Chebyshev series of
+                # exp(-i theta x) at x = i z / theta, independent of the tabulated power-form coefficients
+                import scipy.special
+
+                x = np.clongdouble(1j) * z / np.longdouble(theta)
+                T_prev, T_cur = np.clongdouble(1.0), x
+                series = np.clongdouble(scipy.special.jv(0, theta))
+                for k in range(1, m + 1):
+                    series += 2 * np.clongdouble((-1j) ** k) * np.longdouble(scipy.special.jv(k, theta)) * T_cur
+                    T_prev, T_cur = T_cur, 2 * x * T_cur - T_prev
+                trunc = abs(complex(series - exact))
+                assert trunc < 4.0 * 2.0 ** -53, (cap, defect, m, theta, trunc)  # (jv is double precision: ~2e-16 of noise)
+                # (b) the tabulated polynomial itself: truncation + the rounding of its double-precision coefficient
+                # ratios, which grows like e^theta in the power form (DESIGN 3.1: the reason for the caps)
+                assert err < 2.0 ** -53 * (2.0 + 0.5 * np.exp(theta)), (cap, defect, m, theta, err)
+                checked += 1
+            assert checked >= 3, (cap, defect)
