@@ -937,7 +937,8 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
                                                        cplx &state, unsigned int &rid, KhCoopLds &s, int N, int y,
                                                        int g, int row, int col, bool owner_valid, double fre,
                                                        double fim, double dt, int nsub, int m, int tid, int wave,
-                                                       int lane) {
+                                                       int lane, const cplx (*p1pre)[MAXKS] = nullptr) {
+    // p1pre: this lane's slots of the P1 table, fetched by the caller while it waited for eps (zero slots hold zeros)
     const double h = nsub == 1 ? dt : dt / nsub;
     const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
     const int phases = (m + 1) >> 1;
@@ -959,7 +960,15 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
 #endif
         const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
 #ifndef KH_COOP_X_NOP1  // (timing experiment: wrong results)
-        kh_coop_reg_axpy<MAXKS>(c.sq[1], e1, g, wave, lane, c.ks, breg, mk.p1);
+        if (p1pre != nullptr) {
+#pragma unroll
+            for (int q = 0; q < MAXKS; ++q) {
+                breg[q].x = fma(e1, (*p1pre)[q].x, breg[q].x);
+                breg[q].y = fma(e1, (*p1pre)[q].y, breg[q].y);
+            }
+        } else {
+            kh_coop_reg_axpy<MAXKS>(c.sq[1], e1, g, wave, lane, c.ks, breg, mk.p1);
+        }
 #endif
 #ifndef KH_COOP_X_NOP2H1
         kh_coop_reg_axpy<MAXKS>(c.sq[2], e2, g, wave, lane, c.ks, breg, mk.p2);
@@ -1013,6 +1022,70 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         ++rid;
     }
     return true;
+}
+
+// ---------------------------------------------------------------------------
+// Update sums on the adjoint side (one control, first order)
+// ---------------------------------------------------------------------------
+// <chi_k(t_n) | H_1 phi_k(t_n)> = <H_1^+ chi_k(t_n) | phi_k(t_n)>, and the left factor does not depend on the running
+// forward state: V = H_1^+ X for ALL stored co-states X = [chi_k(t_n)]_{k,n} (N x K nt) is ONE dense product in front
+// of the update sweep -- off its serial chain -- instead of one cross-workgroup round per time interval inside it
+// (1.9 us x (nt - 1), plus the 64 transient registers of the control operator's fragment).  In the sweep every owner
+// thread then reads its element of V next to its element of the state: no round, no fragment.
+//
+// kh_coop_adj_mask_kernel marks the non-zero 16 x 16 blocks of H_1^+ once per engine; kh_coop_adjoint_side multiplies
+// block-sparsely on the fp64 matrix cores (v_mfma_f64_16x16x4: A = operator block [row lane & 15][k lane >> 4],
+// B = sixteen vectors [k lane >> 4][vector lane & 15], D = [row 4 reg + (lane >> 4)][vector lane & 15]).  A control
+// that is a commutator with a diagonal operator (the transmon of BASELINE config 4) has ONE non-zero block per row
+// block: the product is then a streaming pass over the store (read 16 N K nt bytes, write as many).
+__global__ void kh_coop_adj_mask_kernel(const cplx *__restrict__ op /*row-major N x N*/, int N, int G,
+                                        unsigned char *__restrict__ nz /*[G][G]*/) {
+    const int g = blockIdx.x / G, kb = blockIdx.x % G;
+    const int r = 16 * g + (threadIdx.x >> 4), col = 16 * kb + (threadIdx.x & 15);
+    bool any = false;
+    if (r < N && col < N) {
+        const cplx v = op[(size_t)r * N + col];
+        any = v.x != 0.0 || v.y != 0.0;
+    }
+    const int found = __syncthreads_or(any ? 1 : 0);
+    if (threadIdx.x == 0) nz[blockIdx.x] = found ? 1 : 0;
+}
+
+#define KH_COOP_ADJ_THREADS 256  // 4 waves x 16 vectors
+__global__ void __launch_bounds__(KH_COOP_ADJ_THREADS)
+kh_coop_adjoint_side(const cplx *__restrict__ op /*H_1^+, row-major N x N*/, const unsigned char *__restrict__ nz,
+                     const cplx *__restrict__ X /*[M][N]*/, cplx *__restrict__ V /*[M][N]*/, int N, int G, long long M) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, kq = lane >> 4;
+    const long long vec = ((long long)blockIdx.x * 4 + wave) * 16 + j;  // this lane's vector (B operand column)
+    const bool vec_ok = vec < M;
+    const cplx *x = X + (size_t)(vec_ok ? vec : 0) * N;
+    cplx *v = V + (size_t)(vec_ok ? vec : 0) * N;
+    for (int g = 0; g < G; ++g) {
+        kh_d4 dr = {0.0, 0.0, 0.0, 0.0}, di = {0.0, 0.0, 0.0, 0.0};
+        const int arow = 16 * g + j;  // A operand: row lane & 15
+        for (int kb = 0; kb < G; ++kb) {
+            if (!nz[g * G + kb]) continue;  // (uniform over the grid)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int kk = 16 * kb + 4 * ks + kq;
+                cplx a = c_make(0.0, 0.0), b = c_make(0.0, 0.0);
+                if (kk < N) {
+                    if (arow < N) a = op[(size_t)arow * N + kk];
+                    if (vec_ok) b = x[kk];
+                }
+                dr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, dr, 0, 0, 0);
+                dr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, -b.y, dr, 0, 0, 0);
+                di = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, di, 0, 0, 0);
+                di = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, di, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * g + 4 * reg + kq;
+            if (vec_ok && row < N) v[row] = c_make(dr[reg], di[reg]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1114,9 +1187,14 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
 // ---------------------------------------------------------------------------
 // forward sweep with sequential pulse update (optimize.py:444-508); single launch, in-kernel sums
 // ---------------------------------------------------------------------------
-template <int MAXKS, int COLS, bool SO>
+// ADJ (first order, one control on the A^2 chain, u.adj_store = H_1^+ chi from kh_coop_adjoint_side): the update sums
+// are taken on the adjoint side -- an element-wise product of the owners, no round -- and the dense P1 table of the
+// fragment update is fetched into registers while the sums cross the workgroups (the registers are those the control
+// operator's fragment needed before; the ~3 us L2-bound read sits in the shadow of the ~4.5 us exchange wait).
+template <int MAXKS, int COLS, bool SO, bool ADJ = false>
 __global__ void __launch_bounds__(KH_COOP_THREADS)
 kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchange ex) {
+    static_assert(!(SO && ADJ), "the second-order bra depends on the new state");
     extern __shared__ __attribute__((aligned(16))) char kh_coop_smem[];
     KhCoopLds &s = *(KhCoopLds *)kh_coop_smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1151,11 +1229,20 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     const KhCoopSqMasks mk = kh_coop_sq_masks(c, g, wave);
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) breg[q] = c_make(0.0, 0.0);
+    cplx bra_next = c_make(0.0, 0.0);
+    if constexpr (ADJ) bra_next = has_state ? u.adj_store[((size_t)k * nt) * N + row] : c_make(0.0, 0.0);
     for (int n = 0; n < nt - 1; ++n) {
         const int par = n & 1;
-        if (c.sq != nullptr && n % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
-        // co-state (and, second order, previous-iteration state) element of this owner
-        cplx bra = has_state ? u.chi_store[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0);
+        if ((ADJ || c.sq != nullptr) && n % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
+        // co-state (and, second order, previous-iteration state) element of this owner; ADJ: the element of
+        // H_1^+ chi(t_n), fetched one interval ahead
+        cplx bra;
+        if constexpr (ADJ) {
+            bra = bra_next;
+            if (n + 1 < nt - 1 && has_state) bra_next = u.adj_store[((size_t)k * nt + n + 1) * N + row];
+        } else {
+            bra = has_state ? u.chi_store[((size_t)k * nt + n) * N + row] : c_make(0.0, 0.0);
+        }
         if constexpr (SO) {
             if (has_state) {
                 const cplx prev = u.fw_prev[((size_t)k * nt + n) * N + row];
@@ -1165,9 +1252,20 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
             }
         }
         // ---- phi(t_n) of all objectives, then the update sums (optimize.py:454-470) ----
+        cplx p1pre[ADJ ? MAXKS : 1];
+        if constexpr (ADJ) {
+            if (COLS == 2 || wave < 4) {  // <H_1^+ chi | phi>: the owners' own elements
+                cplx ov = c_make(0.0, 0.0);
+                c_fma_conj(ov, bra, state);
+                const double piece = sum64(chi_norm * (u.mu_re * ov.y + u.mu_im * ov.x));
+                if (lane == 0) s.red[par][wave][0] = piece;
+            }
+            // the dense table of the coming fragment update, on its way while the sums are exchanged
+            kh_coop_reg_load<MAXKS>(c.sq[1], g, wave, lane, c.ks, p1pre, mk.p1);
+        }
 #pragma unroll
         for (int l = 0; l < KH_COOP_MAX_L; ++l) {
-            if (l >= L) break;
+            if (ADJ || l >= L) break;
             cplx w;
             if (c.sq != nullptr) {  // (the LDS fragment holds A for the whole sweep: the control operator from registers)
                 cplx hreg[MAXKS];
@@ -1185,7 +1283,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
                 if (lane == 0) s.red[par][wave][l] = piece;
             }
         }
-        rounds += L;
+        if constexpr (!ADJ) rounds += L;
         __syncthreads();
         if (s.abort) return;
         if (wave == 0) {
@@ -1230,7 +1328,12 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
         int nsub, m;
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
-        if (c.sq != nullptr) {
+        if constexpr (ADJ) {  // (one control on the A^2 chain: the only form this instantiation contains)
+            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,
+                                                     owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane, &p1pre))
+                return;
+            rounds += (double)nsub * (((m + 1) >> 1) + 1);
+        } else if (c.sq != nullptr) {
             if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
                 return;

@@ -236,6 +236,8 @@ struct KhUpdateArgs {
                                 // (read here, incremented by kh_reduce_partials), so every replay is identical
     double adj_sign;            // +1 / -1 if every control operator equals +/- its own adjoint (exactly), else 0:
                                 // <chi|H phi> may then be taken as <(sign H) chi|phi> (kernels with ADJ = true)
+    const cplx *adj_store;      // [K][nt][N] H_1^+ chi_k(t_n) (cooperative kernels, one control, first order:
+                                // kh_coop_adjoint_side), or NULL
 };
 
 // Im( mu * norm_k * <chi_k(t_n) | H_l phi_k> ) summed over this workgroup's

@@ -60,6 +60,12 @@ struct kh_engine {
     unsigned int *d_coop_xcc = nullptr;  // [Y * G] placement check of the cooperative kernels (zeroed per launch)
     bool coop_xcd = false;               // one column group per XCD (kh_coop.h, kh_coop_place); KH_COOP_XCD=0: off
     size_t coop_vbuf_bytes = 0;
+    // update sums on the adjoint side (kh_coop_adjoint_side): H_1^+ chi for the whole store, formed in front of the
+    // update sweep; KH_COOP_NO_ADJ=1: the sums by one more round per interval, as for second order / two controls
+    bool coop_adj = false;
+    unsigned char *d_coop_adj_nz = nullptr;  // [G][G] non-zero 16 x 16 blocks of H_1^+
+    cplx *d_coop_adj = nullptr;              // [K][nt][N], allocated by the first update sweep
+    const cplx *coop_adj_op = nullptr;       // H_1^+, row-major (the staged adjoint of the shared control operator)
     // device-side problem data
     const cplx **d_ops_fw = nullptr;  // [K*(1+L)]
     const cplx **d_ops_bw = nullptr;  // [K*(1+L)] adjoints
@@ -237,6 +243,8 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_step_partial);
     (void)hipFree(e->d_coop_vbuf);
     (void)hipFree(e->d_coop_xcc);
+    (void)hipFree(e->d_coop_adj_nz);
+    (void)hipFree(e->d_coop_adj);
     for (void *ptr : e->p2p_opened) (void)hipIpcCloseMemHandle(ptr);
     (void)hipFree(e->p2p_window);
     (void)hipFree((void *)e->d_p2p_peers);
@@ -566,6 +574,13 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             }
         }
         KH_HIP_E(hipGetLastError());
+        if (coop_sq && bw[1] != nullptr && !(getenv("KH_COOP_NO_ADJ") && atoi(getenv("KH_COOP_NO_ADJ")))) {
+            e->coop_adj = true;
+            e->coop_adj_op = bw[1];
+            KH_HIP_E(hipMalloc(&e->d_coop_adj_nz, (size_t)e->coop_G * e->coop_G));
+            kh_coop_adj_mask_kernel<<<e->coop_G * e->coop_G, 256>>>(bw[1], e->N, e->coop_G, e->d_coop_adj_nz);
+            KH_HIP_E(hipGetLastError());
+        }
     }
     {  // (every kernel family but the cooperative one reads the series tables)
         std::vector<double> tab(KH_MAX_DEGREE + 1), c0(KH_MAX_DEGREE + 1), rows((size_t)(KH_MAX_DEGREE + 1) * KH_Q2_ROWS * 2),
@@ -754,15 +769,35 @@ static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *p
 }
 
 template <int MAXKS, int COLS>
-static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u, const KhExchange &ex,
+static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u_in, const KhExchange &ex,
                               hipStream_t st) {
+    KhUpdateArgs u = u_in;
+    const bool adj = e->coop_adj && u.sigma == nullptr && e->L == 1 && e->d_coop_sq_fw != nullptr;
     const void *func = u.sigma != nullptr ? (const void *)kh_coop_forward_update<MAXKS, COLS, true>
+                       : adj              ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, true>
                                           : (const void *)kh_coop_forward_update<MAXKS, COLS, false>;
     const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
+    if (adj) {
+        // V = H_1^+ X over the whole co-state store, block-sparse on the matrix cores (kh_coop.h)
+        const long long M = (long long)e->K * e->nt;
+        if (e->d_coop_adj == nullptr) {
+            if (hipMalloc(&e->d_coop_adj, sizeof(cplx) * (size_t)M * e->N) != hipSuccess) {
+                (void)hipGetLastError();
+                return kh_fail(KH_ERR_NOMEM, "no memory for H_1^+ chi (%zu bytes)", sizeof(cplx) * (size_t)M * e->N);
+            }
+        }
+        const unsigned blocks = (unsigned)((M + 63) / 64);
+        kh_coop_adjoint_side<<<blocks, KH_COOP_ADJ_THREADS, 0, st>>>(e->coop_adj_op, e->d_coop_adj_nz, u.chi_store, e->d_coop_adj,
+                                                                     e->N, e->coop_G, M);
+        KH_HIP(hipGetLastError());
+        u.adj_store = e->d_coop_adj;
+    }
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
     return launch_coop_placed(e, [&](dim3 grid) {
+        if (adj)
+            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
         if (u.sigma != nullptr)
             return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
         return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
@@ -950,6 +985,7 @@ static KhUpdateArgs update_args(kh_engine *e, const kh_cdouble *chi_store, const
     u.n_end = e->nt - 1;
     u.internal_exchange = 1;
     u.adj_sign = e->adj_sign;
+    u.adj_store = nullptr;
     return u;
 }
 
