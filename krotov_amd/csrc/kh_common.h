@@ -387,7 +387,8 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
                                           double (&out)[MAXL]) {
     const kh_u64 *base = ex.slots + (size_t)parity * ex.G * L * 2;
     kh_u64 a[MAXL][CH], b[MAXL][CH];
-    const long long t0 = wall_clock64();
+    long long t0 = 0;  // (taken when the first poll fails: s_memrealtime is an SMEM read that the next lgkmcnt wait -- the
+                       // LDS write of the result -- would sit behind in every interval)
     unsigned int spins = 0;
     // a poll issued before the slowest producer's store has reached the memory
     // side costs a whole extra round trip: give the stores a head start
@@ -415,6 +416,7 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
                 ok = ok && ((unsigned int)(a[l][c] >> 32) == epoch) && ((unsigned int)(b[l][c] >> 32) == epoch);
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
+        if (spins == 0) t0 = wall_clock64();
         if ((++spins & 255u) == 0) {  // wave-uniform
             const bool gave_up =
                 (wall_clock64() - t0 > ex.timeout_ticks) ||
@@ -425,6 +427,9 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
             }
         }
     }
+#ifdef KH_TIMING
+    if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) ex.abort_flag[1] += spins + 1u;  // polling rounds (workgroup 0)
+#endif
 #pragma unroll
     for (int l = 0; l < MAXL; ++l) {
         double acc = 0.0;
@@ -460,7 +465,7 @@ __device__ __forceinline__ bool kh_p2p_gather(const KhExchange &ex, int parity, 
     const bool active = lane < pairs;
     const kh_u64 *g = ex.my_window + ((size_t)parity * ex.world * L + (active ? lane : 0)) * 2;
     kh_u64 a = 0, b = 0;
-    const long long t0 = wall_clock64();
+    long long t0 = 0;  // (taken when the first poll fails, see kh_gather)
     unsigned int spins = 0;
     for (;;) {
         if (active) {
@@ -470,6 +475,7 @@ __device__ __forceinline__ bool kh_p2p_gather(const KhExchange &ex, int parity, 
         const bool ok = !active || (((unsigned int)(a >> 32) == epoch) && ((unsigned int)(b >> 32) == epoch));
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
+        if (spins == 0) t0 = wall_clock64();
         if ((++spins & 255u) == 0) {
             const bool gave_up =
                 (wall_clock64() - t0 > ex.timeout_ticks) ||

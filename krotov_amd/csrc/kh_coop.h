@@ -1300,7 +1300,15 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
             const bool ok = true;
             for (int l = 0; l < KH_COOP_MAX_L; ++l) D[l] = part[l];
 #else
+#ifdef KH_TIMING
+            const long long tx0 = clock64();
+#endif
             const bool ok = kh_exchange<KH_COOP_MAX_L>(ex, n, wg, L, lane, part, D);
+#ifdef KH_TIMING
+            // how long each column group waits for the sums of ALL groups (the one point per interval where the
+            // XCDs meet): cycles per interval, read back per group by scripts/timing_coop.py (stats[20 + y])
+            if (g == 0 && lane == 0 && p.stats != nullptr && y < 16) p.stats[20 + y] += (double)(clock64() - tx0) / (nt - 1);
+#endif
 #endif
             if (lane == 0) {
 #pragma unroll

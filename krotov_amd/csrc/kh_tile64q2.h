@@ -457,7 +457,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     KhDegreeCache dc = {12, 1.0, 0.0};
 
 #ifdef KH_TIMING
-    long long t_ex = 0, t_prop = 0, t_part = 0;
+    long long t_ex = 0, t_prop = 0, t_part = 0, t_coll = 0;
     const long long t_all0 = clock64();
 #endif
     for (int nr = u.n_begin, n_stop; nr < u.n_end; nr = n_stop) {
@@ -480,26 +480,59 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         const long long tq0 = clock64();
 #endif
         // ---- cross-objective sum (optimize.py:470) ----
+        cplx q1[8], q2[8];
         if (u.internal_exchange) {
             double part[1] = {0.0};
             if (wave == 0) {
                 part[0] = partial_total(par);
+#ifndef KH_Q2_X_NOEXCH
                 kh_exchange_publish(ex, n, k, 1, lane, part);
+#endif
             }
+#ifndef KH_Q2_NO_PREFETCH
+            // The P1 / P2 elements of the coming tile advance leave LDS now, while the sums cross the GPU (the
+            // registers are free here: no product is in flight), instead of behind the exchange in front of the
+            // first phase (16 ds_read_b128 per lane = 128 KiB per workgroup and interval: ~1000 cycles of LDS pipe)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                q1[j] = s.h0[j * KH_Q2_THREADS + tid];
+                q2[j] = s.p0[j * KH_Q2_THREADS + tid];
+            }
+#endif
             if constexpr (ADJ) {
                 if (n + 1 < nt - 1) adjoint_side();  // chib holds chi(t_{n+1})
             }
             if (wave == 0) {
                 double D[1];
+#ifdef KH_Q2_X_NOEXCH  // (timing experiment: wrong results) the workgroup's own sum instead of everybody's
+                const bool ok = true;
+                D[0] = part[0];
+#else
+#ifdef KH_TIMING
+                const long long tc0 = clock64();
+#endif
                 const bool ok = kh_exchange_collect<1>(ex, n, k, 1, lane, part, D);
+#ifdef KH_TIMING
+                t_coll += clock64() - tc0;
+#endif
+#endif
                 if (lane == 0) {
                     D_sh[par][0] = D[0];
                     D_sh[par][1] = ok ? 1.0 : 0.0;
                 }
             }
-        } else if (tid == 0) {
-            D_sh[par][0] = u.D_in[0];
-            D_sh[par][1] = 1.0;
+        } else {
+            if (tid == 0) {
+                D_sh[par][0] = u.D_in[0];
+                D_sh[par][1] = 1.0;
+            }
+#ifndef KH_Q2_NO_PREFETCH
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                q1[j] = s.h0[j * KH_Q2_THREADS + tid];
+                q2[j] = s.p0[j * KH_Q2_THREADS + tid];
+            }
+#endif
         }
         // (issued here, not before the exchange: measured 21.3 vs 22.1 ms per sweep)
         const double dt = dt_next, guess = guess_next, stepw = stepw_next;
@@ -530,24 +563,33 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
             kh_q2_load_rows(p, s, m, tid);
             m_rows = m;
         }
+#ifndef KH_Q2_NO_PREFETCH
+        kh_q2_advance_reg(eps, eps_prev, h1, q1, q2, a, b);
+#else
         kh_q2_advance(s, tid, eps, eps_prev, h1, a, b);
+#endif
         eps_prev = eps;
         stepw_next = kh_uniform(shape_next / lam);  // (under the LDS latency of the tile reads)
         cplx *fw_out = nullptr;
         if constexpr (SO) fw_out = u.fw_store + ((size_t)k * nt + n) * N;
         if constexpr (ADJ) {
             if (n + 2 < nt - 1) load_chi(n + 2);  // lands during the phases; goes to LDS in the epilogue
+            auto epilogue = [&] {
+                if (n + 1 < nt - 1) {
+                    cplx ov = c_make(0.0, 0.0);
+                    if (writer) c_fma_conj(ov, w, state);
+                    const double v = KhQ2Lanes::writers_sum(u.mu_re * ov.y + u.mu_im * ov.x);
+                    if (lane == 0) red[(n + 1) & 1][wave][0] = v;
+                    if (n + 2 < nt - 1 && writer) s.chib[row] = chi;
+                }
+            };
+#ifdef KH_Q2_X_NOPHASES  // (timing experiment: wrong results) the exchange alone: no propagation
+            epilogue();
+            __syncthreads();
+#else
             matvecs += kh_q2_expm_action(a, b, state, s.buf, s.sbuf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
-                                         lane, [&] {
-                                             if (n + 1 < nt - 1) {
-                                                 cplx ov = c_make(0.0, 0.0);
-                                                 if (writer) c_fma_conj(ov, w, state);
-                                                 const double v =
-                                                     KhQ2Lanes::writers_sum(u.mu_re * ov.y + u.mu_im * ov.x);
-                                                 if (lane == 0) red[(n + 1) & 1][wave][0] = v;
-                                                 if (n + 2 < nt - 1 && writer) s.chib[row] = chi;
-                                             }
-                                         });
+                                         lane, epilogue);
+#endif
         } else {
             matvecs += kh_q2_expm_action(a, b, state, s.buf, s.sbuf, s.inv2, cur, fw_out, N, p.fre, p.fim, dt, nsub, m, wave,
                                          lane, [] {});
@@ -571,7 +613,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
     if (tid == 0 && k == 0 && p.stats != nullptr) {
         p.stats[1] = (double)t_ex;
         p.stats[2] = (double)t_prop;
-        p.stats[3] = (double)t_part;
+        p.stats[3] = (double)t_coll;  // (wave 0: first poll issued -> sums complete)
     }
 #endif
     if (wave == 0 && lane < N) {

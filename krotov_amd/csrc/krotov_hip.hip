@@ -22,6 +22,9 @@
 #include "kh_generic.h"
 #include "kh_tile64.h"
 #include "kh_tile64q2.h"
+#ifdef KH_WITH_Q4  // experiment build only (scripts/experiments/kh_tile64q4.h: 1024-thread plain sweep, measured 71 % slower)
+#include "../../scripts/experiments/kh_tile64q4.h"
+#endif
 #include "kh_coop.h"
 #include "kh_mini.h"
 
@@ -111,6 +114,7 @@ struct kh_engine {
     double imag_defect = -1.0;   // >= 0: bound on the Hermitian part of f A dt when the controls' f H_l are exactly
                                  // anti-Hermitian (|| . ||_F of the drift's part x max dt); < 0: not of that kind
     bool coop_series = false;    // the cooperative kernels run the Chebyshev-form series (kh_common.h)
+    bool use_q4 = false;         // KH_Q4=1 in a -DKH_WITH_Q4 build (experiment): plain sweeps with 1024-thread workgroups
     bool stepwise_only = false;  // more objectives than can be co-resident: kh_forward_update runs one launch per interval
     double *d_step_partial = nullptr;  // [L] the interval's sums on that path
     bool mini = false;           // kind q2, N <= 16, K <= 8: the one-wave-per-objective kernels (kh_mini.h)
@@ -395,6 +399,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         const char *d = getenv("KH_COOP_LAUNCH");
         g_coop_launch = d == nullptr || atoi(d) != 0;
     }
+    if (const char *d = getenv("KH_Q4")) e->use_q4 = atoi(d) != 0;
     if (const char *d = getenv("KH_POLL_DELAY")) e->poll_delay = atoi(d);
     if (const char *d = getenv("KH_ADJ_DELAY")) e->adj_poll_delay = atoi(d);
     if (const char *d = getenv("KH_COOP_DELAY")) e->coop_poll_delay = atoi(d);
@@ -644,8 +649,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                                                                                          : e->grid_update;
     e->slots_bytes = sizeof(kh_u64) * 2 * (size_t)slot_wgs * Lx * 2;
     KH_HIP_E(hipMalloc(&e->d_slots, e->slots_bytes));
-    KH_HIP_E(hipMalloc(&e->d_abort, sizeof(unsigned int)));
-    KH_HIP_E(hipMemset(e->d_abort, 0, sizeof(unsigned int)));
+    KH_HIP_E(hipMalloc(&e->d_abort, 2 * sizeof(unsigned int)));  // [0] abort flag, [1] (KH_TIMING) polling rounds
+    KH_HIP_E(hipMemset(e->d_abort, 0, 2 * sizeof(unsigned int)));
     KH_HIP_E(hipMalloc(&e->d_stats, sizeof(double) * 68));
     KH_HIP_E(hipMemset(e->d_stats, 0, sizeof(double) * 68));
     KH_HIP_E(hipMalloc(&e->d_wg_partial, sizeof(double) * (size_t)e->grid_update * Lx));
@@ -814,6 +819,13 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         kh_quad_sweep_store<<<1, 64, 0, st>>>(p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
     } else if (e->kind_store == KIND_TILE_Q2 && e->mini) {
         kh_mini_sweep_store<<<e->K, 64, 0, st>>>(p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
+#ifdef KH_WITH_Q4
+    } else if (e->kind_store == KIND_TILE_Q2 && e->use_q4) {
+        rc = ensure_dynamic_lds(e, (const void *)kh_q4_sweep_store, kh_q4_lds_bytes());
+        if (rc == KH_OK)
+            kh_q4_sweep_store<<<e->K, KH_Q4_THREADS, kh_q4_lds_bytes(), st>>>(
+                p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
+#endif
     } else if (e->kind_store == KIND_TILE_Q2) {
         kh_q2_sweep_store<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(
             p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
@@ -1014,7 +1026,11 @@ extern "C" int kh_forward_update(kh_engine *e, const kh_cdouble *chi_store_dev, 
         e->last_wgs = e->grid_update;
         return rc;
     }
+#ifdef KH_TIMING
+    KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 68, st));
+#else
     KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
+#endif
     KH_HIP(hipMemcpyAsync(e->d_phi, init_dev, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice, st));
     KhUpdateArgs u =
         update_args(e, chi_store_dev, chi_norms_dev, guess_dev, shape_dev, lambda_dev, opt_dev, g_a_dev);
@@ -1344,6 +1360,12 @@ extern "C" int kh_last_stats(kh_engine *e, double stats[4]) {
         KH_HIP(hipMemcpy(tr, e->d_stats + 4, sizeof(tr), hipMemcpyDeviceToHost));
         fprintf(stderr, "KH_TRACE (cycles since the interval's start):");
         for (int i = 0; i < 64 && (i == 0 || tr[i] != 0.0); ++i) fprintf(stderr, " %d:%.0f", i, tr[i] - tr[0]);
+        fprintf(stderr, "\n");
+        unsigned int ab[2] = {0, 0};
+        KH_HIP(hipMemcpy(ab, e->d_abort, sizeof(ab), hipMemcpyDeviceToHost));
+        fprintf(stderr, "KH_TRACE polling rounds of workgroup 0 since the engine was created: %u\n", ab[1]);
+        fprintf(stderr, "KH_TRACE raw [16..31]:");
+        for (int i = 16; i < 32; ++i) fprintf(stderr, " %.0f", tr[i]);
         fprintf(stderr, "\n");
     }
 #endif

@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""Per-interval breakdown of the update sweep (needs gpurun_out/libkrotov_hip_timing.so built with -DKH_TIMING; gpurun_out/ is not shipped, so build it on the box: see the command in DESIGN.md section 6)."""
-import os, sys, ctypes
+"""Update sweep of the config-5 shape with an experiment build of the library (KH_LIB=<path>): used with
+-DKH_Q2_X_NOEXCH (the phases alone: every workgroup uses its own partial sum, nothing is published or polled) and
+-DKH_Q2_X_NOPHASES (the exchange alone: no propagation) to split the per-interval time of kh_q2_forward_update into
+its two serial parts.  Results of those builds are wrong by design: timing only."""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from krotov_amd import _lib
-_lib.LIB_PATH = os.environ.get('KH_TIMING_LIB', os.path.join(ROOT, 'gpurun_out', 'libkrotov_hip_timing.so'))
+if os.environ.get('KH_LIB'):
+    _lib.LIB_PATH = os.environ['KH_LIB']
 from krotov_amd import configs
 from krotov_amd.engine import HipKrotovEngine
-import torch
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N, nt = 64, 4001
 spec = configs.config_c5(K=K, N=N, nt=nt)
@@ -20,14 +23,9 @@ pulses = np.array([[0.5 * np.sin(np.pi * (t + 0.5 * (tl[1] - tl[0])) / tl[-1]) f
 chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
 chi = eng.backward(chi_T, pulses)
 norms = np.full(K, 1.0 / (2 * K))
-for _ in range(2):
+for _ in range(3):
     out = eng.forward_update(chi, norms, spec.init, pulses, np.ones((1, nt - 1)), np.array([50.0]))
 eng.check()
-buf = (ctypes.c_double * 4)()
-_lib.check(eng._lib.kh_last_stats(eng._handle, buf))
 ms = min(eng.kernel_times_ms()['update'])
-n = nt - 1
-print('%s K=%d update %.2f ms (%.2f us/interval); ticks/interval: exchange %.0f  build+phases %.0f  of the exchange: collect (first poll -> sums) %.0f' % (
-    eng.kernel, K, ms, ms * 1e3 / n, buf[1] / n, buf[2] / n, buf[3] / n))
-os.environ['KH_TRACE'] = '1'  # prints the polling rounds of workgroup 0 (3 sweeps' worth)
-_lib.check(eng._lib.kh_last_stats(eng._handle, buf))
+print('%s K=%d lib=%s: update sweep %.2f ms = %.2f us per interval' % (
+    eng.kernel, K, os.path.basename(_lib.LIB_PATH), ms, ms * 1e3 / (nt - 1)))

@@ -21,3 +21,12 @@ eng._lib.kh_last_stats(eng._handle, buf)
 print('rounds*cols %d  cycles/round: poll %.0f (fast pass %d)  mfma+lds write %.0f  barrier %.0f | stale lanes after the fast pass %.2f/64, '
       'agent-scope passes per round %.2f' % (buf[0], buf[1] % 1e6, int(buf[1] / 1e6), buf[2] % 1e6, buf[3] % 1e6,
                                            int(buf[2] / 1e6) / 100.0, int(buf[3] / 1e6) / 100.0))
+
+# update sweep: how long every column group (one per XCD) waits in the exchange of the update sums
+S = np.ones((L, len(tl) - 1)); lam = np.full(L, 1.0); norms = np.full(K, 1.0 / (2 * K))
+eng.profile = True
+for _ in range(2):
+    out = eng.forward_update(chi, norms, spec.init, pulses, S, lam)
+torch.cuda.synchronize()
+print('update sweep %.2f ms; KH_TRACE raw [16..31] = exchange wait per column group, cycles per interval' % min(eng.kernel_times_ms()['update']))
+eng._lib.kh_last_stats(eng._handle, buf)
