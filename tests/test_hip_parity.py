@@ -843,6 +843,18 @@ def test_full_size_c4_liouville_properties(monkeypatch):
                                          np.array(S), np.array(lam))
     eng.check()
     assert np.all(np.isfinite(opt.cpu().numpy()))
+    # one iteration of the reference's own optimize_pulses loop at full size (tests/golden/ref_c4_full.npz: 16 x 1000
+    # x 3 dense 400 x 400 expm, 53 CPU-minutes; tests/golden/README.md): the guess pulses, the updated pulses and
+    # tau before and after -- a lost fixture fails the test, it does not skip the comparison.  This is the check of
+    # the degree-20 near-imaginary-spectrum series at theta = 2.6 against the reference's Pade expm.
+    g = golden('ref_c4_full')
+    assert np.abs(pulses - g['all_pulses'][0]).max() == 0.0
+    assert np.abs(opt.cpu().numpy() - g['all_pulses'][1]).max() < 1e-9 * max(1.0, np.abs(g['all_pulses'][1]).max())
+    tau0 = eng.tau(spec.target, fw_T).cpu().numpy()
+    tau1 = eng.tau(spec.target, psi_T).cpu().numpy()
+    assert np.abs(tau0 - g['tau_vals'][0]).max() < 1e-9
+    assert np.abs(tau1 - g['tau_vals'][1]).max() < 1e-9
+    assert np.abs(psi_T.cpu().numpy() - g['fw_T']).max() < 1e-9
     eng.close()
     # the same full-size sweeps through the generic (one workgroup per objective) kernels
     monkeypatch.setenv('KH_KERNEL', 'generic')
