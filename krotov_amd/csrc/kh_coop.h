@@ -939,8 +939,9 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
                                                        double fim, double dt, int nsub, int m, int tid, int wave,
                                                        int lane, const cplx (*p1pre)[MAXKS] = nullptr) {
     // p1pre: this lane's slots of the P1 table, fetched by the caller while it waited for eps (zero slots hold zeros)
-    const double h = nsub == 1 ? dt : dt / nsub;
-    const double f2h2 = (fre * fre - fim * fim) * h * h;  // f is purely real or purely imaginary
+    // (wave-uniform scalars are kept in SGPRs: the VGPR file is full of operator fragments)
+    const double h = kh_uniform(nsub == 1 ? dt : dt / nsub);
+    const double f2h2 = kh_uniform((fre * fre - fim * fim) * h * h);  // f is purely real or purely imaginary
     const int phases = (m + 1) >> 1;
     // series coefficients of degree m: sum_j c_j (f h A)^j, rows[p] = {c_{2p+1}/c_{2p}, c_{2p+2}/c_{2p}} (p = 0: c_1, c_2)
     // (copied to LDS once per interval: a scalar load from the table in every phase sat exposed in the round's chain)
@@ -952,7 +953,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         __syncthreads();
     }
     const double *rows = series ? s.coef : nullptr;
-    const double c_0 = series ? s.coef[2 * phases] : 1.0, c_1 = series ? s.coef[0] : 1.0;
+    const double c_0 = kh_uniform(series ? s.coef[2 * phases] : 1.0), c_1 = kh_uniform(series ? s.coef[0] : 1.0);
 #ifndef KH_COOP_X_NOREBUILD  // (timing experiment: wrong results)
     {
 #ifdef KH_TIMING
@@ -974,7 +975,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         kh_coop_reg_axpy<MAXKS>(c.sq[2], e2, g, wave, lane, c.ks, breg, mk.p2);
         kh_coop_axpy_frag<MAXKS>(c.fops[1], e1, g, wave, lane, c.ks, a, mk.h1);
 #endif
-        eps_prev = eps;
+        eps_prev = kh_uniform(eps);
 #ifdef KH_TIMING
         if (tid == 0 && blockIdx.x == 0) {
             const long long tr1 = clock64();
@@ -992,8 +993,8 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             // (the coefficients are fetched before the round, not between its end and the owners' stores; a timed-out
             // round is noticed after the phases: the later rounds give up at once on the abort flag)
             // (read before the round, used after it)
-            const double r2 = rows != nullptr ? rows[2 * ph + 1] : kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2];
-            const double r1n = ph + 1 < phases ? (rows != nullptr ? rows[2 * ph + 2] : kh_inv_table[2 * ph + 3]) : 0.0;
+            const double r2 = kh_uniform(rows != nullptr ? rows[2 * ph + 1] : kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2]);
+            const double r1n = kh_uniform(ph + 1 < phases ? (rows != nullptr ? rows[2 * ph + 2] : kh_inv_table[2 * ph + 3]) : 0.0);
             cplx w;
             kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, bf, s, tid, wave, lane, w);
             const double c2 = f2h2 * r2, hn = h * r1n;
@@ -1218,7 +1219,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     unsigned int rid = 1;
     if (owner_valid) kh_coop_publish(c, rid, y, row, col, state, c.local != 0);
     __syncthreads();
-    double rounds = 0.0;
+    int rounds = 0;  // (an SGPR counter)
     double g_a_loc[KH_COOP_MAX_L];
 #pragma unroll
     for (int l = 0; l < KH_COOP_MAX_L; ++l) g_a_loc[l] = 0.0;
@@ -1303,7 +1304,16 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
 #ifdef KH_TIMING
             const long long tx0 = clock64();
 #endif
-            const bool ok = kh_exchange<KH_COOP_MAX_L>(ex, n, wg, L, lane, part, D);
+            bool ok;
+            if constexpr (ADJ) {  // (one control: half the gather registers next to the prefetched table)
+                double D1[1];
+                ok = kh_exchange<1>(ex, n, wg, 1, lane, part, D1);
+                D[0] = D1[0];
+#pragma unroll
+                for (int l = 1; l < KH_COOP_MAX_L; ++l) D[l] = 0.0;
+            } else {
+                ok = kh_exchange<KH_COOP_MAX_L>(ex, n, wg, L, lane, part, D);
+            }
 #ifdef KH_TIMING
             // how long each column group waits for the sums of ALL groups (the one point per interval where the
             // XCDs meet): cycles per interval, read back per group by scripts/timing_coop.py (stats[20 + y])
@@ -1319,17 +1329,18 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
         __syncthreads();
         if (s.D[par][KH_COOP_MAX_L] == 0.0) return;
         // ---- pulse update (optimize.py:471-477) ----
-        const double dt = p.dt[n];
+        // (wave-uniform scalars are kept in SGPRs: the VGPR file is full of operator fragments)
+        const double dt = kh_uniform(p.dt[n]);
         double eps[KH_COOP_MAX_L];
-        double theta = p.op_norms[0];
+        double theta = kh_uniform(p.op_norms[0]);
 #pragma unroll
         for (int l = 0; l < KH_COOP_MAX_L; ++l) {
             if (l >= L) break;
-            const double d1 = s.D[par][l];
-            const double stepw = u.shape[(size_t)l * (nt - 1) + n] / u.lambda[l];
-            eps[l] = u.guess[(size_t)l * (nt - 1) + n] + stepw * d1;
-            g_a_loc[l] += stepw * (d1 * d1) * dt;
-            theta += fabs(eps[l]) * p.op_norms[1 + l];
+            const double d1 = kh_uniform(s.D[par][l]);
+            const double stepw = kh_uniform(u.shape[(size_t)l * (nt - 1) + n] / u.lambda[l]);
+            eps[l] = kh_uniform(u.guess[(size_t)l * (nt - 1) + n] + stepw * d1);
+            g_a_loc[l] = kh_uniform(g_a_loc[l] + stepw * (d1 * d1) * dt);
+            theta = kh_uniform(theta + fabs(eps[l]) * p.op_norms[1 + l]);
             if (wg == 0 && tid == 0) u.opt[(size_t)l * (nt - 1) + n] = eps[l];
         }
         // ---- propagate over interval n with the updated pulses (optimize.py:479-491) ----
@@ -1340,18 +1351,18 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
             if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane, &p1pre))
                 return;
-            rounds += (double)nsub * (((m + 1) >> 1) + 1);
+            rounds += nsub * (((m + 1) >> 1) + 1);
         } else if (c.sq != nullptr) {
             if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
                 return;
-            rounds += (double)nsub * (((m + 1) >> 1) + 1);
+            rounds += nsub * (((m + 1) >> 1) + 1);
         } else {
             kh_coop_build<MAXKS>(c.fops, eps, L, g, wave, lane, c.ks, a);
             if (!kh_coop_expm_action<MAXKS, COLS>(c, ex, a, state, rid, s, N, y, row, col, owner_valid, p.fre, p.fim, dt,
                                                   nsub, m, tid, wave, lane))
                 return;
-            rounds += (double)nsub * m;
+            rounds += nsub * m;
         }
     }
     if (has_state) {
@@ -1365,6 +1376,6 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     }
     if (g == 0 && tid == 0 && p.stats != nullptr) {
         const int cols = min(c.cols, p.K - y * c.cols);
-        atomicAdd(p.stats, rounds * cols);
+        atomicAdd(p.stats, (double)rounds * cols);
     }
 }
