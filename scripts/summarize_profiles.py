@@ -66,3 +66,22 @@ if os.path.isdir(vdir):
             print('%-20s %8.2f M props/s  %7.2f ms/iteration  kernel %s  (%s %.1f%% of fp64 peak)' % (
                 k, v['value'] / 1e6, v['ms_per_step'], v['config']['kernel'], v['roofline']['kernel'],
                 100 * v['roofline']['frac']))
+
+# config-4 PMC passes (scripts/collect_c4_pmc.sh <tag>) -> profiles/<tag>/pmc_config4.json
+cdir = os.path.join(src, 'c4_pmc')
+if os.path.isdir(cdir):
+    c4sum = {}
+    for sub in sorted(os.listdir(cdir)):
+        path = os.path.join(cdir, sub, 'b_counter_collection.csv')
+        if not os.path.exists(path):
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(path)):
+            agg[r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+        for kern, ctrs in agg.items():
+            if kern.startswith('kh_coop'):
+                for c, v in ctrs.items():
+                    c4sum.setdefault(kern, {})[c] = {'avg_per_launch': sum(v) / len(v), 'launches': len(v)}
+    json.dump(c4sum, open(os.path.join(dst, 'pmc_config4.json'), 'w'), indent=1, sort_keys=True)
+    for kern, c in c4sum.items():
+        print(kern, {k: '%.3g' % v['avg_per_launch'] for k, v in c.items()})
