@@ -204,6 +204,7 @@ def main():
                     help='skip the short L=4 and distinct-drift runs the default single-GPU line carries under "L4" / "distinct"')
     ap.add_argument('--no-rccl-leg', action='store_true',
                     help='multi-rank runs: skip the extra measurement with one RCCL all-reduce per time interval ("rccl")')
+    ap.add_argument('--rccl-leg-timeout', type=int, default=240, help='seconds the "rccl" side measurement may take')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the multi-GPU code path (stepwise sweep + RCCL all-reduce per interval) even on 1 rank')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -435,11 +436,6 @@ def main():
     other = 'weak' if args.scaling == 'strong' else 'strong'
     out = measure(args.scaling)
     second = measure(other) if world > 1 and args.workload == 'c5' else None
-    rccl = None
-    if (world > 1 or args.force_dist) and args.workload == 'c5' and not args.no_rccl_leg:
-        # the north star's transport: one RCCL all-reduce of the L update sums per time interval (kh_update_begin /
-        # step_dev / end with HIP-graph replay) instead of the peer windows inside the persistent kernel
-        rccl = leg('strong', env={'KH_P2P': '0'}, steps=min(args.steps, 3), warmup=1)
     if rank == 0:
         out['n_ranks_seen'] = torch.distributed.get_world_size() if group is not None else 1
         if second is not None:
@@ -447,6 +443,28 @@ def main():
             out[other] = {k: second[k] for k in ('value', 'unit', 'iterations_per_sec', 'ms_per_step', 'scaling')}
             out[other]['objectives'] = second['config']['objectives']
             out[other]['kernels'] = {k: second['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')}
+    rccl = None
+    if (world > 1 or args.force_dist) and args.workload == 'c5' and not args.no_rccl_leg:
+        # the north star's transport: one RCCL all-reduce of the L update sums per time interval (kh_update_begin /
+        # step_dev / end with HIP-graph replay) instead of the peer windows inside the persistent kernel.  It is a side
+        # measurement: if it does not come back within --rccl-leg-timeout seconds (a collective that hangs cannot be
+        # interrupted from Python), every rank's watchdog ends the process with the headline line printed and rc 0.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out['rccl'] = {'error': 'no result within %d s' % args.rccl_leg_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.rccl_leg_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            rccl = leg('strong', env={'KH_P2P': '0'}, steps=min(args.steps, 3), warmup=1)
+        finally:
+            watchdog.cancel()
+    if rank == 0:
         if rccl is not None:
             out['rccl'] = rccl
         if world == 1 and not args.no_cpu_baseline:
