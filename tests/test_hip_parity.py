@@ -101,6 +101,36 @@ def test_sweeps_match_oracle(name):
     eng.close()
 
 
+@pytest.mark.parametrize('name', ['c4_d9', 'c4_d10_k9', 'shared_n300'])
+def test_coop_update_sums_on_the_adjoint_side_vs_one_more_round(name, monkeypatch):
+    """Cooperative kernels, one control, first order: the update sums as <H_1^+ chi | phi> -- H_1^+ chi for the whole
+    co-state store by one block-sparse matrix-core pass in front of the sweep (kh_coop_adjoint_side; a diagonal
+    commutator control in the transmon cases, a dense Hermitian one with a ragged last row block in 'shared_n300') --
+    against the form with one more cross-workgroup round per interval (KH_COOP_NO_ADJ=1: what second order and two
+    controls use).  Same pulses to rounding, and the adjoint-side sweep issues one product per interval less."""
+    spec = SMALL[name]()
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 1.0 / (2 * spec.K))
+    out = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('KH_COOP_NO_ADJ', flag)
+        eng = _engine(spec)
+        assert eng.kernel == 'coop16/mfma'
+        chi = eng.backward(chi_T, pulses)
+        opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+        eng.check()
+        out[flag] = (opt.cpu().numpy(), psi_T.cpu().numpy(), g_a.cpu().numpy(), eng.stats()['matvecs'])
+        eng.close()
+    scale = max(1.0, np.abs(out['1'][0]).max())
+    assert np.abs(out['0'][0] - out['1'][0]).max() < 1e-13 * scale
+    assert np.abs(out['0'][1] - out['1'][1]).max() < 1e-13
+    assert np.abs(out['0'][2] - out['1'][2]).max() < 1e-13 * max(1.0, np.abs(out['1'][2]).max())
+    intervals = len(spec.tlist) - 1
+    assert out['1'][3] - out['0'][3] == pytest.approx(spec.K * intervals)  # one round per interval less
+
+
 @pytest.mark.parametrize('name', ['c5_n16', 'c5_n64', 'c5_n64_L2', 'c5_n33'])
 @pytest.mark.parametrize('kernel', ['generic', 'tile512', 'tile256'])
 def test_kernel_families_agree(name, kernel, monkeypatch):
