@@ -7,6 +7,7 @@ test_functionals.py, test_mu.py, test_overlap.py, test_krotov.py, and the TLS
 dump of tests/test_result_serialization.
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -355,3 +356,37 @@ def test_device_path_fails_loudly_without_gpu():
                                    chi_constructor=krotov_amd.functionals.chis_ss, iter_stop=1)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         krotov_amd.propagators.expm([spec.H0[0], [spec.Hc[0][0], 0.1]], spec.init[0], 0.01)
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """``python bench.py --gpus N`` without a launcher (no WORLD_SIZE): bench.self_launch re-executes the same command
+    line under torch.distributed.run -- one rank per GPU, rendezvous on 127.0.0.1 with a free port -- and hands the
+    launcher's return code on (the driver's multi-GPU command is exactly this form)."""
+    import importlib
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen['cmd'], seen['env'] = list(cmd), dict(env)
+        return Done()
+
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1'])
+    assert bench.self_launch(4) == 7
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert 1024 < int(cmd[cmd.index('--master-port') + 1]) < 65536
+    tail = cmd[cmd.index(os.path.join(root, 'bench.py')) + 1:]
+    assert tail == ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
