@@ -26,6 +26,9 @@
 #include "../../scripts/experiments/kh_tile64q4.h"
 #endif
 #include "kh_coop.h"
+#ifdef KH_WITH_C4W  // experiment build only (scripts/experiments/kh_coop4w.h: rows over waves, measured slower)
+#include "../../scripts/experiments/kh_coop4w.h"
+#endif
 #include "kh_mini.h"
 
 static thread_local std::string g_last_error;
@@ -65,6 +68,12 @@ struct kh_engine {
     size_t coop_vbuf_bytes = 0;
     // update sums on the adjoint side (kh_coop_adjoint_side): H_1^+ chi for the whole store, formed in front of the
     // update sweep; KH_COOP_NO_ADJ=1: the sums by one more round per interval, as for second order / two controls
+    // experiment (-DKH_WITH_C4W builds, KH_COOP4W=1; scripts/experiments/kh_coop4w.h): four waves per workgroup, a wave
+    // owns four rows for the whole k range; plain sweeps only; measured slower than the k-split kernels
+    bool coop4w = false;
+    int c4_NG = 0;  // groups of 16 columns
+    const cplx **d_c4_fops_fw = nullptr, **d_c4_fops_bw = nullptr;  // [2] H0, H1 in kh_coop4w.h's fragment order
+    const cplx **d_c4_sq_fw = nullptr, **d_c4_sq_bw = nullptr;      // [3] P0, P1, P2
     bool coop_adj = false;
     unsigned char *d_coop_adj_nz = nullptr;  // [G][G] non-zero 16 x 16 blocks of H_1^+
     cplx *d_coop_adj = nullptr;              // [K][nt][N], allocated by the first update sweep
@@ -237,6 +246,10 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree((void *)e->d_coop_fops_bw);
     (void)hipFree((void *)e->d_coop_sq_fw);
     (void)hipFree((void *)e->d_coop_sq_bw);
+    (void)hipFree((void *)e->d_c4_fops_fw);
+    (void)hipFree((void *)e->d_c4_fops_bw);
+    (void)hipFree((void *)e->d_c4_sq_fw);
+    (void)hipFree((void *)e->d_c4_sq_bw);
     (void)hipFree((void *)e->d_sq_fw);
     (void)hipFree((void *)e->d_sq_bw);
     (void)hipFree(e->d_phi);
@@ -579,6 +592,49 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             }
         }
         KH_HIP_E(hipGetLastError());
+#ifdef KH_WITH_C4W
+        if (coop_sq && e->coop_cols == 2 && e->L == 1 && bw[1] != nullptr && kh_c4_groups(e->N) <= 30 &&
+            getenv("KH_COOP4W") != nullptr && atoi(getenv("KH_COOP4W")) != 0) {
+            // the same five tables in the fragment order of kh_coop4w.h
+            const int NG = kh_c4_groups(e->N);
+            const size_t elems = kh_c4_table_elems(e->coop_G, NG), frag = (size_t)e->coop_G * KH_C4_WAVES * NG * 64;
+            std::map<const void *, const cplx *> perm4;
+            auto permuted4 = [&](const cplx *src, const cplx **out) -> hipError_t {
+                *out = nullptr;
+                if (src == nullptr) return hipSuccess;
+                auto it = perm4.find(src);
+                if (it == perm4.end()) {
+                    cplx *dst = nullptr;
+                    const hipError_t err = hipMalloc(&dst, sizeof(cplx) * elems + sizeof(unsigned int) * e->coop_G * KH_C4_WAVES);
+                    if (err != hipSuccess) return err;
+                    e->owned.push_back(dst);
+                    const hipError_t merr = hipMemset(dst, 0, sizeof(cplx) * elems);
+                    if (merr != hipSuccess) return merr;
+                    kh_c4_permute_kernel<<<(unsigned)((frag + 255) / 256), 256>>>(src, dst, e->N, e->coop_G, NG);
+                    kh_c4_mask_kernel<<<e->coop_G * KH_C4_WAVES, 64>>>(dst, (unsigned int *)(dst + elems), NG);
+                    it = perm4.emplace(src, dst).first;
+                }
+                *out = it->second;
+                return hipSuccess;
+            };
+            for (int dir = 0; dir < 2; ++dir) {
+                const std::vector<const cplx *> &tab = dir == 0 ? fw : bw;
+                std::vector<const cplx *> fops(2, nullptr), sq3(3, nullptr), nat(3, nullptr);
+                for (int o = 0; o < 2; ++o) KH_HIP_E(permuted4(tab[o], &fops[o]));
+                KH_HIP_E(hipMemcpy(nat.data(), dir == 0 ? e->d_sq_fw : e->d_sq_bw, sizeof(cplx *) * 3, hipMemcpyDeviceToHost));
+                for (int i = 0; i < 3; ++i) KH_HIP_E(permuted4(nat[i], &sq3[i]));
+                const cplx ***fslot = dir == 0 ? &e->d_c4_fops_fw : &e->d_c4_fops_bw;
+                const cplx ***sslot = dir == 0 ? &e->d_c4_sq_fw : &e->d_c4_sq_bw;
+                KH_HIP_E(hipMalloc((void **)fslot, sizeof(cplx *) * 2));
+                KH_HIP_E(hipMemcpy((void *)*fslot, fops.data(), sizeof(cplx *) * 2, hipMemcpyHostToDevice));
+                KH_HIP_E(hipMalloc((void **)sslot, sizeof(cplx *) * 3));
+                KH_HIP_E(hipMemcpy((void *)*sslot, sq3.data(), sizeof(cplx *) * 3, hipMemcpyHostToDevice));
+            }
+            KH_HIP_E(hipGetLastError());
+            e->coop4w = true;
+            e->c4_NG = NG;
+        }
+#endif
         if (coop_sq && bw[1] != nullptr && !(getenv("KH_COOP_NO_ADJ") && atoi(getenv("KH_COOP_NO_ADJ")))) {
             e->coop_adj = true;
             e->coop_adj_op = bw[1];
@@ -760,6 +816,31 @@ static int launch_coop_placed(kh_engine *e, Launch &&launch) {
     return rc;
 }
 
+#ifdef KH_WITH_C4W
+static KhCoopArgs c4_args(const kh_engine *e, bool backward) {
+    KhCoopArgs c = coop_args(e, backward);
+    c.fops = backward ? e->d_c4_fops_bw : e->d_c4_fops_fw;
+    c.sq = backward ? e->d_c4_sq_bw : e->d_c4_sq_fw;
+    c.ks = e->c4_NG;
+    return c;
+}
+
+template <int MAXG>
+static int launch_c4_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
+                           cplx *out, int direction, hipStream_t st) {
+    const size_t lds = kh_c4_lds_bytes(MAXG);
+    const int rc = ensure_dynamic_lds(e, (const void *)kh_c4_sweep_store<MAXG>, lds);
+    if (rc != KH_OK) return rc;
+    KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
+    KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
+    return launch_coop_placed(e, [&](dim3 grid) {
+        return launch_persistent(kh_c4_sweep_store<MAXG>, grid, dim3(KH_C4_THREADS), lds, st, p, c4_args(e, direction < 0),
+                                 exchange_args(e, true), pulses, in, store, out, direction);
+    });
+}
+
+#endif
+
 template <int MAXKS, int COLS>
 static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
                              cplx *out, int direction, hipStream_t st) {
@@ -833,6 +914,17 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         rc = dispatch_tile_store<2>(e, p, pulses, in, store, out, direction, st);
     } else if (e->kind_store == KIND_TILE_RPT1) {
         rc = dispatch_tile_store<1>(e, p, pulses, in, store, out, direction, st);
+#ifdef KH_WITH_C4W
+    } else if (e->kind_store == KIND_COOP && e->coop4w) {
+        rc = e->c4_NG <= 8    ? launch_c4_store<8>(e, p, pulses, in, store, out, direction, st)
+             : e->c4_NG <= 16 ? launch_c4_store<16>(e, p, pulses, in, store, out, direction, st)
+             : e->c4_NG <= 26 ? launch_c4_store<26>(e, p, pulses, in, store, out, direction, st)
+                              : launch_c4_store<30>(e, p, pulses, in, store, out, direction, st);
+        if (rc == KH_ERR_UNSUPPORTED) {
+            e->kind_store = KIND_GENERIC;
+            return sweep_store(e, backward, pulses, in, store, out, st);
+        }
+#endif
     } else if (e->kind_store == KIND_COOP) {
         if (e->coop_cols == 2)
             rc = e->coop_ks <= 8 ? launch_coop_store<8, 2>(e, p, pulses, in, store, out, direction, st)
