@@ -213,8 +213,10 @@ struct KhTileOps {
 // (it also keeps chi, the partial sums and, second order, phi_prev), the plain sweep one for L = 4
 template <int RPT, int LT>
 struct KhTileLds {
-    static constexpr int UPDATE = (RPT == 1 && LT >= 3) ? LT - 2 : 0;
-    static constexpr int STORE = (RPT == 1 && LT >= 4) ? 1 : 0;
+    // RPT = 2 (256-thread workgroups, two per CU, K > #CUs): a tile is 64 VGPRs per lane there, so with one control the
+    // drift is parked as well (64 KiB per workgroup, 128 KiB per CU) -- generator + control + broadcast vector then fit
+    static constexpr int UPDATE = (RPT == 1 && LT >= 3) ? LT - 2 : (RPT == 2 && LT == 1) ? 1 : 0;
+    static constexpr int STORE = (RPT == 1 && LT >= 4) ? 1 : (RPT == 2 && LT == 1) ? 1 : 0;
     static constexpr size_t bytes(int nl) { return (size_t)nl * KH_TILE_N * KH_TILE_N * sizeof(cplx); }
 };
 
