@@ -185,7 +185,7 @@ static int check_residency(const kh_engine *e, const void *func, int threads, si
     return KH_OK;
 }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.3 (gfx950; tile64q2, tile64, mini16, mini4, coop16/mfma, generic, generic/csr kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.4 (gfx950; tile64q2, tile64, mini16, mini4, coop16/mfma, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
