@@ -102,11 +102,25 @@ class Result:
             out.append(new)
         return out
 
-    def dump(self, filename):
+    def dump(self, filename, reference=False):
         """Pickle the result.  Controls that are Python functions cannot be
         pickled: in the stored objectives they are replaced by
         :class:`ControlPlaceholder` s (pass the objectives again to
-        :meth:`load`), as in the reference (result.py:247-262)."""
+        :meth:`load`), as in the reference (result.py:247-262).
+
+        ``reference=True`` writes the file in the reference's own format
+        instead -- a pickled ``krotov.result.Result`` whose objectives are
+        reduced through ``krotov.objectives._Objective_reduce_init`` and whose
+        function controls are ``krotov.objectives._ControlPlaceholder`` s
+        (result.py:247-262, objectives.py:581-636) -- with every state and
+        operator as a NumPy array: the reference reads it with
+        ``krotov.result.Result.load(filename, objectives=...)`` in its NumPy
+        mode (``krotov.Objective.type_checking = False``, reference notebook
+        09), e.g. to continue there an optimisation that was run here.  Neither
+        ``krotov`` nor ``qutip`` is needed to write it; :meth:`load` reads it
+        back as well."""
+        if reference:
+            return _dump_reference(self, filename)
         clone = copy.copy(self)
         clone.objectives = []
         for obj in self.objectives:
@@ -271,3 +285,122 @@ def _without_qobj(value):
         for k, v in list(value.__dict__.items()):
             setattr(value, k, _without_qobj(v))
     return value
+
+
+# ---------------------------------------------------------------------------
+# dumps the reference can load (Result.dump(..., reference=True))
+# ---------------------------------------------------------------------------
+def _plain(value):
+    """``value`` in terms of what a process without this package unpickles: NumPy arrays, Python scalars, lists,
+    tuples, dicts (states / operators -> arrays; lazy state lists -> lists)."""
+    from ._ingest import to_dense
+
+    if value is None or isinstance(value, (bool, int, float, complex, str, bytes, time.struct_time)):
+        return value
+    if isinstance(value, np.generic):
+        return value.item()
+    if isinstance(value, np.ndarray):
+        return value if value.dtype != object else [_plain(v) for v in value]
+    if isinstance(value, dict):
+        return {k: _plain(v) for k, v in value.items()}
+    if isinstance(value, tuple):
+        return tuple(_plain(v) for v in value)
+    if isinstance(value, list) or (hasattr(value, '__len__') and hasattr(value, '__getitem__') and not hasattr(value, 'shape')
+                                   and not hasattr(value, 'full')):
+        return [_plain(value[i]) for i in range(len(value))]
+    if hasattr(value, 'full') or hasattr(value, 'shape') or hasattr(value, 'toarray'):
+        return np.asarray(to_dense(value))
+    return value  # (a user's own picklable object, e.g. an info_hook's return value)
+
+
+def _dump_reference(result, filename):
+    import sys
+    import types
+
+    # Stand-ins that pickle BY REFERENCE under the reference's names: the file then contains the global names
+    # krotov.result.Result, krotov.objectives._Objective_reduce_init and krotov.objectives._ControlPlaceholder, which a
+    # process that has the reference installed resolves to the real things.
+    mod_result, mod_obj, mod_top = (types.ModuleType(n) for n in ('krotov.result', 'krotov.objectives', 'krotov'))
+
+    class RefResult:
+        pass
+
+    class RefPlaceholder:
+        def __init__(self, id):
+            self.id = id
+
+    def ref_reduce_init(initial_state, H, target, c_ops):  # (never called here: only its name is written)
+        raise RuntimeError("stand-in for krotov.objectives._Objective_reduce_init")
+
+    RefResult.__module__, RefResult.__qualname__, RefResult.__name__ = 'krotov.result', 'Result', 'Result'
+    RefPlaceholder.__module__, RefPlaceholder.__qualname__ = 'krotov.objectives', '_ControlPlaceholder'
+    RefPlaceholder.__name__ = '_ControlPlaceholder'
+    ref_reduce_init.__module__, ref_reduce_init.__qualname__ = 'krotov.objectives', '_Objective_reduce_init'
+    ref_reduce_init.__name__ = '_Objective_reduce_init'
+    mod_result.Result = RefResult
+    mod_obj._ControlPlaceholder, mod_obj._Objective_reduce_init = RefPlaceholder, ref_reduce_init
+    mod_top.result, mod_top.objectives = mod_result, mod_obj
+
+    class ObjectiveOut:
+        """Pickles like the reference's ``_Objective_reduce`` (objectives.py:588-611)."""
+
+        def __init__(self, obj):
+            def nested(lst):
+                if isinstance(lst, list):
+                    return [nested(v) for v in lst]
+                if isinstance(lst, ControlPlaceholder):
+                    return RefPlaceholder(lst.id)
+                if callable(lst) and not hasattr(lst, 'shape') and not hasattr(lst, 'full'):
+                    return RefPlaceholder(id(lst))  # (the reference uses id() as well)
+                return _plain(lst)
+
+            self.args = (_plain(obj.initial_state), nested(obj.H), _plain(obj.target), nested(list(obj.c_ops)))
+            self.extra = {k: _plain(v) for k, v in obj.__dict__.items() if k not in obj._default_attribs}
+
+        def __reduce__(self):
+            return (ref_reduce_init, self.args, self.extra)
+
+    out = RefResult()
+    for name in _FIELDS:
+        value = getattr(result, name)
+        out.__dict__[name] = [ObjectiveOut(o) for o in value] if name == 'objectives' else _plain(value)
+    out.tlist = np.asarray(result.tlist, dtype=np.float64)
+    out.guess_controls = [np.asarray(c) for c in result.guess_controls]
+    out.optimized_controls = [np.asarray(c) for c in result.optimized_controls]
+    out.start_local_time, out.end_local_time, out.message = result.start_local_time, result.end_local_time, result.message
+    # Arrays are written with the reconstruction function under its NumPy-1 name, numpy.core.multiarray._reconstruct:
+    # the reference's environment (QuTiP 4) has NumPy 1.x, which knows no numpy._core; NumPy 2 still resolves the old name.
+    mod_np = types.ModuleType('numpy.core.multiarray')
+
+    def np_reconstruct(*args):  # (never called here: only its name is written)
+        raise RuntimeError("stand-in for numpy.core.multiarray._reconstruct")
+
+    np_reconstruct.__module__, np_reconstruct.__qualname__ = 'numpy.core.multiarray', '_reconstruct'
+    np_reconstruct.__name__ = '_reconstruct'
+    mod_np._reconstruct = np_reconstruct
+
+    class RefPickler(pickle.Pickler):
+        def reducer_override(self, obj):
+            if type(obj) is np.ndarray:
+                red = obj.__reduce__()
+                return (np_reconstruct,) + tuple(red[1:])
+            return NotImplemented
+
+    names = ('krotov', 'krotov.result', 'krotov.objectives', 'numpy.core.multiarray')
+    saved = {n: sys.modules.get(n) for n in names}
+    try:
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')  # (NumPy 2 warns when its numpy.core shim is imported)
+            importlib.import_module('numpy.core')
+            sys.modules.update({'krotov': mod_top, 'krotov.result': mod_result, 'krotov.objectives': mod_obj,
+                                'numpy.core.multiarray': mod_np})
+            with open(filename, 'wb') as fh:
+                RefPickler(fh, protocol=2).dump(out)
+    finally:
+        for name, module in saved.items():
+            if module is None:
+                sys.modules.pop(name, None)
+            else:
+                sys.modules[name] = module

@@ -1,0 +1,117 @@
+"""Result.dump(..., reference=True): a dump the REFERENCE can load (write direction).
+
+Part 1 runs anywhere (no GPU, no reference): the file names only classes / functions that exist in an environment
+with the reference and NumPy 1.x or 2.x installed, and this package's own Result.load reads it back.
+
+Part 2 runs where the reference's sources are present (this build container: /root/reference; never the GPU box): a
+separate process imports the REAL ``krotov`` package (QuTiP & friends stubbed, as tests/golden/make_reference_goldens.py
+does), loads the file with the reference's own ``krotov.result.Result.load`` and CONTINUES the optimisation with the
+reference's own ``optimize_pulses(..., continue_from=...)``; the pulses it arrives at must be the ones this package
+arrives at when it continues the same result itself."""
+import os
+import pickletools
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import krotov_amd
+from krotov_amd import configs
+
+from helpers import numpy_plugins
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = '/root/reference/src/krotov'
+
+ALLOWED_GLOBALS = {
+    'krotov.result Result', 'krotov.objectives _Objective_reduce_init', 'krotov.objectives _ControlPlaceholder',
+    'numpy.core.multiarray _reconstruct', 'numpy ndarray', 'numpy dtype', 'time struct_time', '_codecs encode',
+    '__builtin__ complex', 'builtins complex',
+}
+
+
+def _run_here(spec, iter_stop, continue_from=None):
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    prop, mu, overlap = numpy_plugins(spec.is_super)
+    return objectives, krotov_amd.optimize_pulses(
+        objectives, pulse_options, spec.tlist, propagator=prop,
+        chi_constructor=getattr(krotov_amd.functionals, 'chis_' + spec.chi), mu=mu, overlap=overlap,
+        norm=np.linalg.norm, iter_stop=iter_stop, store_all_pulses=True, continue_from=continue_from)
+
+
+@pytest.mark.parametrize('name', ['c1', 'c5_L3'])
+def test_reference_format_dump_names_only_reference_classes(name, tmp_path):
+    spec = configs.config_c1(nt=80) if name == 'c1' else configs.config_c5(K=3, N=6, nt=41, L=3, distinct=True)
+    objectives, res = _run_here(spec, 2)
+    path = str(tmp_path / 'result.dump')
+    res.dump(path, reference=True)
+    names = {arg for op, arg, _ in pickletools.genops(open(path, 'rb').read()) if op.name == 'GLOBAL'}
+    assert names <= ALLOWED_GLOBALS, names - ALLOWED_GLOBALS
+    assert {'krotov.result Result', 'krotov.objectives _Objective_reduce_init',
+            'krotov.objectives _ControlPlaceholder'} <= names
+    assert 'krotov' not in sys.modules  # (the stand-in modules of the dump are gone again)
+    back = krotov_amd.result.Result.load(path, objectives=objectives)
+    assert back.iters == res.iters and back.message == res.message
+    assert np.array_equal(np.array(back.optimized_controls), np.array(res.optimized_controls))
+    assert np.array_equal(np.array(back.all_pulses), np.array(res.all_pulses))
+    assert np.allclose(np.array(back.tau_vals, dtype=complex), np.array(res.tau_vals, dtype=complex), atol=0, rtol=0)
+    assert np.array_equal(back.tlist, spec.tlist)
+    # without `objectives`: the stored ones come back with placeholders where the control functions were
+    stored = krotov_amd.result.Result.load(path)
+    assert len(stored.objectives) == spec.K
+    assert isinstance(stored.objectives[0].H[1][1], krotov_amd.result.ControlPlaceholder)
+    assert np.array_equal(np.asarray(stored.objectives[0].H[0]), np.asarray(objectives[0].H[0]))
+
+
+_CHILD = textwrap.dedent('''
+    import sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r}); sys.path.insert(0, {golden!r})
+    import numpy as np
+    import make_reference_goldens as gen          # the committed generator: imports the REAL reference with stubs
+    from krotov_amd import configs
+    krotov = gen.import_reference_krotov()         # (sets krotov.Objective.type_checking = False: NumPy mode)
+    spec = {spec_expr}
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov)
+    res = krotov.result.Result.load({path!r}, objectives=objectives)
+    assert type(res).__module__ == 'krotov.result' and res.iters == [0, 1, 2], res.iters
+    assert res.message == 'Reached 2 iterations' and len(res.optimized_controls) == spec.L
+    assert isinstance(res.tlist, np.ndarray) and len(res.tau_vals) == 3 and len(res.all_pulses) == 3
+    import scipy.linalg as la
+    f0 = (1.0 + 0j) if spec.is_super else -1j
+    def expm(H, state, dt, c_ops=None, backwards=False, initialize=False):
+        f = f0.conjugate() if backwards else f0
+        A = f * H[0]
+        for part in H[1:]:
+            A = A + (f * part[1]) * part[0]
+        return la.expm(A * dt) @ state
+    def mu(objs, i_obj, pulses, mapping, i_pulse, n):
+        op = objs[i_obj].H[1 + i_pulse][0]
+        return (lambda s: 1j * (op @ s)) if spec.is_super else (lambda s: op @ s)
+    out = krotov.optimize_pulses(
+        objectives, pulse_options, spec.tlist, propagator=expm,
+        chi_constructor=getattr(krotov.functionals, 'chis_' + spec.chi), mu=mu,
+        overlap=lambda a, b: complex(np.vdot(a, b)), norm=np.linalg.norm, iter_stop=4, continue_from=res,
+        store_all_pulses=True)
+    assert out.iters == [0, 1, 2, 3, 4], out.iters
+    np.save({out!r}, np.array(out.optimized_controls))
+''')
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference's sources (build container only)")
+@pytest.mark.parametrize('name', ['c1', 'c5_L3'])
+def test_the_reference_loads_the_dump_and_continues_it(name, tmp_path):
+    spec_expr = "configs.config_c1(nt=80)" if name == 'c1' else "configs.config_c5(K=3, N=6, nt=41, L=3, distinct=True)"
+    spec = eval(spec_expr)
+    objectives, res = _run_here(spec, 2)
+    path, out = str(tmp_path / 'result.dump'), str(tmp_path / 'continued.npy')
+    res.dump(path, reference=True)
+    child = _CHILD.format(root=ROOT, tests=os.path.join(ROOT, 'tests'), golden=os.path.join(ROOT, 'tests', 'golden'),
+                          spec_expr=spec_expr, path=path, out=out)
+    proc = subprocess.run([sys.executable, '-c', child], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    theirs = np.load(out)
+    _, mine = _run_here(spec, 4, continue_from=krotov_amd.result.Result.load(path, objectives=objectives))
+    assert mine.iters == [0, 1, 2, 3, 4]
+    assert np.abs(theirs - np.array(mine.optimized_controls)).max() < 1e-12 * max(1.0, np.abs(theirs).max())
