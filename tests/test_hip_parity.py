@@ -1068,6 +1068,16 @@ def test_dump_result_and_continue_on_device(tmp_path):
     assert list(cont.iters) == list(range(5))
     assert np.abs(np.array(cont.all_pulses[3:]) - np.array(scratch.all_pulses[3:])).max() < 1e-12
     assert np.abs(np.array(cont.tau_vals[3:]) - np.array(scratch.tau_vals[3:])).max() < 1e-12
+    # the same result written in the REFERENCE's dump format (krotov.result.Result, NumPy mode; the device-backed states
+    # are fetched for it) and read back: identical fields, and the continuation from it ends where the other one does
+    ref_path = str(tmp_path / 'oct_reference_format.dump')
+    res.dump(ref_path, reference=True)
+    again = krotov_amd.result.Result.load(ref_path, objectives=objectives)
+    assert list(again.iters) == [0, 1, 2] and again.message == res.message
+    assert np.array_equal(np.array(again.optimized_controls), np.array(res.optimized_controls))
+    assert np.abs(np.array([np.asarray(x) for x in again.states]) - np.array([np.asarray(x) for x in res.states])).max() == 0.0
+    cont2 = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=4, continue_from=again, **kw)
+    assert np.array_equal(np.array(cont2.all_pulses[3:]), np.array(cont.all_pulses[3:]))
 
 
 def test_two_update_sweeps_on_two_streams():
