@@ -134,11 +134,12 @@ def check_monotonic_fidelity(result):
     return _fidelity_increase(result)
 
 
-def dump_result(filename, every=10):
+def dump_result(filename, every=10, reference=False):
     """A ``check_convergence`` that never stops the optimisation but writes
     ``result.dump(filename.format(iter=...))`` every ``every`` iterations; if the
     file cannot be written the message ``"Could not store <file>: <error>"`` is
-    returned, which ends the optimisation."""
+    returned, which ends the optimisation.  ``reference=True`` (extension): the
+    files are written in the reference's own dump format (:meth:`.Result.dump`)."""
     every = int(every)
     if every <= 0:
         raise ValueError("every must be > 0")
@@ -149,7 +150,7 @@ def dump_result(filename, every=10):
             outfile = filename.format(iter=iteration)
             logging.getLogger('krotov').info("Dumping result to %s", outfile)
             try:
-                result.dump(outfile)
+                result.dump(outfile, reference=True) if reference else result.dump(outfile)
             except IOError as exc_info:
                 return "Could not store %s: %s" % (outfile, exc_info)
         return None

@@ -118,7 +118,11 @@ class Result:
         mode (``krotov.Objective.type_checking = False``, reference notebook
         09), e.g. to continue there an optimisation that was run here.  Neither
         ``krotov`` nor ``qutip`` is needed to write it; :meth:`load` reads it
-        back as well."""
+        back as well.  (While the file is written, stand-in modules named
+        ``krotov``, ``krotov.result``, ``krotov.objectives`` and
+        ``numpy.core.multiarray`` sit in ``sys.modules``: do not import or
+        unpickle from other threads at that moment.  Values of ``info_vals``
+        that are instances of your own classes are pickled as they are.)"""
         if reference:
             return _dump_reference(self, filename)
         clone = copy.copy(self)
