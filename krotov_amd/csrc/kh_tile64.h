@@ -401,11 +401,9 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
                     c_fma_conj(ov, bra, y[r]);
                 }
             }
-            const double re = sum64(ov.x), im = sum64(ov.y);
-            if (lane == 0) {
-                red[par][wave][l][0] = re;
-                red[par][wave][l][1] = im;
-            }
+            // Im(mu <bra | H_l phi>) needs only one real combination: reduce that, not both parts
+            const double v = sum64(u.mu_re * ov.y + u.mu_im * ov.x);
+            if (lane == 0) red[par][wave][l][0] = v;
         }
         matvecs += LT;
     };
@@ -413,13 +411,10 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     auto partial_total = [&](int par, double (&part)[LT]) {
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
-            double re = 0.0, im = 0.0;
+            double acc = 0.0;
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                re += red[par][w][l][0];
-                im += red[par][w][l][1];
-            }
-            part[l] = chi_norm * (u.mu_re * im + u.mu_im * re);
+            for (int w = 0; w < WAVES; ++w) acc += red[par][w][l][0];
+            part[l] = chi_norm * acc;
         }
     };
 
