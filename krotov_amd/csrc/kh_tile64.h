@@ -402,7 +402,8 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
                 }
             }
             // Im(mu <bra | H_l phi>) needs only one real combination: reduce that, not both parts
-            const double v = sum64(u.mu_re * ov.y + u.mu_im * ov.x);
+            // (the value is zero except on the 8 writer lanes: the matrix core adds those, kh_tile64.h "Lane roles")
+            const double v = KhLanes<true>::writers_sum(u.mu_re * ov.y + u.mu_im * ov.x);
             if (lane == 0) red[par][wave][l][0] = v;
         }
         matvecs += LT;
