@@ -106,6 +106,17 @@ __device__ __forceinline__ double sum64(double v) {
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
+// The same sum on the matrix core: v_mfma_f64_4x4x4 with a constant B operand adds its A operand over the four lanes
+// 16 k + i; two row rotations add the four 4-lane blocks of a 16-lane row (every lane of row r then holds the sum over
+// the lanes 16 k + 4 blk + r); a second MFMA adds the four rows.  2 MFMA + 6 VALU instead of the butterfly's 12 DPP
+// moves, 6 adds and 8 read-lanes; every lane ends up with the total (fixed order: deterministic).
+__device__ __forceinline__ double sum64_mfma(double v) {
+    double d = __builtin_amdgcn_mfma_f64_4x4x4f64(v, 1.0, 0.0, 0, 0, 0);
+    d += dpp_move<KH_DPP_ROR8>(d);
+    d += dpp_move<KH_DPP_ROR4>(d);
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(d, 1.0, 0.0, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------
 // Taylor degree selection
 // ---------------------------------------------------------------------------

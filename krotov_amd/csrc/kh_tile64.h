@@ -193,6 +193,16 @@ struct KhTileOps {
                 a[r][j] = v;
             }
     }
+    // this lane's share of (op[o] x)[row]: its 8 columns only, NOT summed over the row's lanes; xv = x[cg + 8 j]
+    __device__ __forceinline__ void matvec_part(int o, const cplx (&xv)[8], cplx (&y)[RPT]) const {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            cplx acc = c_make(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c_fma(acc, at(o, r, j), xv[j]);
+            y[r] = acc;
+        }
+    }
     // y = op[o] x, reduced over the row's 8 lanes
     __device__ __forceinline__ void matvec(int o, const cplx *x, int cg, cplx (&y)[RPT]) const {
         cplx xv[8];
@@ -384,26 +394,29 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     };
 
     // wave-level pieces of  chi_norm * Im(mu <chi(t_n) | H_l phi>)  -> red[par][wave]; phi in buf[cur]
+    // The broadcast vector is read ONCE for all L controls, and no product is summed over its row: chi (and the
+    // second-order bra) is replicated over the row's 8 lanes, so every lane multiplies its own 8-column share with the
+    // bra and ONE 64-lane sum per control (on the matrix core) adds shares and rows together.
     auto partial_pieces = [&](int par) {
+        cplx xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = buf[cur][cg + 8 * j];
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
             cplx y[RPT];
-            h.matvec(1 + l, buf[cur], cg, y);
+            h.matvec_part(1 + l, xv, y);
             cplx ov = c_make(0.0, 0.0);
-            if (writer) {
 #pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    // second order: the bra is chi + hs (phi - phi_prev)
-                    cplx bra = chi[r];
-                    if constexpr (SO)
-                        bra = c_make(fma(hs, state[r].x - prev[r].x, chi[r].x),
-                                     fma(hs, state[r].y - prev[r].y, chi[r].y));
-                    c_fma_conj(ov, bra, y[r]);
-                }
+            for (int r = 0; r < RPT; ++r) {
+                // second order: the bra is chi + hs (phi - phi_prev)
+                cplx bra = chi[r];
+                if constexpr (SO)
+                    bra = c_make(fma(hs, state[r].x - prev[r].x, chi[r].x),
+                                 fma(hs, state[r].y - prev[r].y, chi[r].y));
+                c_fma_conj(ov, bra, y[r]);
             }
             // Im(mu <bra | H_l phi>) needs only one real combination: reduce that, not both parts
-            // (the value is zero except on the 8 writer lanes: the matrix core adds those, kh_tile64.h "Lane roles")
-            const double v = KhLanes<true>::writers_sum(u.mu_re * ov.y + u.mu_im * ov.x);
+            const double v = sum64_mfma(u.mu_re * ov.y + u.mu_im * ov.x);
             if (lane == 0) red[par][wave][l][0] = v;
         }
         matvecs += LT;
