@@ -454,6 +454,56 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
     return true;
 }
 
+// The gather of ONE control out of L (slot layout [wg][L][2]): several controls are gathered by several waves side by
+// side (kh_tile64.h) -- a wave that polls 8 L granules per lane for all controls at once pays for every failed round
+// with L times the loads.  Same summation order as kh_gather.
+template <int CH = KH_GATHER_CHUNKS>
+__device__ __forceinline__ bool kh_gather_one(const KhExchange &ex, int parity, int L, int l, unsigned int epoch, int lane,
+                                              double &out) {
+    const kh_u64 *base = ex.slots + (size_t)parity * ex.G * L * 2;
+    kh_u64 a[CH], b[CH];
+    long long t0 = 0;
+    unsigned int spins = 0;
+    for (int d = 0; d < ex.first_poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int wg = lane + 64 * c;
+            if (wg < ex.G) {
+                const kh_u64 *g = base + ((size_t)wg * L + l) * 2;
+                a[c] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b[c] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                a[c] = b[c] = (kh_u64)epoch << 32;  // neutral: tag ok, value +0.0
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            ok = ok && ((unsigned int)(a[c] >> 32) == epoch) && ((unsigned int)(b[c] >> 32) == epoch);
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (spins == 0) t0 = wall_clock64();
+        if ((++spins & 255u) == 0) {  // wave-uniform
+            const bool gave_up =
+                (wall_clock64() - t0 > ex.timeout_ticks) ||
+                (__hip_atomic_load(ex.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+            if (__any(gave_up)) {
+                if (lane == 0) __hip_atomic_store(ex.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const kh_u64 bits = ((a[c] & 0xffffffffull) << 32) | (b[c] & 0xffffffffull);
+        acc += __longlong_as_double((long long)bits);
+    }
+    out = sum64(acc);
+    return true;
+}
+
 // ---- cross-GPU stage -------------------------------------------------------
 __device__ __forceinline__ void kh_p2p_publish(const KhExchange &ex, int parity, int L, int lane,
                                                const double *values, unsigned int epoch) {

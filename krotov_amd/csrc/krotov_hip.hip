@@ -114,7 +114,8 @@ struct kh_engine {
     double last_intervals = 0, last_wgs = 0;
     std::set<const void *> lds_raised;  // kernels whose dynamic-LDS limit was raised on this engine's device
     // tuning knobs (s_sleep units of 64 cycles), read from the environment once at creation
-    int poll_delay = 16;       // KH_POLL_DELAY: head start of the update-sum stores, ~0.4 us: measured best
+    int poll_delay = 16;       // KH_POLL_DELAY: head start of the update-sum stores, ~0.4 us: measured best (one control)
+    bool poll_delay_set = false;  // ... given in the environment: several controls do not apply their own default then
     int adj_poll_delay = 0;    // KH_ADJ_DELAY: the same where a matrix-vector product already sits between store and poll
     int coop_poll_delay = 0;   // KH_COOP_DELAY: the same for the cooperative kernels' block exchange (a polling pass is four
                                // 16-byte loads per lane there: an early, stale pass costs little -- measured 0 best)
@@ -413,7 +414,10 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         g_coop_launch = d == nullptr || atoi(d) != 0;
     }
     if (const char *d = getenv("KH_Q4")) e->use_q4 = atoi(d) != 0;
-    if (const char *d = getenv("KH_POLL_DELAY")) e->poll_delay = atoi(d);
+    if (const char *d = getenv("KH_POLL_DELAY")) {
+        e->poll_delay = atoi(d);
+        e->poll_delay_set = true;
+    }
     if (const char *d = getenv("KH_ADJ_DELAY")) e->adj_poll_delay = atoi(d);
     if (const char *d = getenv("KH_COOP_DELAY")) e->coop_poll_delay = atoi(d);
     if (const char *d = getenv("KH_TIMEOUT_MS"))  // e.g. under a profiler that slows the kernels down
@@ -984,9 +988,14 @@ static int launch_tile_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
             kh_tile_forward_update<RPT, LT, false><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
         return KH_OK;
     }
+    KhExchange exl = ex;
+    // several controls: L waves gather side by side (kh_tile64.h) and a failed polling round costs L times the loads,
+    // so the stores get a longer head start -- measured best on config-5 shapes: 24 / 28 / 32 x 64 cycles for L = 2 / 3 / 4
+    // (update sweep 7.47 / - / 9.86 us per interval against 7.92 / - / 11.21 with 16)
+    if (LT >= 2 && !e->poll_delay_set) exl.first_poll_delay = 24 + 4 * (LT - 2);
     if (u.sigma != nullptr)
-        return launch_persistent(kh_tile_forward_update<RPT, LT, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, ex);
-    return launch_persistent(kh_tile_forward_update<RPT, LT, false>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, ex);
+        return launch_persistent(kh_tile_forward_update<RPT, LT, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+    return launch_persistent(kh_tile_forward_update<RPT, LT, false>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
 }
 
 static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
