@@ -156,6 +156,42 @@ def test_kernel_families_agree(name, kernel, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize('L', [2, 3, 4])
+def test_full_gpu_ensemble_with_several_controls_vs_oracle_and_generic(L, monkeypatch):
+    """256 objectives (one workgroup per CU) with L = 2, 3, 4 controls: the register-tile update sweep gathers the L
+    sums over all 256 slots with L waves side by side -- against the oracle on a short time grid (N = 24 keeps the
+    oracle's 256 x 20 x 2 dense expm affordable) and against the generic kernels, which gather with one wave."""
+    spec = configs.config_c5(K=256, N=24, nt=21, L=L, distinct=True)
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 1.0 / (2 * spec.K))
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    out = {}
+    for kernel in ('tile', 'generic'):
+        if kernel == 'generic':
+            monkeypatch.setenv('KH_KERNEL', 'generic')
+        eng = _engine(spec)
+        assert eng.kernel == ('generic' if kernel == 'generic' else 'tile64/512')
+        chi = eng.backward(chi_T, pulses)
+        assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-12
+        opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+        eng.check()
+        out[kernel] = opt.cpu().numpy()
+        assert np.abs(out[kernel] - np.array(ref_opt)).max() < 1e-12 * scale
+        assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+        assert np.abs(g_a.cpu().numpy() - ref_ga).max() < 1e-12 * max(1.0, np.abs(ref_ga).max())
+        # bitwise repeatable (fixed summation order in every gathering wave)
+        opt2, _, _ = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+        eng.check()
+        assert np.array_equal(opt2.cpu().numpy(), out[kernel])
+        eng.close()
+    assert np.abs(out['tile'] - out['generic']).max() < 1e-13 * scale
+
+
 @pytest.mark.parametrize('name', ['c1', 'c2l', 'c3', 'c5_n64', 'c5_n33'])
 def test_q2_update_forward_side_partial_sums(name, monkeypatch):
     """The q2 update sweep normally takes <chi|H phi> on the adjoint side when the control operators are
