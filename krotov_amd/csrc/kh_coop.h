@@ -344,6 +344,7 @@ __device__ __forceinline__ void kh_coop_load2(__amdgpu_buffer_rsrc_t rsrc, unsig
 }
 
 // owner thread: element (row, col) of round `rid`
+template <int COLS>
 __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned int rid, int y, int row, int col,
                                                 cplx v, bool local = false) {
     const kh_u64 tag = (kh_u64)(c.epoch_base + rid) << 32;
@@ -351,7 +352,7 @@ __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned in
 #ifdef KH_COOP_X_NOSTORE
     if (rid > 1) return;
 #endif
-    if (c.cols == 2) {  // (a group is 1 KiB: [lane][2 granules], lane column n = re of objective n / im of objective n - 2)
+    if constexpr (COLS == 2) {  // (a group is 1 KiB: [lane][2 granules], lane column n = re of objective n / im of objective n - 2)
         kh_u64 *g = c.vbuf + kh_coop_group4(c, rid, y, row >> 4) / 2 + 2 * kh_coop4_lane(row & 15, col);
         if (local) {
             __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -366,7 +367,7 @@ __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned in
         }
         return;
     }
-    if (c.cols == 4) {
+    if constexpr (COLS == 4) {
         kh_u64 *g = kh_coop_slot4(c, rid, y, row >> 4) + 2 * kh_coop4_lane(row & 15, col);
         if (local) {
             __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -886,7 +887,7 @@ __device__ __forceinline__ bool kh_coop_expm_action(const KhCoopArgs &c, const K
                 const cplx t = c_mul(c_make(fre * hj, fim * hj), w);
                 state.x += t.x;
                 state.y += t.y;
-                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, j == m ? state : t, c.local != 0);
+                if (owner_valid) kh_coop_publish<COLS>(c, rid + 1, y, row, col, j == m ? state : t, c.local != 0);
             }
             ++rid;
         }
@@ -1007,7 +1008,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
                     sacc.x = fma(hn, t2.x, sacc.x);
                     sacc.y = fma(hn, t2.y, sacc.y);
                 }
-                if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, last ? sacc : t2, c.local != 0);
+                if (owner_valid) kh_coop_publish<COLS>(c, rid + 1, y, row, col, last ? sacc : t2, c.local != 0);
             }
             ++rid;
         }
@@ -1018,7 +1019,7 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             const cplx odd = c_mul(c_make(fre, fim), w);
             state.x += odd.x;
             state.y += odd.y;
-            if (owner_valid) kh_coop_publish(c, rid + 1, y, row, col, state, c.local != 0);
+            if (owner_valid) kh_coop_publish<COLS>(c, rid + 1, y, row, col, state, c.local != 0);
         }
         ++rid;
     }
@@ -1119,7 +1120,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
     const bool has_state = owner_valid && k < p.K;
     cplx state = has_state ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
     unsigned int rid = 1;
-    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state, c.local != 0);
+    if (owner_valid) kh_coop_publish<COLS>(c, rid, y, row, col, state, c.local != 0);
     if (has_state && store != nullptr) store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + row] = state;
     __syncthreads();
     double rounds = 0.0;
@@ -1217,7 +1218,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     cplx state = has_state ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     const double chi_norm = has_state ? u.chi_norms[k] : 0.0;
     unsigned int rid = 1;
-    if (owner_valid) kh_coop_publish(c, rid, y, row, col, state, c.local != 0);
+    if (owner_valid) kh_coop_publish<COLS>(c, rid, y, row, col, state, c.local != 0);
     __syncthreads();
     int rounds = 0;  // (an SGPR counter)
     double g_a_loc[KH_COOP_MAX_L];
