@@ -611,30 +611,42 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)c.vbuf, 0, (int)((size_t)KH_COOP_RING * c.Y * c.G * GB), 0x00020000);
     const unsigned int ring_off = (unsigned int)(kh_coop_group4(c, rid, y, 0) * 8 / (2048u / GB)) + 16u * lane;
-    // first pass through L2 (fast; may see a stale line); padding: tag ok, value +0.0
-#pragma unroll
-    for (int j = 0; j < MAXG; ++j) {
-        const int row = 16 * (start + j) + roff;
-#pragma unroll
-        for (int i = 0; i < NGR; ++i) g[j][i] = (kh_u64)epoch << 32;
+    // first pass through L2 (fast; may see a stale line).  No branch per group: a group this lane has no row in (beyond
+    // the wave's share, or beyond N in the last one) is fetched from beyond the buffer -- the load returns zeros without
+    // touching memory: value +0.0 -- and counts as fresh.
+    const int jv = min(count, (N - roff - 16 * start + 15) >> 4);  // this lane's groups j < jv exist
 #ifndef KH_COOP_X_NOLOAD
-        if (j < count && row < N) {
-            const unsigned int off = ring_off + GB * (start + j);
-            if (c.local) {  // one XCD: its L2 has the producers' stores (agent-scope loads bypass only the L1)
-                kh_coop_load2<KH_CPOL_SC1>(rsrc, off, g[j][0], g[j][1]);
-                if constexpr (COLS == 4) kh_coop_load2<KH_CPOL_SC1>(rsrc, off + 1024u, g[j][2], g[j][3]);
-            } else {
-                kh_coop_load2<KH_CPOL_SC0>(rsrc, off, g[j][0], g[j][1]);
-                if constexpr (COLS == 4) kh_coop_load2<KH_CPOL_SC0>(rsrc, off + 1024u, g[j][2], g[j][3]);
-            }
+    if (c.local) {  // one XCD: its L2 has the producers' stores (agent-scope loads bypass only the L1)
+#pragma unroll
+        for (int j = 0; j < MAXG; ++j) {
+            const unsigned int off = j < jv ? ring_off + GB * (start + j) : 0xffffff00u;
+            kh_coop_load2<KH_CPOL_SC1>(rsrc, off, g[j][0], g[j][1]);
+            if constexpr (COLS == 4) kh_coop_load2<KH_CPOL_SC1>(rsrc, off + (j < jv ? 1024u : 0u), g[j][2], g[j][3]);
         }
-#endif
+    } else {
+#pragma unroll
+        for (int j = 0; j < MAXG; ++j) {
+            const unsigned int off = j < jv ? ring_off + GB * (start + j) : 0xffffff00u;
+            kh_coop_load2<KH_CPOL_SC0>(rsrc, off, g[j][0], g[j][1]);
+            if constexpr (COLS == 4) kh_coop_load2<KH_CPOL_SC0>(rsrc, off + (j < jv ? 1024u : 0u), g[j][2], g[j][3]);
+        }
     }
-    bool all_fresh = true;
+#else
 #pragma unroll
     for (int j = 0; j < MAXG; ++j)
 #pragma unroll
-        for (int i = 0; i < NGR; ++i) all_fresh = all_fresh && ((unsigned int)(g[j][i] >> 32) == epoch);
+        for (int i = 0; i < NGR; ++i) g[j][i] = (kh_u64)epoch << 32;
+#endif
+    // (bitwise, not &&: a short-circuit chain over the tags compiles to nested branches)
+    unsigned int bad_tags = 0u;
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j) {
+        unsigned int bj = 0u;
+#pragma unroll
+        for (int i = 0; i < NGR; ++i) bj |= (unsigned int)(g[j][i] >> 32) ^ epoch;
+        bad_tags |= j < jv ? bj : 0u;
+    }
+    bool all_fresh = bad_tags == 0u;
 #ifdef KH_TIMING
     {
         const int stale_lanes = __popcll(__ballot(!all_fresh));
@@ -655,8 +667,7 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < MAXG; ++j) {
-            const int row = 16 * (start + j) + roff;
-            if (j < count && row < N) {
+            if (j < jv) {
                 const unsigned int off = ring_off + GB * (start + j);
                 if ((unsigned int)(g[j][0] >> 32) != epoch || (unsigned int)(g[j][1] >> 32) != epoch)
                     kh_coop_load2<KH_CPOL_SC1>(rsrc, off, g[j][0], g[j][1]);
@@ -666,10 +677,15 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
                 }
             }
         }
+        unsigned int bad2 = 0u;
 #pragma unroll
-        for (int j = 0; j < MAXG; ++j)
+        for (int j = 0; j < MAXG; ++j) {
+            unsigned int bj = 0u;
 #pragma unroll
-            for (int i = 0; i < NGR; ++i) ok = ok && ((unsigned int)(g[j][i] >> 32) == epoch);
+            for (int i = 0; i < NGR; ++i) bj |= (unsigned int)(g[j][i] >> 32) ^ epoch;
+            bad2 |= j < jv ? bj : 0u;
+        }
+        ok = bad2 == 0u;
         all_fresh = ok;
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(2);
