@@ -1010,8 +1010,10 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             // (the coefficients are fetched before the round, not between its end and the owners' stores; a timed-out
             // round is noticed after the phases: the later rounds give up at once on the abort flag)
             // (read before the round, used after it)
-            const double r2 = kh_uniform(rows != nullptr ? rows[2 * ph + 1] : kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2]);
-            const double r1n = kh_uniform(ph + 1 < phases ? (rows != nullptr ? rows[2 * ph + 2] : kh_inv_table[2 * ph + 3]) : 0.0);
+            // (plain loads, NOT kh_uniform: a read-first-lane would wait for the LDS read here, in front of the round's
+            // block fetch; as it is the read's latency hides under the round)
+            const double r2 = rows != nullptr ? rows[2 * ph + 1] : kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2];
+            const double r1n = ph + 1 < phases ? (rows != nullptr ? rows[2 * ph + 2] : kh_inv_table[2 * ph + 3]) : 0.0;
             cplx w;
             kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, bf, s, tid, wave, lane, w);
             const double c2 = f2h2 * r2, hn = h * r1n;
