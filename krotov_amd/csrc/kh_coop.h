@@ -352,33 +352,33 @@ __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned in
 #ifdef KH_COOP_X_NOSTORE
     if (rid > 1) return;
 #endif
-    if constexpr (COLS == 2) {  // (a group is 1 KiB: [lane][2 granules], lane column n = re of objective n / im of objective n - 2)
-        kh_u64 *g = c.vbuf + kh_coop_group4(c, rid, y, row >> 4) / 2 + 2 * kh_coop4_lane(row & 15, col);
+    if constexpr (COLS == 2 || COLS == 4) {
+        // The element's two granules per part are adjacent: ONE 16-byte store per part ({hi | tag}, {lo | tag}; each
+        // 8-byte granule still carries its own tag) instead of two 8-byte ones.  COLS = 2: a group is 1 KiB,
+        // [lane][2 granules], lane column n = re of objective n / im of objective n - 2; COLS = 4: 2 KiB,
+        // [half: re, im][lane][2 granules].
+        constexpr unsigned int GB = COLS == 4 ? 2048u : 1024u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)c.vbuf, 0, (int)((size_t)KH_COOP_RING * c.Y * c.G * GB), 0x00020000);
+        const unsigned int off = (unsigned int)(kh_coop_group4(c, rid, y, row >> 4) * 8 / (2048u / GB)) +
+                                 16u * (unsigned int)kh_coop4_lane(row & 15, col);
+        const unsigned int t32 = (unsigned int)(tag >> 32);
+        kh_u32x4 vr, vi;
+        vr.x = (unsigned int)(re >> 32);
+        vr.y = t32;
+        vr.z = (unsigned int)(re & 0xffffffffull);
+        vr.w = t32;
+        vi.x = (unsigned int)(im >> 32);
+        vi.y = t32;
+        vi.z = (unsigned int)(im & 0xffffffffull);
+        vi.w = t32;
+        constexpr unsigned int IM = COLS == 4 ? 1024u : 32u;  // bytes from the re granules to the im granules
         if (local) {
-            __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(g + 4, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(g + 5, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_raw_buffer_store_b128(vr, rsrc, (int)off, 0, KH_CPOL_SC0);
+            __builtin_amdgcn_raw_buffer_store_b128(vi, rsrc, (int)(off + IM), 0, KH_CPOL_SC0);
         } else {
-            __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 4, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 5, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    if constexpr (COLS == 4) {
-        kh_u64 *g = kh_coop_slot4(c, rid, y, row >> 4) + 2 * kh_coop4_lane(row & 15, col);
-        if (local) {
-            __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(g + 128, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(g + 129, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            __hip_atomic_store(g + 0, tag | (re >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 1, tag | (re & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 128, tag | (im >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g + 129, tag | (im & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_raw_buffer_store_b128(vr, rsrc, (int)off, 0, KH_CPOL_SC1);
+            __builtin_amdgcn_raw_buffer_store_b128(vi, rsrc, (int)(off + IM), 0, KH_CPOL_SC1);
         }
         return;
     }
