@@ -771,12 +771,18 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
         w = c_make(ar[0] + ar[1] + ar[2] + ar[3], ai[0] + ai[1] + ai[2] + ai[3]);
         return;
 #endif
+        // (the four row blocks' chains step by step side by side, not one after the other: each step is a DPP move whose
+        // result the next instruction needs)
+        double e4[4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            double e = fma(sgn, dpp_move<KH_DPP_XOR2>(ai[rb]), ar[rb]);
-            e += dpp_move<KH_DPP_ROR8>(e);
-            e += dpp_move<KH_DPP_ROR4>(e);
-            if (((lane >> 2) & 3) == 0) part[wave * KH_COOP_PART2 + 16 * rb + 4 * (lane >> 4) + (lane & 3)] = e;
+        for (int rb = 0; rb < 4; ++rb) e4[rb] = fma(sgn, dpp_move<KH_DPP_XOR2>(ai[rb]), ar[rb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) e4[rb] += dpp_move<KH_DPP_ROR8>(e4[rb]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) e4[rb] += dpp_move<KH_DPP_ROR4>(e4[rb]);
+        if (((lane >> 2) & 3) == 0) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) part[wave * KH_COOP_PART2 + 16 * rb + 4 * (lane >> 4) + (lane & 3)] = e4[rb];
         }
     }
 #ifdef KH_TIMING
