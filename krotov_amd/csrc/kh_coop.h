@@ -61,6 +61,14 @@ __device__ __forceinline__ void kh_coop_owner_element(int tid, int &r, int &col)
     }
 }
 
+typedef unsigned int kh_u32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ T *kh_uniform_ptr(T *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+    const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
 struct KhCoopArgs {
     kh_u64 *vbuf;             // cols = 16: [KH_COOP_RING][Y][G*16][4][16] granules; cols = 4: [KH_COOP_RING][Y][G]
                               // [2][64][2], a 16-row group in the CONSUMER's lane order (kh_coop_slot4)
@@ -79,6 +87,9 @@ struct KhCoopArgs {
     const double *ser_rows;   // or NULL: Taylor
     const cplx *const *sq;    // one control only: P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 of this direction's
                               // operators (A^2 = P0 + eps P1 + eps^2 P2) in fragment order, or NULL: term-by-term series
+    const cplx *tab[5];       // (set in the kernel, kh_coop_resolve_tables: fops[0], fops[1], sq[0], sq[1], sq[2] read ONCE,
+                              // as wave-uniform values -- read where they are used, each is a dependent vector load in
+                              // front of the table read it addresses, once per interval and table)
 };
 
 struct KhCoopLds {
@@ -197,6 +208,17 @@ __device__ __forceinline__ unsigned int kh_coop_frag_mask(const cplx *op, int G,
     return __builtin_amdgcn_readfirstlane(m[g * KH_COOP_WAVES + wave]);
 }
 
+__device__ __forceinline__ void kh_coop_resolve_tables(KhCoopArgs &c) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c.tab[i] = nullptr;
+    if (c.sq != nullptr) {
+        c.tab[0] = kh_uniform_ptr(c.fops[0]);
+        c.tab[1] = kh_uniform_ptr(c.fops[1]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c.tab[2 + i] = kh_uniform_ptr(c.sq[i]);
+    }
+}
+
 // Workgroup placement.  The term block of a column group is written by its G workgroups and read by the same G
 // workgroups, every round.  If they all sit on ONE XCD, the block can stay in that XCD's L2: producers store with
 // workgroup scope (the line is kept in L2), consumers load with agent scope (L1 bypassed, L2-served) -- no trip
@@ -252,18 +274,28 @@ __device__ __forceinline__ void kh_coop_check_placement(const KhCoopArgs &c, con
 // would read the tables with FLAT loads -- which also count against the LDS counter and so serialise with the LDS
 // traffic of a fragment update.  They are global memory: say so.)
 typedef double kh_d2 __attribute__((ext_vector_type(2)));
+// A lane's view of a fragment-ordered table: ONE buffer resource per (table, row block) in SGPRs and one 32-bit lane
+// offset shared by all tables; slot q is the scalar offset 1024 q.  (64-bit lane addresses per table and slot, once
+// the table pointers are wave-uniform values, were hoisted out of the interval loop by the compiler: 140 spilled
+// registers.)  A NULL table reads as zeros (no records).
 struct KhCoopSrc {
-    const __attribute__((address_space(1))) kh_d2 *p;
-    __device__ __forceinline__ bool null() const { return p == nullptr; }
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned int voff;
+    bool is_null;
+    __device__ __forceinline__ bool null() const { return is_null; }
     __device__ __forceinline__ cplx operator[](size_t i) const {
-        const kh_d2 v = p[i];
-        return c_make(v.x, v.y);
+        const kh_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(unsigned int)(i * sizeof(cplx)), 0);
+        return c_make(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
     }
 };
-__device__ __forceinline__ KhCoopSrc kh_coop_frag_src(const cplx *op, int g, int wave, int lane, int ks) {
+__device__ __forceinline__ KhCoopSrc kh_coop_frag_src(const cplx *op_in, int g, int wave, int lane, int ks) {
+    const cplx *op = kh_uniform_ptr(op_in);
     KhCoopSrc r;
-    r.p = op == nullptr ? nullptr
-                        : (const __attribute__((address_space(1))) kh_d2 *)(op + (size_t)g * kh_coop_table_stride(ks) + (size_t)wave * ks * 64 + lane);
+    r.is_null = op == nullptr;
+    const cplx *base = op == nullptr ? nullptr : op + (size_t)__builtin_amdgcn_readfirstlane(g) * kh_coop_table_stride(ks);
+    r.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0,
+                                               op == nullptr ? 0 : (int)(sizeof(cplx) * KH_COOP_WAVES * ks * 64), 0x00020000);
+    r.voff = (unsigned int)(sizeof(cplx) * ((size_t)wave * ks * 64 + lane));
     return r;
 }
 
@@ -329,7 +361,6 @@ __device__ __forceinline__ size_t kh_coop_group4(const KhCoopArgs &c, unsigned i
 __device__ __forceinline__ kh_u64 *kh_coop_slot4(const KhCoopArgs &c, unsigned int rid, int y, int group) {
     return c.vbuf + kh_coop_group4(c, rid, y, group);
 }
-typedef unsigned int kh_u32x4 __attribute__((ext_vector_type(4)));
 #define KH_CPOL_SC0 1           // workgroup scope (may be served by the L1 / a stale L2 line)
 #define KH_CPOL_SC1 16          // agent scope
 // two granules (16 bytes) of the lane's element; each granule carries its own tag, so only 8-byte atomicity is used.
@@ -879,6 +910,37 @@ __device__ __forceinline__ void kh_coop_reg_axpy(const cplx *op, double eps, int
     }
 }
 
+// The same read with every load in flight before the first use: a chunk of four slots per (wave-uniform) branch, the
+// values consumed by the caller afterwards.  Zero chunks are not read.
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_reg_load_chunks(const cplx *op, int g, int wave, int lane, int ks, cplx (&r)[MAXKS],
+                                                        unsigned int mask = ~0u) {
+    const KhCoopSrc src = kh_coop_frag_src(op, g, wave, lane, ks);
+#pragma unroll
+    for (int q = 0; q < MAXKS; ++q) r[q] = c_make(0.0, 0.0);
+    if (src.null()) return;
+#pragma unroll
+    for (int c0 = 0; c0 < MAXKS; c0 += 4) {
+        if (c0 < ks && ((mask >> c0) & 0xfu) != 0u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const cplx v = src[(size_t)(c0 + j < ks ? c0 + j : ks - 1) * 64];
+                r[c0 + j] = c0 + j < ks ? v : c_make(0.0, 0.0);
+            }
+        }
+    }
+}
+// the chunks of four slots a mask marks as non-zero: -1 none, 0 ... MAXKS / 4 - 1 exactly that one, MAXKS / 4 several
+template <int MAXKS>
+__device__ __forceinline__ int kh_coop_one_chunk(unsigned int mask) {
+    unsigned int nz = 0u;
+#pragma unroll
+    for (int c0 = 0; c0 < MAXKS; c0 += 4) nz |= ((mask >> c0) & 0xfu) != 0u ? 1u << (c0 >> 2) : 0u;
+    if (nz == 0u) return -1;
+    if ((nz & (nz - 1u)) != 0u) return MAXKS / 4;
+    return __builtin_ctz(nz);
+}
+
 // A = op_0 + sum_l eps_l op_l (fragments rebuilt from L2 once per interval; ops: fragment-ordered copies)
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_build(const cplx *const *ops, const double *eps, int L, int g, int wave,
@@ -936,11 +998,11 @@ struct KhCoopSqMasks {
 __device__ __forceinline__ KhCoopSqMasks kh_coop_sq_masks(const KhCoopArgs &c, int g, int wave) {
     KhCoopSqMasks m = {0u, 0u, 0u, 0u, 0u};
     if (c.sq != nullptr) {
-        m.h0 = kh_coop_frag_mask(c.fops[0], c.G, g, wave, c.ks);
-        m.h1 = kh_coop_frag_mask(c.fops[1], c.G, g, wave, c.ks);
-        m.p0 = kh_coop_frag_mask(c.sq[0], c.G, g, wave, c.ks);
-        m.p1 = kh_coop_frag_mask(c.sq[1], c.G, g, wave, c.ks);
-        m.p2 = kh_coop_frag_mask(c.sq[2], c.G, g, wave, c.ks);
+        m.h0 = kh_coop_frag_mask(c.tab[0], c.G, g, wave, c.ks);
+        m.h1 = kh_coop_frag_mask(c.tab[1], c.G, g, wave, c.ks);
+        m.p0 = kh_coop_frag_mask(c.tab[2], c.G, g, wave, c.ks);
+        m.p1 = kh_coop_frag_mask(c.tab[3], c.G, g, wave, c.ks);
+        m.p2 = kh_coop_frag_mask(c.tab[4], c.G, g, wave, c.ks);
     }
     return m;
 }
@@ -948,8 +1010,8 @@ template <int MAXKS>
 __device__ __forceinline__ void kh_coop_sq_restart(const KhCoopArgs &c, const KhCoopSqMasks &mk, int g, int wave,
                                                    int lane, const KhCoopFrag &a, cplx (&breg)[MAXKS],
                                                    double &eps_prev) {
-    kh_coop_reg_load<MAXKS>(c.sq[0], g, wave, lane, c.ks, breg, mk.p0);
-    kh_coop_load_frag<MAXKS>(c.fops[0], g, wave, lane, c.ks, a, mk.h0);
+    kh_coop_reg_load<MAXKS>(c.tab[2], g, wave, lane, c.ks, breg, mk.p0);
+    kh_coop_load_frag<MAXKS>(c.tab[0], g, wave, lane, c.ks, a, mk.h0);
     eps_prev = 0.0;
 }
 
@@ -983,6 +1045,63 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         const long long tr0 = clock64();
 #endif
         const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
+        const int c2 = kh_coop_one_chunk<MAXKS>(mk.p2), c1 = kh_coop_one_chunk<MAXKS>(mk.h1);
+#ifdef KH_COOP_BATCH
+        if (c2 < MAXKS / 4 && c1 < MAXKS / 4) {
+            // The usual shape -- a dense P1 next to a control operator and its square with at most one non-zero chunk
+            // per wave (a commutator superoperator of a diagonal or banded H_1): ALL table reads of the interval are
+            // issued before the first is used, one trip to L2 instead of one per chunk (measured on config 4: 6 chunks
+            // x ~1 100 cycles per interval in the plain sweeps, 2 in the update sweep behind the prefetched P1).
+            const KhCoopSrc s2 = kh_coop_frag_src(c.tab[4], g, wave, lane, c.ks);
+            const KhCoopSrc s1 = kh_coop_frag_src(c.tab[1], g, wave, lane, c.ks);
+            const int z2 = c2 < 0 ? 0 : 4 * c2, z1 = c1 < 0 ? 0 : 4 * c1;
+            cplx v2[4], v1[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q2 = z2 + j < c.ks ? z2 + j : c.ks - 1, q1 = z1 + j < c.ks ? z1 + j : c.ks - 1;
+                v2[j] = (c2 >= 0 && !s2.null()) ? s2[(size_t)q2 * 64] : c_make(0.0, 0.0);
+                v1[j] = (c1 >= 0 && !s1.null()) ? s1[(size_t)q1 * 64] : c_make(0.0, 0.0);
+                t1[j] = a.f[(size_t)q1 * KH_COOP_THREADS];
+            }
+            if (p1pre != nullptr) {
+#pragma unroll
+                for (int q = 0; q < MAXKS; ++q) {
+                    breg[q].x = fma(e1, (*p1pre)[q].x, breg[q].x);
+                    breg[q].y = fma(e1, (*p1pre)[q].y, breg[q].y);
+                }
+            } else {
+                cplx p1[MAXKS];
+                kh_coop_reg_load_chunks<MAXKS>(c.tab[3], g, wave, lane, c.ks, p1, mk.p1);
+#pragma unroll
+                for (int q = 0; q < MAXKS; ++q) {
+                    breg[q].x = fma(e1, p1[q].x, breg[q].x);
+                    breg[q].y = fma(e1, p1[q].y, breg[q].y);
+                }
+            }
+            if (c2 >= 0) {
+#pragma unroll
+                for (int cc = 0; cc < MAXKS / 4; ++cc) {
+                    if (cc == c2) {  // (wave-uniform: the register index must be a constant)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (4 * cc + j < c.ks) {
+                                breg[4 * cc + j].x = fma(e2, v2[j].x, breg[4 * cc + j].x);
+                                breg[4 * cc + j].y = fma(e2, v2[j].y, breg[4 * cc + j].y);
+                            }
+                        }
+                    }
+                }
+            }
+            if (c1 >= 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (z1 + j < c.ks)
+                        a.f[(size_t)(z1 + j) * KH_COOP_THREADS] = c_make(fma(e1, v1[j].x, t1[j].x), fma(e1, v1[j].y, t1[j].y));
+                }
+            }
+        } else
+#endif
+        {
 #ifndef KH_COOP_X_NOP1  // (timing experiment: wrong results)
         if (p1pre != nullptr) {
 #pragma unroll
@@ -991,13 +1110,14 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
                 breg[q].y = fma(e1, (*p1pre)[q].y, breg[q].y);
             }
         } else {
-            kh_coop_reg_axpy<MAXKS>(c.sq[1], e1, g, wave, lane, c.ks, breg, mk.p1);
+            kh_coop_reg_axpy<MAXKS>(c.tab[3], e1, g, wave, lane, c.ks, breg, mk.p1);
         }
 #endif
 #ifndef KH_COOP_X_NOP2H1
-        kh_coop_reg_axpy<MAXKS>(c.sq[2], e2, g, wave, lane, c.ks, breg, mk.p2);
-        kh_coop_axpy_frag<MAXKS>(c.fops[1], e1, g, wave, lane, c.ks, a, mk.h1);
+        kh_coop_reg_axpy<MAXKS>(c.tab[4], e2, g, wave, lane, c.ks, breg, mk.p2);
+        kh_coop_axpy_frag<MAXKS>(c.tab[1], e1, g, wave, lane, c.ks, a, mk.h1);
 #endif
+        }
         eps_prev = kh_uniform(eps);
 #ifdef KH_TIMING
         if (tid == 0 && blockIdx.x == 0) {
@@ -1137,6 +1257,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
     kh_coop_check_placement(c_in, ex, s, g, y, tid);
     KhCoopArgs c = c_in;
     c.local = __builtin_amdgcn_readfirstlane(s.local);
+    kh_coop_resolve_tables(c);
     int r, col;
     kh_coop_owner_element<COLS>(tid, r, col);
     const int row = rowbase + r, k = y * COLS + col;
@@ -1173,8 +1294,11 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         if (c.sq != nullptr) {
+            // the dense table of the fragment update: all its slots in flight at once (one trip to L2, not one per chunk)
+            cplx p1pre[MAXKS];
+            kh_coop_reg_load<MAXKS>(c.tab[3], g, wave, lane, c.ks, p1pre, mk.p1);
             if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,
-                                                     owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
+                                                     owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane, &p1pre))
                 return;
             rounds += (double)nsub * (((m + 1) >> 1) + 1);
         } else {
@@ -1234,6 +1358,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     kh_coop_check_placement(c_in, ex, s, g, y, tid);
     KhCoopArgs c = c_in;
     c.local = __builtin_amdgcn_readfirstlane(s.local);
+    kh_coop_resolve_tables(c);
     int r, col;
     kh_coop_owner_element<COLS>(tid, r, col);
     const int row = rowbase + r, k = y * COLS + col;
@@ -1287,7 +1412,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
                 if (lane == 0) s.red[par][wave][0] = piece;
             }
             // the dense table of the coming fragment update, on its way while the sums are exchanged
-            kh_coop_reg_load<MAXKS>(c.sq[1], g, wave, lane, c.ks, p1pre, mk.p1);
+            kh_coop_reg_load<MAXKS>(c.tab[3], g, wave, lane, c.ks, p1pre, mk.p1);
         }
 #pragma unroll
         for (int l = 0; l < KH_COOP_MAX_L; ++l) {
@@ -1295,7 +1420,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
             cplx w;
             if (c.sq != nullptr) {  // (the LDS fragment holds A for the whole sweep: the control operator from registers)
                 cplx hreg[MAXKS];
-                kh_coop_reg_load<MAXKS>(c.fops[1 + l], g, wave, lane, c.ks, hreg, mk.h1);  // (sq: one control, l = 0)
+                kh_coop_reg_load<MAXKS>(c.tab[1], g, wave, lane, c.ks, hreg, mk.h1);  // (sq: one control, l = 0)
                 const KhCoopRegFrag<MAXKS, true> hf = {hreg, mk.h1};
                 kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, hf, s, tid, wave, lane, w);
             } else {
