@@ -33,7 +33,14 @@
 #define KH_COOP_WAVES 8
 #define KH_COOP_COLS 16     // MFMA N: a workgroup handles c.cols <= 16 objectives (the rest of the tile is zero)
 // owner threads: tid < 16 COLS owns element (row tid / COLS, column tid % COLS) of the block (one wave for COLS = 4)
-#define KH_COOP_RING 32      // blocks in the exchange ring
+#define KH_COOP_RING 32      // blocks in the exchange ring (as allocated; in use across XCDs)
+// ... of which a column group that sits on ONE XCD uses the first few: its L2 is coherent for its own workgroups, so
+// the race-free minimum (2) would do, and a short ring keeps the L2 for the operator tables -- with 32 blocks in turn a
+// group's ring took 0.8 MB of the 4 MB next to 3.3 MB of P1 slices, and every interval's table read missed somewhere
+// (config 4: backward 18.4 -> 17.7 ms, update 20.7 -> 19.7 ms)
+#ifndef KH_COOP_RING_LOCAL
+#define KH_COOP_RING_LOCAL 4
+#endif
 #ifndef KH_COOP_CHUNK
 #define KH_COOP_CHUNK 4     // slots whose loads are in flight together in a fragment update (MAXKS is a multiple)
 #endif
@@ -80,6 +87,7 @@ struct KhCoopArgs {
     int first_poll_delay;     // s_sleep units (64 cycles) before a round's first fetch
     int xcd_rows;             // > 0: one-dimensional grid of 8 * xcd_rows blocks, block b = 8 g + y (see kh_coop_place)
     int local;                // (set in the kernel after kh_coop_check_placement: a wave-uniform copy of KhCoopLds::local)
+    unsigned int ring_mask;   // blocks of the ring in use - 1 (set with `local`: KH_COOP_RING_LOCAL or KH_COOP_RING)
     unsigned int *xcc;        // [Y * G] XCC id + 1 of every workgroup (placement check, zeroed with vbuf)
     const cplx *const *fops;  // [1 + L] this direction's (shared) operators in fragment order
     const double *ser_theta;  // A^2 chain only: degree thresholds, c_0 and rows {c_{2p+1}/c_{2p}, c_{2p+2}/c_{2p}} of the series
@@ -344,7 +352,7 @@ __device__ __forceinline__ void kh_coop_axpy_frag(const cplx *op, double eps, in
 // of one granule index are contiguous, so a wave's 8-byte accesses cover whole 128-byte lines
 __device__ __forceinline__ kh_u64 *kh_coop_slot(const KhCoopArgs &c, unsigned int rid, int y, int row, int col) {
     return c.vbuf +
-           (((size_t)(rid % KH_COOP_RING) * c.Y + y) * ((size_t)c.G * 16) + row) * (4 * KH_COOP_COLS) + col;
+           (((size_t)(rid & c.ring_mask) * c.Y + y) * ((size_t)c.G * 16) + row) * (4 * KH_COOP_COLS) + col;
 }
 
 // 4 objectives per workgroup: a 16-row group of the block is 2 KiB laid out as the consumer's wave reads it --
@@ -356,7 +364,7 @@ __device__ __forceinline__ int kh_coop4_lane(int row_in_group, int col) {
     return 16 * (row_in_group & 3) + 4 * (row_in_group >> 2) + col;
 }
 __device__ __forceinline__ size_t kh_coop_group4(const KhCoopArgs &c, unsigned int rid, int y, int group) {
-    return (((size_t)(rid % KH_COOP_RING) * c.Y + y) * (size_t)c.G + group) * 256;  // (granules)
+    return (((size_t)(rid & c.ring_mask) * c.Y + y) * (size_t)c.G + group) * 256;  // (granules)
 }
 __device__ __forceinline__ kh_u64 *kh_coop_slot4(const KhCoopArgs &c, unsigned int rid, int y, int group) {
     return c.vbuf + kh_coop_group4(c, rid, y, group);
@@ -1257,6 +1265,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
     kh_coop_check_placement(c_in, ex, s, g, y, tid);
     KhCoopArgs c = c_in;
     c.local = __builtin_amdgcn_readfirstlane(s.local);
+    c.ring_mask = c.local ? KH_COOP_RING_LOCAL - 1 : KH_COOP_RING - 1;
     kh_coop_resolve_tables(c);
     int r, col;
     kh_coop_owner_element<COLS>(tid, r, col);
@@ -1355,9 +1364,13 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     const int N = p.N, nt = p.nt, L = p.L;
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = (c_in.sq != nullptr && c_in.ser_theta != nullptr) ? c_in.ser_theta[tid] : p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
+#ifdef KH_TIMING
+    if (tid < 12) s.tim[tid] = 0.0;
+#endif
     kh_coop_check_placement(c_in, ex, s, g, y, tid);
     KhCoopArgs c = c_in;
     c.local = __builtin_amdgcn_readfirstlane(s.local);
+    c.ring_mask = c.local ? KH_COOP_RING_LOCAL - 1 : KH_COOP_RING - 1;
     kh_coop_resolve_tables(c);
     int r, col;
     kh_coop_owner_element<COLS>(tid, r, col);
@@ -1524,6 +1537,13 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
         for (int l = 0; l < KH_COOP_MAX_L; ++l)
             if (l < L) u.g_a[l] = g_a_loc[l];
     }
+#ifdef KH_TIMING
+    if (blockIdx.x == 0 && tid == 0 && p.stats != nullptr) {  // (raw slots of KH_TRACE: fragment updates per interval, rounds)
+        p.stats[28] = s.tim[10] / (nt - 1);
+        p.stats[29] = (s.tim[0] + s.tim[1] + s.tim[2] + s.tim[7] + s.tim[8]) / (nt - 1);
+        p.stats[30] = s.tim[9] / (nt - 1);
+    }
+#endif
     if (g == 0 && tid == 0 && p.stats != nullptr) {
         const int cols = min(c.cols, p.K - y * c.cols);
         atomicAdd(p.stats, (double)rounds * cols);

@@ -799,6 +799,7 @@ static KhCoopArgs coop_args(const kh_engine *e, bool backward) {
     c.xcd_rows = e->coop_xcd ? e->coop_G : 0;
     c.xcc = e->d_coop_xcc;
     c.local = 0;
+    c.ring_mask = KH_COOP_RING - 1;
     for (int i = 0; i < 5; ++i) c.tab[i] = nullptr;  // (resolved in the kernel)
     c.ser_theta = e->coop_series ? e->d_q2_theta : nullptr;
     c.ser_c0 = e->coop_series ? e->d_q2_c0 : nullptr;

@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 
+from krotov_amd import _lib
+if os.environ.get('KH_LIB'):  # (an experiment build of the library, e.g. -DKH_COOP_X_NOEXCH)
+    _lib.LIB_PATH = os.path.abspath(os.environ['KH_LIB'])
 from krotov_amd import configs
 from krotov_amd.engine import HipKrotovEngine
 
