@@ -517,8 +517,22 @@ class _HipBackend:
                 "cross-GPU exchange: %s", "peer windows" if self.p2p else "RCCL all-reduce per interval")
 
     # -- helpers -----------------------------------------------------------
-    def _pulses(self, pulses):
-        return self.engine.dev(np.array(pulses, dtype=np.float64).reshape(self.L, self.nt - 1), self.torch.float64)
+    def _cached_upload(self, key, host, dtype=None):
+        """Device copy of a small host array that is usually the same from one iteration to the next (every upload from
+        pageable memory blocks the host for ~30 us with the GPU idle)."""
+        cache = self.__dict__.setdefault('_uploads', {})
+        hit = cache.get(key)
+        if hit is not None and hit[0].shape == host.shape and np.array_equal(hit[0], host):
+            return hit[1]
+        dev = self.engine.dev(host, dtype if dtype is not None else self.torch.float64)
+        cache[key] = (host.copy(), dev)
+        return dev
+
+    def _pulses(self, pulses, cached=False):
+        host = np.array(pulses, dtype=np.float64).reshape(self.L, self.nt - 1)
+        if cached:  # (the guess of an iteration is normally the optimized pulse of the one before: still on the device)
+            return self._cached_upload('pulses', host)
+        return self.engine.dev(host, self.torch.float64)
 
     def _gather_rows(self, local):
         """(K_loc, ...) host array on every rank -> (K_total, ...) on every rank."""
@@ -560,7 +574,13 @@ class _HipBackend:
         then formed and normalised on the device (kh_chi_boundary)."""
         t = self.torch
         eng = self.engine
-        guess = self._pulses(guess_pulses)
+        guess = self._pulses(guess_pulses, cached=True)
+        # every upload of the iteration BEFORE the first sweep is launched: a host-to-device copy from pageable memory
+        # is ordered behind the kernels already in the stream and blocks the host until it is done -- issued between the
+        # two sweeps it kept the update sweep's launch back until the backward sweep had finished (the GPU idled for
+        # two copies and a launch per iteration).  Shapes and step widths rarely change: uploaded when they do.
+        shapes = self._cached_upload('shapes', np.array(shape_arrays, dtype=np.float64).reshape(self.L, self.nt - 1))
+        lambdas = self._cached_upload('lambdas', np.asarray(lambda_vals, dtype=np.float64))
         if sigma is not None:
             # sigma at the interval mid-points (optimize.py:451-452); phi under the guess pulses is
             # the trajectory the previous sweep stored, the running one goes to the other buffer
@@ -572,14 +592,14 @@ class _HipBackend:
         if chi_coef is not None:
             c, d = chi_coef
             psi = self.fw_T_dev if self.fw_T_dev is not None else self.init  # (d == 0 without phi(T))
-            chi_loc, norms_loc = eng.chi_boundary(self.targets, psi, c[self.k0:self.k1], d[self.k0:self.k1])
+            c_dev = self._cached_upload('chi_c', np.ascontiguousarray(c[self.k0:self.k1], dtype=np.complex128), t.complex128)
+            d_dev = self._cached_upload('chi_d', np.ascontiguousarray(d[self.k0:self.k1], dtype=np.complex128), t.complex128)
+            chi_loc, norms_loc = eng.chi_boundary(self.targets, psi, c_dev, d_dev)
         else:
             chi_loc = eng.dev(chi_T[self.k0:self.k1], t.complex128)
             norms_loc = eng.dev(np.asarray(chi_norms, dtype=np.float64)[self.k0:self.k1], t.float64)
         self.last_chi = (chi_loc, norms_loc)
         self.chi_store = eng.backward(chi_loc, guess, out=self.chi_store)
-        shapes = eng.dev(np.array(shape_arrays, dtype=np.float64).reshape(self.L, self.nt - 1), t.float64)
-        lambdas = eng.dev(np.asarray(lambda_vals, dtype=np.float64), t.float64)
         done = False
         if self.group is None:
             if self._single_launch_ok:
@@ -635,6 +655,7 @@ class _HipBackend:
         eng.check()
         fw_states_T = self._final_states(psi_T)
         opt_host = opt.cpu().numpy()
+        self.__dict__.setdefault('_uploads', {})['pulses'] = (opt_host.copy(), opt)  # (the next iteration's guess, if unchanged)
         optimized = [opt_host[l].copy() for l in range(self.L)]
         backward_states = _DeviceTrajectories(self.chi_store, self.likes, self.k0)
         forward_states = None
