@@ -505,8 +505,15 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     if (e->kind == KIND_GENERIC && csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 &&
         !(force && strcmp(force, "generic") == 0))
         e->kind_store = KIND_TILE_RPT1;
+    // ... and with one control that kernel is the two-terms-per-phase one (kh_q2_sweep_store takes its objectives in
+    // turns: no co-residency needed), whatever the update sweep has to use: K = 512 on one GPU 7.5 -> 5.8 us per
+    // interval of the backward sweep (two turns of the 256-objective sweep instead of the one-term-per-phase kernel
+    // with two workgroups per CU).  KH_Q2_STORE=0: the update sweep's own family (A/B switch)
+    if ((e->kind_store == KIND_TILE_RPT2 || e->kind_store == KIND_TILE_RPT1) && e->L == 1 && force == nullptr &&
+        !(getenv("KH_Q2_STORE") && atoi(getenv("KH_Q2_STORE")) == 0))
+        e->kind_store = KIND_TILE_Q2;
     const bool coop_sq = e->kind == KIND_COOP && e->L == 1 && !(getenv("KH_COOP_NOSQ") && atoi(getenv("KH_COOP_NOSQ")));
-    if (e->kind == KIND_TILE_Q2 || coop_sq) {
+    if (e->kind == KIND_TILE_Q2 || e->kind_store == KIND_TILE_Q2 || coop_sq) {
         // stage P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 once per distinct operator (pair)
         const unsigned pgrid = (unsigned)(((size_t)e->N * e->N + 255) / 256 < 16 ? 16 : ((size_t)e->N * e->N + 255) / 256);
         const size_t bytes = sizeof(cplx) * (size_t)e->N * e->N;
@@ -674,9 +681,10 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         KH_HIP_E(hipMemcpy(e->d_q2_c0, c0.data(), sizeof(double) * c0.size(), hipMemcpyHostToDevice));
         KH_HIP_E(hipMemcpy(e->d_q2_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
     }
-    if (e->kind == KIND_TILE_Q2) {
+    if (e->kind_store == KIND_TILE_Q2)
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_sweep_store, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kh_q2_lds_bytes()));
+    if (e->kind == KIND_TILE_Q2) {
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false, true>,
@@ -696,8 +704,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             rc = check_residency(e, (const void *)kh_q2_forward_update<true, false>, KH_Q2_THREADS, kh_q2_lds_bytes(), e->K,
                                  "kh_q2_forward_update (second order)");
         if (rc != KH_OK) {
-            e->kind = KIND_GENERIC;
-            e->kind_store = KIND_TILE_RPT1;
+            e->kind = KIND_GENERIC;  // (the plain sweeps keep the q2 kernel: its workgroups do not wait for each other)
             e->grid_update = e->K < max_wgs ? e->K : max_wgs;
         }
     }
