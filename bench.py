@@ -26,7 +26,12 @@ kernels (peer-mapped windows over xGMI).  The same JSON line carries
 * ``"rccl"``: the strong-scaling job again with the north star's transport, one
   RCCL all-reduce of the L sums per time interval (``KH_P2P=0``; HIP-graph replay
   of the interval loop), a few iterations,
+* ``"config4"`` (N = 2, 4, 8): three iterations of BASELINE config 4 -- quoted on 2 and 4
+  GPUs -- with its 16 density matrices sharded over the ranks (cooperative matrix-core
+  kernels, update sums through the peer windows),
 * ``"n_ranks_seen"``: ``torch.distributed.get_world_size()``.
+Each of these side measurements runs under a watchdog (``--rccl-leg-timeout``): if one
+hangs or fails, the headline line is printed with an ``"error"`` entry in its place.
 At N = 1 the line carries instead, measured after the headline and not part of
 ``value``: ``"config4"`` (three iterations of BASELINE config 4, 16 density
 matrices under one 400-dim Liouvillian: the cooperative fp64 matrix-core
@@ -443,27 +448,44 @@ def main():
             out[other] = {k: second[k] for k in ('value', 'unit', 'iterations_per_sec', 'ms_per_step', 'scaling')}
             out[other]['objectives'] = second['config']['objectives']
             out[other]['kernels'] = {k: second['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')}
-    rccl = None
-    if (world > 1 or args.force_dist) and args.workload == 'c5' and not args.no_rccl_leg:
-        # the north star's transport: one RCCL all-reduce of the L update sums per time interval (kh_update_begin /
-        # step_dev / end with HIP-graph replay) instead of the peer windows inside the persistent kernel.  It is a side
-        # measurement: if it does not come back within --rccl-leg-timeout seconds (a collective that hangs cannot be
-        # interrupted from Python), every rank's watchdog ends the process with the headline line printed and rc 0.
+    def guarded(name, seconds, fn):
+        """A side measurement of a sharded run under a watchdog: if it does not come back within `seconds` (a collective
+        or an in-kernel wait that hangs cannot be interrupted from Python), every rank ends the process with the headline
+        line -- and what the earlier side measurements gave -- printed and rc 0."""
         import threading
 
-        def give_up():
+        def give_up(why=None):
             if rank == 0:
-                out['rccl'] = {'error': 'no result within %d s' % args.rccl_leg_timeout}
+                out[name] = {'error': why or 'no result within %d s' % seconds}
                 print(json.dumps(out), flush=True)
             os._exit(0)
 
-        watchdog = threading.Timer(args.rccl_leg_timeout, give_up)
+        watchdog = threading.Timer(seconds, give_up)
         watchdog.daemon = True
         watchdog.start()
         try:
-            rccl = leg('strong', env={'KH_P2P': '0'}, steps=min(args.steps, 3), warmup=1)
+            return fn()
+        except Exception as exc:  # (the other ranks may be waiting in a collective: nobody goes on; theirs end the same way)
+            give_up(repr(exc)[:200])
         finally:
             watchdog.cancel()
+
+    rccl = None
+    if (world > 1 or args.force_dist) and args.workload == 'c5' and not args.no_rccl_leg:
+        # the north star's transport: one RCCL all-reduce of the L update sums per time interval (kh_update_begin /
+        # step_dev / end with HIP-graph replay) instead of the peer windows inside the persistent kernel.
+        rccl = guarded('rccl', args.rccl_leg_timeout,
+                       lambda: leg('strong', env={'KH_P2P': '0'}, steps=min(args.steps, 3), warmup=1))
+        if rank == 0 and rccl is not None:
+            out['rccl'] = rccl
+            rccl = None
+    if world > 1 and 16 % world == 0 and args.workload == 'c5' and not args.no_config4:
+        # BASELINE config 4 is quoted on 2 and 4 GPUs: its 16 density matrices sharded over the ranks (16 / N each: the
+        # cooperative matrix-core kernels with fewer column groups per GPU, the update sums across the GPUs through the
+        # peer windows), three iterations.  Not part of `value`.
+        c4 = guarded('config4', args.rccl_leg_timeout, lambda: leg('strong', workload='c4', steps=3, warmup=1))
+        if rank == 0 and c4 is not None:
+            out['config4'] = c4
     if rank == 0:
         if rccl is not None:
             out['rccl'] = rccl

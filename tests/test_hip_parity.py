@@ -1298,4 +1298,7 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert rec['weak']['objectives'] == 512 and rec['weak']['value'] > 0
     assert 'peer-mapped windows' in rec['config']['parallelism']
     assert 'all-reduce per time step' in rec['rccl']['parallelism'] and rec['rccl']['value'] > 0
+    # BASELINE config 4 (quoted on 2 and 4 GPUs): its 16 density matrices over the two ranks, cooperative kernels
+    assert 'error' not in rec['config4'], rec['config4']
+    assert rec['config4']['kernel'].startswith('coop') and rec['config4']['value'] > 0
     assert rec['value'] > 0 and rec['roofline']['frac'] > 0
