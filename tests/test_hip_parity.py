@@ -1277,7 +1277,7 @@ def test_bench_self_launches_two_ranks(tmp_path):
     """``python bench.py --gpus 2`` with no launcher and no WORLD_SIZE in the environment -- the form the driver's
     scaling run uses -- must start its ranks itself, print ONE JSON line from rank 0 and exit 0.  Here both ranks
     share the one GPU (host collectives over gloo, picked automatically; the in-kernel peer windows as on a node).
-    The line must carry the headline (strong scaling), the weak-scaling measurement, the RCCL-per-interval leg and
+    The line must carry the headline (weak scaling), the strong-scaling measurement, the RCCL-per-interval leg and
     the number of ranks torch.distributed saw."""
     import json
     import subprocess
@@ -1286,16 +1286,17 @@ def test_bench_self_launches_two_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.pop('KH_DIST_BACKEND', None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # (--K 128: the two ranks' workgroups must be resident on the ONE GPU at the same time -- 2 x 128 fill it)
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--no-cpu-baseline', '--nt', '401']
+           '--no-cpu-baseline', '--nt', '401', '--K', '128']
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, proc.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['n_ranks_seen'] == 2 and rec['steps'] == 2
-    assert rec['scaling'] == 'strong' and rec['config']['objectives'] == 256
-    assert rec['weak']['objectives'] == 512 and rec['weak']['value'] > 0
+    assert rec['scaling'] == 'weak' and rec['config']['objectives'] == 256
+    assert rec['strong']['objectives'] == 128 and rec['strong']['value'] > 0
     assert 'peer-mapped windows' in rec['config']['parallelism']
     assert 'all-reduce per time step' in rec['rccl']['parallelism'] and rec['rccl']['value'] > 0
     # BASELINE config 4 (quoted on 2 and 4 GPUs): its 16 density matrices over the two ranks, cooperative kernels
