@@ -28,5 +28,6 @@ eng.profile = True
 for _ in range(2):
     out = eng.forward_update(chi, norms, spec.init, pulses, S, lam)
 torch.cuda.synchronize()
-print('update sweep %.2f ms; KH_TRACE raw [16..31] = exchange wait per column group, cycles per interval' % min(eng.kernel_times_ms()['update']))
+print('update sweep %.2f ms; KH_TRACE raw [16..23] = exchange wait per column group, [24] fragment update, [25] inside the rounds, '
+      '[26] between rounds + interval boundary: cycles per interval' % min(eng.kernel_times_ms()['update']))
 eng._lib.kh_last_stats(eng._handle, buf)
