@@ -918,37 +918,6 @@ __device__ __forceinline__ void kh_coop_reg_axpy(const cplx *op, double eps, int
     }
 }
 
-// The same read with every load in flight before the first use: a chunk of four slots per (wave-uniform) branch, the
-// values consumed by the caller afterwards.  Zero chunks are not read.
-template <int MAXKS>
-__device__ __forceinline__ void kh_coop_reg_load_chunks(const cplx *op, int g, int wave, int lane, int ks, cplx (&r)[MAXKS],
-                                                        unsigned int mask = ~0u) {
-    const KhCoopSrc src = kh_coop_frag_src(op, g, wave, lane, ks);
-#pragma unroll
-    for (int q = 0; q < MAXKS; ++q) r[q] = c_make(0.0, 0.0);
-    if (src.null()) return;
-#pragma unroll
-    for (int c0 = 0; c0 < MAXKS; c0 += 4) {
-        if (c0 < ks && ((mask >> c0) & 0xfu) != 0u) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const cplx v = src[(size_t)(c0 + j < ks ? c0 + j : ks - 1) * 64];
-                r[c0 + j] = c0 + j < ks ? v : c_make(0.0, 0.0);
-            }
-        }
-    }
-}
-// the chunks of four slots a mask marks as non-zero: -1 none, 0 ... MAXKS / 4 - 1 exactly that one, MAXKS / 4 several
-template <int MAXKS>
-__device__ __forceinline__ int kh_coop_one_chunk(unsigned int mask) {
-    unsigned int nz = 0u;
-#pragma unroll
-    for (int c0 = 0; c0 < MAXKS; c0 += 4) nz |= ((mask >> c0) & 0xfu) != 0u ? 1u << (c0 >> 2) : 0u;
-    if (nz == 0u) return -1;
-    if ((nz & (nz - 1u)) != 0u) return MAXKS / 4;
-    return __builtin_ctz(nz);
-}
-
 // A = op_0 + sum_l eps_l op_l (fragments rebuilt from L2 once per interval; ops: fragment-ordered copies)
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_build(const cplx *const *ops, const double *eps, int L, int g, int wave,
@@ -1053,63 +1022,6 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         const long long tr0 = clock64();
 #endif
         const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
-        const int c2 = kh_coop_one_chunk<MAXKS>(mk.p2), c1 = kh_coop_one_chunk<MAXKS>(mk.h1);
-#ifdef KH_COOP_BATCH
-        if (c2 < MAXKS / 4 && c1 < MAXKS / 4) {
-            // The usual shape -- a dense P1 next to a control operator and its square with at most one non-zero chunk
-            // per wave (a commutator superoperator of a diagonal or banded H_1): ALL table reads of the interval are
-            // issued before the first is used, one trip to L2 instead of one per chunk (measured on config 4: 6 chunks
-            // x ~1 100 cycles per interval in the plain sweeps, 2 in the update sweep behind the prefetched P1).
-            const KhCoopSrc s2 = kh_coop_frag_src(c.tab[4], g, wave, lane, c.ks);
-            const KhCoopSrc s1 = kh_coop_frag_src(c.tab[1], g, wave, lane, c.ks);
-            const int z2 = c2 < 0 ? 0 : 4 * c2, z1 = c1 < 0 ? 0 : 4 * c1;
-            cplx v2[4], v1[4], t1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q2 = z2 + j < c.ks ? z2 + j : c.ks - 1, q1 = z1 + j < c.ks ? z1 + j : c.ks - 1;
-                v2[j] = (c2 >= 0 && !s2.null()) ? s2[(size_t)q2 * 64] : c_make(0.0, 0.0);
-                v1[j] = (c1 >= 0 && !s1.null()) ? s1[(size_t)q1 * 64] : c_make(0.0, 0.0);
-                t1[j] = a.f[(size_t)q1 * KH_COOP_THREADS];
-            }
-            if (p1pre != nullptr) {
-#pragma unroll
-                for (int q = 0; q < MAXKS; ++q) {
-                    breg[q].x = fma(e1, (*p1pre)[q].x, breg[q].x);
-                    breg[q].y = fma(e1, (*p1pre)[q].y, breg[q].y);
-                }
-            } else {
-                cplx p1[MAXKS];
-                kh_coop_reg_load_chunks<MAXKS>(c.tab[3], g, wave, lane, c.ks, p1, mk.p1);
-#pragma unroll
-                for (int q = 0; q < MAXKS; ++q) {
-                    breg[q].x = fma(e1, p1[q].x, breg[q].x);
-                    breg[q].y = fma(e1, p1[q].y, breg[q].y);
-                }
-            }
-            if (c2 >= 0) {
-#pragma unroll
-                for (int cc = 0; cc < MAXKS / 4; ++cc) {
-                    if (cc == c2) {  // (wave-uniform: the register index must be a constant)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (4 * cc + j < c.ks) {
-                                breg[4 * cc + j].x = fma(e2, v2[j].x, breg[4 * cc + j].x);
-                                breg[4 * cc + j].y = fma(e2, v2[j].y, breg[4 * cc + j].y);
-                            }
-                        }
-                    }
-                }
-            }
-            if (c1 >= 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (z1 + j < c.ks)
-                        a.f[(size_t)(z1 + j) * KH_COOP_THREADS] = c_make(fma(e1, v1[j].x, t1[j].x), fma(e1, v1[j].y, t1[j].y));
-                }
-            }
-        } else
-#endif
-        {
 #ifndef KH_COOP_X_NOP1  // (timing experiment: wrong results)
         if (p1pre != nullptr) {
 #pragma unroll
@@ -1125,7 +1037,6 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         kh_coop_reg_axpy<MAXKS>(c.tab[4], e2, g, wave, lane, c.ks, breg, mk.p2);
         kh_coop_axpy_frag<MAXKS>(c.tab[1], e1, g, wave, lane, c.ks, a, mk.h1);
 #endif
-        }
         eps_prev = kh_uniform(eps);
 #ifdef KH_TIMING
         if (tid == 0 && blockIdx.x == 0) {
