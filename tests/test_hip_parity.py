@@ -667,9 +667,16 @@ def test_edge_cases(monkeypatch):
     # non-uniform dt, control absent from one objective, more objectives than CUs: 300 -> two 256-thread
     # workgroups per CU (register tiles), 600 -> the register-tile kernel with one launch per interval, or
     # (KH_NO_STEPWISE=1) the generic kernels' persistent loop over objectives
-    for K, kernel in ((300, 'tile64/256'), (600, 'tile64/512 per interval'), (600, 'generic')):
+    # (the plain sweeps of such engines run kh_q2_sweep_store, objectives in turns; the second K = 300 case keeps the
+    # update sweep's own family for them: KH_Q2_STORE=0)
+    for K, kernel, q2_store in ((300, 'tile64/256', True), (300, 'tile64/256', False), (600, 'tile64/512 per interval', True),
+                                (600, 'generic', True)):
         if kernel == 'generic':
             monkeypatch.setenv('KH_NO_STEPWISE', '1')
+        if q2_store:
+            monkeypatch.delenv('KH_Q2_STORE', raising=False)
+        else:
+            monkeypatch.setenv('KH_Q2_STORE', '0')
         N, nt = 6, 21
         tl = np.cumsum(np.concatenate([[0.0], rng.uniform(0.01, 0.05, nt - 1)]))
         H0 = [configs.herm(rng, N, 3.0) for _ in range(K)]
@@ -695,6 +702,7 @@ def test_edge_cases(monkeypatch):
         assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
         eng.close()
     monkeypatch.delenv('KH_NO_STEPWISE')
+    monkeypatch.delenv('KH_Q2_STORE', raising=False)
     # N = 1 and a large step norm (several Taylor sub-steps)
     ops1 = [[np.array([[2.5 + 0j]]), np.array([[40.0 + 0j]])]]
     eng = HipKrotovEngine(ops1, [0.5, 0.25])
