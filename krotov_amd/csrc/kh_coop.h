@@ -391,6 +391,13 @@ __device__ __forceinline__ void kh_coop_publish(const KhCoopArgs &c, unsigned in
 #ifdef KH_COOP_X_NOSTORE
     if (rid > 1) return;
 #endif
+#ifdef KH_COOP_STRESS  // (protocol test build: publications delayed pseudo-randomly per workgroup and round -- results must not change)
+    {
+        const unsigned int hsh = (blockIdx.x * 2654435761u) ^ (rid * 40503u);
+        const int naps = (int)((hsh >> 7) % 23u);
+        for (int d = 0; d < naps; ++d) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     if constexpr (COLS == 2 || COLS == 4) {
         // The element's two granules per part are adjacent: ONE 16-byte store per part ({hi | tag}, {lo | tag}; each
         // 8-byte granule still carries its own tag) instead of two 8-byte ones.  COLS = 2: a group is 1 KiB,
