@@ -375,6 +375,13 @@ struct KhExchange {
 // Called by (at least) the first 2*L lanes of one wave: one 8-byte store each.
 __device__ __forceinline__ void kh_publish(const KhExchange &ex, int parity, int wg, int L, int lane,
                                            const double *values, unsigned int epoch) {
+#ifdef KH_EXCH_STRESS  // (protocol test build: publications delayed pseudo-randomly per workgroup and interval -- results must not change)
+    {
+        const unsigned int hsh = ((unsigned int)wg * 2654435761u) ^ (epoch * 40503u);
+        const int naps = (int)((hsh >> 9) % 19u);
+        for (int d = 0; d < naps; ++d) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     if (lane < 2 * L) {
         const int l = lane >> 1;
         const kh_u64 bits = (kh_u64)__double_as_longlong(values[l]);
