@@ -629,6 +629,13 @@ class _HipBackend:
         elif self.p2p:
             # one persistent launch per rank; the per-GPU sums cross the node inside the kernel
             failed = 0
+            if not self.__dict__.get('_p2p_synced', False):
+                # the ranks' kernels wait for each other INSIDE the sweep (bounded by KH_TIMEOUT_MS): before the first
+                # one, line the ranks up -- set-up time (imports, engine creation, operator norms) differs by more than
+                # that bound between ranks; afterwards they stay within a sweep's jitter of each other
+                t.cuda.synchronize(eng.device)
+                self.dist.barrier(group=self.group)
+                self._p2p_synced = True
             try:
                 opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
                 eng.check()
