@@ -1163,7 +1163,9 @@ kh_coop_adjoint_side(const cplx *__restrict__ op /*H_1^+, row-major N x N*/, con
 // ---------------------------------------------------------------------------
 // plain propagation with storage (backward sweep / iteration-0 forward sweep)
 // ---------------------------------------------------------------------------
-template <int MAXKS, int COLS>
+// SQ: the A^2 chain (one control, tables staged: c.sq != NULL) -- a template parameter, not a branch: with both forms in one
+// kernel the table prefetch of the one had to stay alive across the rounds of the other
+template <int MAXKS, int COLS, bool SQ>
 __global__ void __launch_bounds__(KH_COOP_THREADS)
 kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double *__restrict__ pulses,
                     const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out,
@@ -1175,7 +1177,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
     if (!kh_coop_place(c_in, g, y)) return;
     const int rowbase = g * 16;
     const int N = p.N, nt = p.nt, L = p.L;
-    if (tid <= KH_MAX_DEGREE) s.deg[tid] = (c_in.sq != nullptr && c_in.ser_theta != nullptr) ? c_in.ser_theta[tid] : p.deg_theta[tid];
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = (SQ && c_in.ser_theta != nullptr) ? c_in.ser_theta[tid] : p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
 #ifdef KH_TIMING
     if (tid < 12) s.tim[tid] = 0.0;
@@ -1205,7 +1207,7 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
     for (int q = 0; q < MAXKS; ++q) breg[q] = c_make(0.0, 0.0);
     for (int step = 0; step < nt - 1; ++step) {
         const int n = direction > 0 ? step : nt - 2 - step;
-        if (c.sq != nullptr && step % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
+        if (SQ && step % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
         double eps[KH_COOP_MAX_L];
         double theta = p.op_norms[0];
 #pragma unroll
@@ -1220,8 +1222,10 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
         int nsub, m;
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
-        if (c.sq != nullptr) {
+        if constexpr (SQ) {
             // the dense table of the fragment update: all its slots in flight at once (one trip to L2, not one per chunk)
+            // (issued at the END of the interval before instead -- the table is the same in every interval --: measured,
+            // no gain)
             cplx p1pre[MAXKS];
             kh_coop_reg_load<MAXKS>(c.tab[3], g, wave, lane, c.ks, p1pre, mk.p1);
             if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,

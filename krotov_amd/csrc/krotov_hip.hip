@@ -857,12 +857,18 @@ static int launch_c4_store(kh_engine *e, const KhSweepArgs &p, const double *pul
 template <int MAXKS, int COLS>
 static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
                              cplx *out, int direction, hipStream_t st) {
-    const int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS>, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
+    const bool sq = (direction < 0 ? e->d_coop_sq_bw : e->d_coop_sq_fw) != nullptr;
+    int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS, true>, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
+    if (rc == KH_OK)
+        rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS, false>, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
     return launch_coop_placed(e, [&](dim3 grid) {
-        return launch_persistent(kh_coop_sweep_store<MAXKS, COLS>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
+        if (sq)
+            return launch_persistent(kh_coop_sweep_store<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
+                                     coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
+        return launch_persistent(kh_coop_sweep_store<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
                                  coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
     });
 }
