@@ -627,9 +627,16 @@ __device__ __forceinline__ void kh_coop_round16(const KhCoopArgs &c, const KhExc
 // no replication across blocks, no ds_bpermute (208 of them per wave and round in the first version: 1.2 us).
 // Four row groups rb = 0..3 need four MFMA sets per group; the blocks' partial sums are added with two row
 // rotations, and the wave's 16 x 4 block goes to LDS as 64 values per component: element (row r, column c) at 4 r + c.
-template <int MAXKS, int COLS, class Frag>
+struct KhNoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// hook: the caller's work in the shadow of the block fetch -- called once the fetch's loads are issued, before the first
+// look at their tags; hook2: called when the blocks have arrived, in front of the matrix-core phase (loads issued there
+// arrive under it).  The plain sweeps' fragment updates: kh_coop_expm_action_sq_ahead.
+template <int MAXKS, int COLS, class Frag, class Hook = KhNoHook, class Hook2 = KhNoHook>
 __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y, int N,
-                                               const Frag &f, KhCoopLds &s, int tid, int wave, int lane, cplx &w) {
+                                               const Frag &f, KhCoopLds &s, int tid, int wave, int lane, cplx &w,
+                                               const Hook &hook = Hook(), const Hook2 &hook2 = Hook2()) {
     constexpr int MAXG = MAXKS / 4;  // groups per wave
     // (2 objectives: double-buffered by round parity -- the next round's barrier orders the reuse)
     double *part = kh_coop_part(s, c.ks) + (COLS == 2 ? (rid & 1u) * (KH_COOP_WAVES * KH_COOP_PART2) : 0);
@@ -683,6 +690,7 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
 #pragma unroll
         for (int i = 0; i < NGR; ++i) g[j][i] = (kh_u64)epoch << 32;
 #endif
+    hook();
     // (bitwise, not &&: a short-circuit chain over the tags compiles to nested branches)
     unsigned int bad_tags = 0u;
 #pragma unroll
@@ -752,6 +760,7 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
 #ifdef KH_TIMING
     const long long tq1 = clock64();
 #endif
+    hook2();
     double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};  // one accumulator pair per row group
     if constexpr (COLS == 4) {
 #pragma unroll
@@ -879,14 +888,17 @@ __device__ __forceinline__ void kh_coop_round4(const KhCoopArgs &c, const KhExch
 #endif
 }
 
-template <int MAXKS, int COLS, class Frag>
+template <int MAXKS, int COLS, class Frag, class Hook = KhNoHook, class Hook2 = KhNoHook>
 __device__ __forceinline__ void kh_coop_round(const KhCoopArgs &c, const KhExchange &ex, unsigned int rid, int y,
                                               int N, const Frag &f, KhCoopLds &s, int tid, int wave, int lane,
-                                              cplx &w) {
+                                              cplx &w, const Hook &hook = Hook(), const Hook2 &hook2 = Hook2()) {
     if constexpr (COLS <= 4)
-        kh_coop_round4<MAXKS, COLS>(c, ex, rid, y, N, f, s, tid, wave, lane, w);
-    else
+        kh_coop_round4<MAXKS, COLS>(c, ex, rid, y, N, f, s, tid, wave, lane, w, hook, hook2);
+    else {
+        hook2();  // (16 objectives per workgroup: in the open, in front of the round)
+        hook();
         kh_coop_round16<MAXKS, COLS>(c, ex, rid, y, N, f, s, tid, wave, lane, w);
+    }
 }
 
 // register fragment <- / += eps * (fragment-ordered operator)
@@ -1096,6 +1108,126 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
     return true;
 }
 
+// The same step for the PLAIN sweeps, whose pulse values are known in advance: the fragment updates leave the interval's
+// serial chain.  The dense P1 table -- 102 KB per workgroup: 1 600 cycles of the CU's vector-memory path, whatever its
+// latency -- arrives a quarter per round UNDER the matrix-core phases of the step's last four B rounds (requested when a
+// round's blocks are in: hook2); B (registers) is moved to the NEXT interval's pulse value inside the step's last round
+// -- the A round, which does not read B -- between the issue of that round's block fetch and the first look at the tags
+// (hook); A (LDS) follows one round later, inside the next step's first round (a B round, which does not read A).
+// eps_b / eps_a: the pulse values B and A stand at (0 after kh_coop_sq_restart); a B that is not at `eps` on entry --
+// first interval, restart -- is brought there in the open, as in kh_coop_expm_action_sq.
+template <int MAXKS, int COLS>
+__device__ __forceinline__ bool kh_coop_expm_action_sq_ahead(const KhCoopArgs &c, const KhExchange &ex, const KhCoopSqMasks &mk,
+                                                             double eps, double eps_next, bool have_next, double &eps_b,
+                                                             double &eps_a, const KhCoopFrag &a, cplx (&breg)[MAXKS],
+                                                             cplx &state, unsigned int &rid, KhCoopLds &s, int N, int y, int g,
+                                                             int row, int col, bool owner_valid, double fre, double fim,
+                                                             double dt, int nsub, int m, int tid, int wave, int lane) {
+    static_assert(MAXKS % 4 == 0, "quarters");
+    const double h = kh_uniform(nsub == 1 ? dt : dt / nsub);
+    const double f2h2 = kh_uniform((fre * fre - fim * fim) * h * h);
+    const int phases = (m + 1) >> 1;
+    const bool series = c.ser_rows != nullptr;
+    if (series) {
+        const double *grow = c.ser_rows + (size_t)m * KH_Q2_ROWS * 2;
+        if (tid < 2 * phases) s.coef[tid] = grow[tid];
+        if (tid == 2 * phases) s.coef[tid] = c.ser_c0[m];
+        __syncthreads();
+    }
+    const double *rows = series ? s.coef : nullptr;
+    const double c_0 = kh_uniform(series ? s.coef[2 * phases] : 1.0), c_1 = kh_uniform(series ? s.coef[0] : 1.0);
+    if (eps_b != eps) {  // (wave-uniform; rare)
+        const double e1 = eps - eps_b, e2 = e1 * (eps + eps_b);
+        kh_coop_reg_axpy<MAXKS>(c.tab[3], e1, g, wave, lane, c.ks, breg, mk.p1);
+        kh_coop_reg_axpy<MAXKS>(c.tab[4], e2, g, wave, lane, c.ks, breg, mk.p2);
+        eps_b = kh_uniform(eps);
+    }
+    const auto advance_a = [&]() {
+        if (eps_a != eps) {
+            kh_coop_axpy_frag<MAXKS>(c.tab[1], eps - eps_a, g, wave, lane, c.ks, a, mk.h1);
+            eps_a = kh_uniform(eps);
+        }
+    };
+    const KhCoopRegFrag<MAXKS> bf = {breg, ~0u};
+    const KhCoopSrc src1 = kh_coop_frag_src(c.tab[3], g, wave, lane, c.ks);
+    constexpr int QS = MAXKS / 4;  // slots of a quarter
+    for (int sub = 0; sub < nsub; ++sub) {
+        const bool ahead = have_next && sub + 1 == nsub;
+        const bool staged = ahead && phases >= 4;  // (otherwise: all of P1 requested in front of the A round)
+        cplx p1n[MAXKS];
+#pragma unroll
+        for (int q = 0; q < MAXKS; ++q) p1n[q] = c_make(0.0, 0.0);
+        cplx sacc = c_make(h * c_1 * state.x, h * c_1 * state.y);
+        state = c_make(c_0 * state.x, c_0 * state.y);
+        // one B round; hook2 (called when the round's blocks are in, in front of its matrix-core phase) requests a quarter
+        // of P1 in the step's last four B rounds -- peeled below, so that the registers the quarter lands in are constants
+        const auto b_round = [&](int ph, const auto &hook2) {
+            const double r2 = rows != nullptr ? rows[2 * ph + 1] : kh_inv_table[2 * ph + 1] * kh_inv_table[2 * ph + 2];
+            const double r1n = ph + 1 < phases ? (rows != nullptr ? rows[2 * ph + 2] : kh_inv_table[2 * ph + 3]) : 0.0;
+            cplx w;
+            kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, bf, s, tid, wave, lane, w, advance_a, hook2);
+            const double c2 = f2h2 * r2, hn = h * r1n;
+            if (kh_coop_is_owner<COLS>(tid)) {
+                const cplx t2 = c_make(c2 * w.x, c2 * w.y);
+                state.x += t2.x;
+                state.y += t2.y;
+                const bool last = (ph + 1 == phases);
+                if (!last) {
+                    sacc.x = fma(hn, t2.x, sacc.x);
+                    sacc.y = fma(hn, t2.y, sacc.y);
+                }
+                if (owner_valid) kh_coop_publish<COLS>(c, rid + 1, y, row, col, last ? sacc : t2, c.local != 0);
+            }
+            ++rid;
+        };
+        const int plain_rounds = staged ? phases - 4 : phases;
+        for (int ph = 0; ph < plain_rounds; ++ph) b_round(ph, KhNoHook());
+        if (staged) {
+            b_round(phases - 4, [&]() {
+#pragma unroll
+                for (int j = 0; j < QS; ++j) p1n[0 * QS + j] = src1[(size_t)(0 * QS + j) * 64];
+            });
+            b_round(phases - 3, [&]() {
+#pragma unroll
+                for (int j = 0; j < QS; ++j) p1n[1 * QS + j] = src1[(size_t)(1 * QS + j) * 64];
+            });
+            b_round(phases - 2, [&]() {
+#pragma unroll
+                for (int j = 0; j < QS; ++j) p1n[2 * QS + j] = src1[(size_t)(2 * QS + j) * 64];
+            });
+            b_round(phases - 1, [&]() {
+#pragma unroll
+                for (int j = 0; j < QS; ++j) p1n[3 * QS + j] = src1[(size_t)(3 * QS + j) * 64];
+            });
+        }
+        advance_a();  // (a step without B rounds: degree 0 -- not reached by the tables, kept for safety)
+        if (ahead && !staged) kh_coop_reg_load<MAXKS>(c.tab[3], g, wave, lane, c.ks, p1n, mk.p1);
+        const auto advance_b = [&]() {
+            if (ahead) {
+                const double e1 = eps_next - eps_b, e2 = e1 * (eps_next + eps_b);
+#pragma unroll
+                for (int q = 0; q < MAXKS; ++q) {
+                    breg[q].x = fma(e1, p1n[q].x, breg[q].x);
+                    breg[q].y = fma(e1, p1n[q].y, breg[q].y);
+                }
+                kh_coop_reg_axpy<MAXKS>(c.tab[4], e2, g, wave, lane, c.ks, breg, mk.p2);
+                eps_b = kh_uniform(eps_next);
+            }
+        };
+        cplx w;
+        kh_coop_round<MAXKS, COLS>(c, ex, rid, y, N, a, s, tid, wave, lane, w, advance_b);
+        if (s.abort) return false;
+        if (kh_coop_is_owner<COLS>(tid)) {
+            const cplx odd = c_mul(c_make(fre, fim), w);
+            state.x += odd.x;
+            state.y += odd.y;
+            if (owner_valid) kh_coop_publish<COLS>(c, rid + 1, y, row, col, state, c.local != 0);
+        }
+        ++rid;
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // Update sums on the adjoint side (one control, first order)
 // ---------------------------------------------------------------------------
@@ -1201,13 +1333,16 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
     int m_hint = 12;
     const KhCoopFrag a = {(cplx *)s.frag + tid};
     cplx breg[MAXKS];
-    double eps_prev = 0.0;
+    double eps_prev = 0.0, eps_a = 0.0;  // (the pulse values B and A stand at: kh_coop_expm_action_sq_ahead)
     const KhCoopSqMasks mk = kh_coop_sq_masks(c, g, wave);
 #pragma unroll
     for (int q = 0; q < MAXKS; ++q) breg[q] = c_make(0.0, 0.0);
     for (int step = 0; step < nt - 1; ++step) {
         const int n = direction > 0 ? step : nt - 2 - step;
-        if (SQ && step % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
+        if (SQ && step % KH_COOP_REFRESH == 0) {
+            kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
+            eps_a = 0.0;
+        }
         double eps[KH_COOP_MAX_L];
         double theta = p.op_norms[0];
 #pragma unroll
@@ -1223,13 +1358,11 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
         kh_degree_lookup(theta * dt, s.deg, p.theta_max, p.inv_theta_max, m_hint, &nsub, &m);
         m_hint = m;
         if constexpr (SQ) {
-            // the dense table of the fragment update: all its slots in flight at once (one trip to L2, not one per chunk)
-            // (issued at the END of the interval before instead -- the table is the same in every interval --: measured,
-            // no gain)
-            cplx p1pre[MAXKS];
-            kh_coop_reg_load<MAXKS>(c.tab[3], g, wave, lane, c.ks, p1pre, mk.p1);
-            if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,
-                                                     owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane, &p1pre))
+            const bool have_next = step + 1 < nt - 1;
+            const double eps_next = have_next ? pulses[direction > 0 ? n + 1 : n - 1] : 0.0;  // (one control)
+            if (!kh_coop_expm_action_sq_ahead<MAXKS, COLS>(c, ex, mk, eps[0], eps_next, have_next, eps_prev, eps_a, a, breg, state,
+                                                           rid, s, N, y, g, row, col, owner_valid, p.fre, p.fim, dt, nsub, m, tid,
+                                                           wave, lane))
                 return;
             rounds += (double)nsub * (((m + 1) >> 1) + 1);
         } else {
