@@ -1405,10 +1405,12 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
 // are taken on the adjoint side -- an element-wise product of the owners, no round -- and the dense P1 table of the
 // fragment update is fetched into registers while the sums cross the workgroups (the registers are those the control
 // operator's fragment needed before; the ~3 us L2-bound read sits in the shadow of the ~4.5 us exchange wait).
-template <int MAXKS, int COLS, bool SO, bool ADJ = false>
+// SQ: the A^2 chain (one control, tables staged) -- a template parameter like kh_coop_sweep_store's, not a branch on c.sq
+template <int MAXKS, int COLS, bool SO, bool ADJ = false, bool SQ = true>
 __global__ void __launch_bounds__(KH_COOP_THREADS)
 kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchange ex) {
     static_assert(!(SO && ADJ), "the second-order bra depends on the new state");
+    static_assert(SQ || !ADJ, "the adjoint-side form runs on the A^2 chain");
     extern __shared__ __attribute__((aligned(16))) char kh_coop_smem[];
     KhCoopLds &s = *(KhCoopLds *)kh_coop_smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1417,7 +1419,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     const int rowbase = g * 16;
     const int wg = y * c_in.G + g;  // linear workgroup index of the exchange
     const int N = p.N, nt = p.nt, L = p.L;
-    if (tid <= KH_MAX_DEGREE) s.deg[tid] = (c_in.sq != nullptr && c_in.ser_theta != nullptr) ? c_in.ser_theta[tid] : p.deg_theta[tid];
+    if (tid <= KH_MAX_DEGREE) s.deg[tid] = (SQ && c_in.ser_theta != nullptr) ? c_in.ser_theta[tid] : p.deg_theta[tid];
     if (tid == 0) s.abort = 0;
 #ifdef KH_TIMING
     if (tid < 12) s.tim[tid] = 0.0;
@@ -1452,7 +1454,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
     if constexpr (ADJ) bra_next = has_state ? u.adj_store[((size_t)k * nt) * N + row] : c_make(0.0, 0.0);
     for (int n = 0; n < nt - 1; ++n) {
         const int par = n & 1;
-        if ((ADJ || c.sq != nullptr) && n % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
+        if (SQ && n % KH_COOP_REFRESH == 0) kh_coop_sq_restart<MAXKS>(c, mk, g, wave, lane, a, breg, eps_prev);
         // co-state (and, second order, previous-iteration state) element of this owner; ADJ: the element of
         // H_1^+ chi(t_n), fetched one interval ahead
         cplx bra;
@@ -1486,7 +1488,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
         for (int l = 0; l < KH_COOP_MAX_L; ++l) {
             if (ADJ || l >= L) break;
             cplx w;
-            if (c.sq != nullptr) {  // (the LDS fragment holds A for the whole sweep: the control operator from registers)
+            if constexpr (SQ) {  // (the LDS fragment holds A for the whole sweep: the control operator from registers)
                 cplx hreg[MAXKS];
                 kh_coop_reg_load<MAXKS>(c.tab[1], g, wave, lane, c.ks, hreg, mk.h1);  // (sq: one control, l = 0)
                 const KhCoopRegFrag<MAXKS, true> hf = {hreg, mk.h1};
@@ -1570,7 +1572,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane, &p1pre))
                 return;
             rounds += nsub * (((m + 1) >> 1) + 1);
-        } else if (c.sq != nullptr) {
+        } else if constexpr (SQ) {
             if (!kh_coop_expm_action_sq<MAXKS, COLS>(c, ex, mk, eps[0], eps_prev, a, breg, state, rid, s, N, y, g, row, col,
                                                      owner_valid, p.fre, p.fim, dt, nsub, m, tid, wave, lane))
                 return;

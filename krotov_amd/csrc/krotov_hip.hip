@@ -878,9 +878,12 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
                               hipStream_t st) {
     KhUpdateArgs u = u_in;
     const bool adj = e->coop_adj && u.sigma == nullptr && e->L == 1 && e->d_coop_sq_fw != nullptr;
-    const void *func = u.sigma != nullptr ? (const void *)kh_coop_forward_update<MAXKS, COLS, true>
-                       : adj              ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, true>
-                                          : (const void *)kh_coop_forward_update<MAXKS, COLS, false>;
+    const bool sq = e->d_coop_sq_fw != nullptr;
+    const void *func = u.sigma != nullptr ? (sq ? (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, true>
+                                                : (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, false>)
+                       : adj              ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true>
+                       : sq               ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, false, true>
+                                          : (const void *)kh_coop_forward_update<MAXKS, COLS, false, false, false>;
     const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     if (adj) {
@@ -901,11 +904,15 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
     return launch_coop_placed(e, [&](dim3 grid) {
-        if (adj)
-            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
+        const size_t lds = kh_coop_lds_bytes(e->coop_ks, COLS);
+        const KhCoopArgs ca = coop_args(e, false);
+        if (adj) return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, true, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        if (u.sigma != nullptr && sq)
+            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true, false, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         if (u.sigma != nullptr)
-            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
-        return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p, coop_args(e, false), u, ex);
+            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true, false, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        if (sq) return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, false, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, false, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
     });
 }
 
