@@ -429,8 +429,9 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         matvecs += 1.0;
     };
 
-    const bool emit_only = (!u.internal_exchange && u.n_begin == u.n_end);
-    if ((u.internal_exchange || emit_only) && u.n_begin < nt - 1) {
+    // (this kernel is only launched as ONE launch over the sweep, sums exchanged in-kernel: the per-interval form of the
+    // sharded RCCL path runs kh_tile_forward_update -- krotov_hip.hip:launch_update; the branches for it are gone)
+    if (u.n_begin < nt - 1) {
         load_chi(u.n_begin);
         partial_pieces(u.n_begin & 1);
     }
@@ -441,11 +442,6 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         }
     }
     __syncthreads();
-    if (emit_only) {
-        const double part = partial_total(u.n_begin & 1);
-        if (tid == 0) u.wg_partial[k] = part;
-        return;
-    }
 
     double dt_next = kh_uniform(p.dt[u.n_begin]), guess_next = kh_uniform(u.guess[u.n_begin]),
            shape_next = kh_uniform(u.shape[u.n_begin]);
@@ -481,7 +477,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
 #endif
         // ---- cross-objective sum (optimize.py:470) ----
         cplx q1[8], q2[8];
-        if (u.internal_exchange) {
+        {
             double part[1] = {0.0};
             if (wave == 0) {
                 part[0] = partial_total(par);
@@ -521,18 +517,6 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
                     D_sh[par][1] = ok ? 1.0 : 0.0;
                 }
             }
-        } else {
-            if (tid == 0) {
-                D_sh[par][0] = u.D_in[0];
-                D_sh[par][1] = 1.0;
-            }
-#ifndef KH_Q2_NO_PREFETCH
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                q1[j] = s.h0[j * KH_Q2_THREADS + tid];
-                q2[j] = s.p0[j * KH_Q2_THREADS + tid];
-            }
-#endif
         }
         // (issued here, not before the exchange: measured 21.3 vs 22.1 ms per sweep)
         const double dt = dt_next, guess = guess_next, stepw = stepw_next;
@@ -620,11 +604,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
         u.phi[(size_t)k * N + lane] = s.buf[cur][lane];
         if constexpr (SO) u.fw_store[((size_t)k * nt + u.n_end) * N + lane] = s.buf[cur][lane];
     }
-    if (!u.internal_exchange && u.n_end < nt - 1) {
-        const double part = partial_total(u.n_end & 1);
-        if (tid == 0) u.wg_partial[k] = part;
-    }
-    if (k == 0 && tid == 0) u.g_a[0] = (u.internal_exchange ? 0.0 : u.g_a[0]) + g_a_loc;
+    if (k == 0 && tid == 0) u.g_a[0] = g_a_loc;
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }
 

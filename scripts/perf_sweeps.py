@@ -9,6 +9,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
+from krotov_amd import _lib
+if os.environ.get('KH_LIB'):  # (an experiment build of the library)
+    _lib.LIB_PATH = os.path.abspath(os.environ['KH_LIB'])
 from krotov_amd import configs
 from krotov_amd.engine import HipKrotovEngine
 
