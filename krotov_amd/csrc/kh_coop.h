@@ -1406,7 +1406,8 @@ kh_coop_sweep_store(KhSweepArgs p, KhCoopArgs c_in, KhExchange ex, const double 
 // fragment update is fetched into registers while the sums cross the workgroups (the registers are those the control
 // operator's fragment needed before; the ~3 us L2-bound read sits in the shadow of the ~4.5 us exchange wait).
 // SQ: the A^2 chain (one control, tables staged) -- a template parameter like kh_coop_sweep_store's, not a branch on c.sq
-template <int MAXKS, int COLS, bool SO, bool ADJ = false, bool SQ = true>
+// P2P = false: launched on a single GPU only (no cross-GPU stage in the sums' exchange: kh_exchange_collect)
+template <int MAXKS, int COLS, bool SO, bool ADJ = false, bool SQ = true, bool P2P = true>
 __global__ void __launch_bounds__(KH_COOP_THREADS)
 kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchange ex) {
     static_assert(!(SO && ADJ), "the second-order bra depends on the new state");
@@ -1527,7 +1528,7 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
             bool ok;
             if constexpr (ADJ) {  // (one control: half the gather registers next to the prefetched table)
                 double D1[1];
-                ok = kh_exchange<1>(ex, n, wg, 1, lane, part, D1);
+                ok = kh_exchange<1, KH_GATHER_CHUNKS, P2P>(ex, n, wg, 1, lane, part, D1);
                 D[0] = D1[0];
 #pragma unroll
                 for (int l = 1; l < KH_COOP_MAX_L; ++l) D[l] = 0.0;

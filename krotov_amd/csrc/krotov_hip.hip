@@ -881,7 +881,8 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     const bool sq = e->d_coop_sq_fw != nullptr;
     const void *func = u.sigma != nullptr ? (sq ? (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, true>
                                                 : (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, false>)
-                       : adj              ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true>
+                       : adj              ? (ex.world == 1 ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true, false>
+                                                            : (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true>)
                        : sq               ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, false, true>
                                           : (const void *)kh_coop_forward_update<MAXKS, COLS, false, false, false>;
     const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
@@ -906,6 +907,8 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     return launch_coop_placed(e, [&](dim3 grid) {
         const size_t lds = kh_coop_lds_bytes(e->coop_ks, COLS);
         const KhCoopArgs ca = coop_args(e, false);
+        if (adj && ex.world == 1)
+            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, true, true, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         if (adj) return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, true, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         if (u.sigma != nullptr && sq)
             return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true, false, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
