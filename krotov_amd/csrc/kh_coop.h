@@ -937,6 +937,37 @@ __device__ __forceinline__ void kh_coop_reg_axpy(const cplx *op, double eps, int
     }
 }
 
+// r += er * opr and (LDS fragment) a += ea * opa, chunk by chunk, BOTH tables' reads of a chunk (and the fragment's LDS reads)
+// issued before any is used: for a banded control operator the non-zero chunk of P2 and of H1 is the same chunk of the
+// same wave -- one trip to L2 instead of two in a row (a chunk is read if either table has something in it: the tables
+// are zero-padded, a zero chunk adds nothing)
+template <int MAXKS>
+__device__ __forceinline__ void kh_coop_axpy_pair(const cplx *opr, double er, cplx (&r)[MAXKS], const cplx *opa, double ea,
+                                                  const KhCoopFrag &a, int g, int wave, int lane, int ks, unsigned int mask) {
+    const KhCoopSrc sr = kh_coop_frag_src(opr, g, wave, lane, ks), sa = kh_coop_frag_src(opa, g, wave, lane, ks);
+#pragma unroll
+    for (int c0 = 0; c0 < MAXKS; c0 += 4) {
+        if (c0 < ks && ((mask >> c0) & 0xfu) != 0u) {
+            cplx vr[4], va[4], t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // (slots >= ks do not exist: clamped address, value dropped; a NULL table reads zeros)
+                const int q = c0 + j < ks ? c0 + j : ks - 1;
+                vr[j] = sr[(size_t)q * 64];
+                va[j] = sa[(size_t)q * 64];
+                t[j] = a.get(c0 + j < MAXKS ? c0 + j : MAXKS - 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (c0 + j < ks) {
+                    r[c0 + j].x = fma(er, vr[j].x, r[c0 + j].x);
+                    r[c0 + j].y = fma(er, vr[j].y, r[c0 + j].y);
+                    a.f[(size_t)(c0 + j) * KH_COOP_THREADS] = c_make(fma(ea, va[j].x, t[j].x), fma(ea, va[j].y, t[j].y));
+                }
+            }
+        }
+    }
+}
+
 // A = op_0 + sum_l eps_l op_l (fragments rebuilt from L2 once per interval; ops: fragment-ordered copies)
 template <int MAXKS>
 __device__ __forceinline__ void kh_coop_build(const cplx *const *ops, const double *eps, int L, int g, int wave,
@@ -1041,8 +1072,9 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
         const long long tr0 = clock64();
 #endif
         const double e1 = eps - eps_prev, e2 = e1 * (eps + eps_prev);
-#ifndef KH_COOP_X_NOP1  // (timing experiment: wrong results)
         if (p1pre != nullptr) {
+            // (the prefetched P1 behind the two sparse tables: their reads are on their way while its 128 FMAs run)
+            kh_coop_axpy_pair<MAXKS>(c.tab[4], e2, breg, c.tab[1], e1, a, g, wave, lane, c.ks, mk.p2 | mk.h1);
 #pragma unroll
             for (int q = 0; q < MAXKS; ++q) {
                 breg[q].x = fma(e1, (*p1pre)[q].x, breg[q].x);
@@ -1050,12 +1082,9 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq(const KhCoopArgs &c, cons
             }
         } else {
             kh_coop_reg_axpy<MAXKS>(c.tab[3], e1, g, wave, lane, c.ks, breg, mk.p1);
+            kh_coop_reg_axpy<MAXKS>(c.tab[4], e2, g, wave, lane, c.ks, breg, mk.p2);
+            kh_coop_axpy_frag<MAXKS>(c.tab[1], e1, g, wave, lane, c.ks, a, mk.h1);
         }
-#endif
-#ifndef KH_COOP_X_NOP2H1
-        kh_coop_reg_axpy<MAXKS>(c.tab[4], e2, g, wave, lane, c.ks, breg, mk.p2);
-        kh_coop_axpy_frag<MAXKS>(c.tab[1], e1, g, wave, lane, c.ks, a, mk.h1);
-#endif
         eps_prev = kh_uniform(eps);
 #ifdef KH_TIMING
         if (tid == 0 && blockIdx.x == 0) {
