@@ -327,7 +327,10 @@ kh_tile_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx
 // and the running state never leave the registers / LDS of their workgroup.
 // Barriers per interval: 1 (partial sums) + 1 (broadcast of the reduced sums)
 // + one per Taylor term.
-template <int RPT, int LT, bool SO>  // SO: second-order update, compiled separately
+// SO: second-order update, compiled separately.  SINGLE: launched on ONE GPU as one launch over the sweep with more than one
+// workgroup (ex.world == 1, ex.G > 1, u.internal_exchange): the sums' exchange without the cross-GPU stage and without the
+// forms it does not take -- an instantiation of its own because the kernel sits at the register limit
+template <int RPT, int LT, bool SO, bool SINGLE = false>
 __global__ void __launch_bounds__(512 / RPT, 2)
 kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     if (u.n_dev != nullptr) {  // graph-replayed stepwise mode: interval index from device memory
@@ -463,9 +466,9 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         const int par = n & 1;
         if (n + 1 < nt - 1) load_chi(n + 1);  // lands while this interval is processed
         // ---- cross-objective sum (optimize.py:470) ----
-        if (u.internal_exchange) {
+        if (SINGLE || u.internal_exchange) {
             constexpr int CH = RPT == 2 ? KH_GATHER_CHUNKS_WIDE : KH_GATHER_CHUNKS;  // (256-thread workgroups run two per CU)
-            if (LT > 1 && LT <= WAVES && ex.world == 1 && ex.G > 1) {
+            if (LT > 1 && LT <= WAVES && (SINGLE || (ex.world == 1 && ex.G > 1))) {
                 // several controls, one GPU: wave 0 publishes all of them, wave l gathers control l -- L polling
                 // rounds side by side instead of one wave polling 8 L granules per lane (measured: the exchange cost
                 // 2.4 us per interval at L = 2 and 4.1 us at L = 4 against 1.25 us with one control)
@@ -486,7 +489,7 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
                 double part[LT];
                 partial_total(par, part);
                 double D[LT];
-                const bool ok = kh_exchange<LT, CH>(ex, n, k, LT, lane, part, D);
+                const bool ok = kh_exchange<LT, CH, !SINGLE>(ex, n, k, LT, lane, part, D);
                 if (lane == 0) {
 #pragma unroll
                     for (int l = 0; l < LT; ++l) {

@@ -1018,6 +1018,15 @@ static int launch_tile_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     // so the stores get a longer head start -- measured best on config-5 shapes: 24 / 28 / 32 x 64 cycles for L = 2 / 3 / 4
     // (update sweep 7.47 / - / 9.86 us per interval against 7.92 / - / 11.21 with 16)
     if (LT >= 2 && !e->poll_delay_set) exl.first_poll_delay = 24 + 4 * (LT - 2);
+    if (exl.world == 1 && exl.G > 1 && !(getenv("KH_TILE_SINGLE") && atoi(getenv("KH_TILE_SINGLE")) == 0)) {
+        const void *fs = u.sigma != nullptr ? (const void *)kh_tile_forward_update<RPT, LT, true, true>
+                                            : (const void *)kh_tile_forward_update<RPT, LT, false, true>;
+        const int rcs = ensure_dynamic_lds(e, fs, lds);
+        if (rcs != KH_OK) return rcs;
+        if (u.sigma != nullptr)
+            return launch_persistent(kh_tile_forward_update<RPT, LT, true, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+        return launch_persistent(kh_tile_forward_update<RPT, LT, false, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+    }
     if (u.sigma != nullptr)
         return launch_persistent(kh_tile_forward_update<RPT, LT, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
     return launch_persistent(kh_tile_forward_update<RPT, LT, false>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
