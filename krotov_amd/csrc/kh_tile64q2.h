@@ -335,7 +335,9 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
 // wave 0 has ~1 us between its store and the first useful poll), and what is left after the last Taylor phase
 // -- one complex multiply per row, the wave sum, one LDS write -- rides on that phase's barrier: the separate
 // "partial sums" step (8 LDS reads, 32 FMAs, row sums, a barrier: 0.46 us of 6 per interval) disappears.
-template <bool SO, bool ADJ>
+// SINGLE: launched on one GPU (ex.world == 1): the sums' exchange without the cross-GPU stage -- its code, inlined by a
+// run-time branch otherwise, costs this kernel the handful of registers that spill (256 VGPRs, 6 spilled -> 253, none)
+template <bool SO, bool ADJ, bool SINGLE = false>
 __global__ void __launch_bounds__(KH_Q2_THREADS)
 kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdateArgs u, KhExchange ex) {
     static_assert(!(SO && ADJ), "the second-order bra depends on the new state");
@@ -507,7 +509,7 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
 #ifdef KH_TIMING
                 const long long tc0 = clock64();
 #endif
-                const bool ok = kh_exchange_collect<1>(ex, n, k, 1, lane, part, D);
+                const bool ok = kh_exchange_collect<1, KH_GATHER_CHUNKS, !SINGLE>(ex, n, k, 1, lane, part, D);
 #ifdef KH_TIMING
                 t_coll += clock64() - tc0;
 #endif

@@ -689,6 +689,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false, true, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<true, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
 
@@ -1076,7 +1078,10 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         else if (u.adj_sign != 0.0) {
             KhExchange exa = ex;
             exa.first_poll_delay = e->adj_poll_delay;
-            rc = launch_persistent(kh_q2_forward_update<false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
+            if (exa.world == 1)  // (the default form on one GPU: an instantiation without the cross-GPU stage)
+                rc = launch_persistent(kh_q2_forward_update<false, true, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
+            else
+                rc = launch_persistent(kh_q2_forward_update<false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
         } else
             rc = launch_persistent(kh_q2_forward_update<false, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_COOP && !stepwise) {
