@@ -691,6 +691,10 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false, true, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<false, false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
+        KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<true, false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
         KH_HIP_E(hipFuncSetAttribute((const void *)kh_q2_forward_update<true, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kh_q2_lds_bytes()));
 
@@ -1073,7 +1077,9 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             kh_mini_forward_update<false><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
         const dim3 g(e->K), b(KH_Q2_THREADS);
-        if (u.sigma != nullptr)
+        if (u.sigma != nullptr && ex.world == 1)
+            rc = launch_persistent(kh_q2_forward_update<true, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+        else if (u.sigma != nullptr)
             rc = launch_persistent(kh_q2_forward_update<true, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else if (u.adj_sign != 0.0) {
             KhExchange exa = ex;
@@ -1082,7 +1088,9 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
                 rc = launch_persistent(kh_q2_forward_update<false, true, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
             else
                 rc = launch_persistent(kh_q2_forward_update<false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
-        } else
+        } else if (ex.world == 1)
+            rc = launch_persistent(kh_q2_forward_update<false, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+        else
             rc = launch_persistent(kh_q2_forward_update<false, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_COOP && !stepwise) {
         if (e->coop_cols == 2)
