@@ -1077,18 +1077,20 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             kh_mini_forward_update<false><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
         const dim3 g(e->K), b(KH_Q2_THREADS);
-        if (u.sigma != nullptr && ex.world == 1)
+        // (KH_Q2_SINGLE=0: the instantiations with the cross-GPU stage on one GPU too -- A/B switch)
+        const bool single = ex.world == 1 && !(getenv("KH_Q2_SINGLE") && atoi(getenv("KH_Q2_SINGLE")) == 0);
+        if (u.sigma != nullptr && single)
             rc = launch_persistent(kh_q2_forward_update<true, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else if (u.sigma != nullptr)
             rc = launch_persistent(kh_q2_forward_update<true, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else if (u.adj_sign != 0.0) {
             KhExchange exa = ex;
             exa.first_poll_delay = e->adj_poll_delay;
-            if (exa.world == 1)  // (the default form on one GPU: an instantiation without the cross-GPU stage)
+            if (single)  // (the default form on one GPU: an instantiation without the cross-GPU stage)
                 rc = launch_persistent(kh_q2_forward_update<false, true, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
             else
                 rc = launch_persistent(kh_q2_forward_update<false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
-        } else if (ex.world == 1)
+        } else if (single)
             rc = launch_persistent(kh_q2_forward_update<false, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else
             rc = launch_persistent(kh_q2_forward_update<false, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
