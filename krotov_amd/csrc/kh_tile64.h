@@ -227,6 +227,9 @@ struct KhTileLds {
     // drift is parked as well (64 KiB per workgroup, 128 KiB per CU) -- generator + control + broadcast vector then fit
     static constexpr int UPDATE = (RPT == 1 && LT >= 3) ? LT - 2 : (RPT == 2 && LT == 1) ? 1 : 0;
     static constexpr int STORE = (RPT == 1 && LT >= 4) ? 1 : (RPT == 2 && LT == 1) ? 1 : 0;
+    // the update kernel's single-GPU instantiation has registers to spare (kh_tile_forward_update: SINGLE): three controls
+    // park nothing there
+    static constexpr int UPDATE_SINGLE = (RPT == 1 && LT == 3) ? 0 : UPDATE;
     static constexpr size_t bytes(int nl) { return (size_t)nl * KH_TILE_N * KH_TILE_N * sizeof(cplx); }
 };
 
@@ -356,7 +359,7 @@ kh_tile_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
 
     const cplx *const *ops_k = p.ops + (size_t)k * (1 + LT);
     const double *norms_k = p.op_norms + (size_t)k * (1 + LT);
-    KhTileOps<RPT, LT, KhTileLds<RPT, LT>::UPDATE> h;
+    KhTileOps<RPT, LT, SINGLE ? KhTileLds<RPT, LT>::UPDATE_SINGLE : KhTileLds<RPT, LT>::UPDATE> h;
     h.load(ops_k, N, wave, lane, kh_tile_dyn_lds, tid);
     double nrm[1 + LT];
 #pragma unroll
