@@ -299,10 +299,12 @@ def _plain(value):
     tuples, dicts (states / operators -> arrays; lazy state lists -> lists)."""
     from ._ingest import to_dense
 
+    if isinstance(value, np.generic):
+        # (first: np.float64 / np.complex128 ARE Python floats / complex numbers by inheritance, and would otherwise
+        # travel as NumPy scalars -- pickled under numpy._core.multiarray.scalar, a name NumPy 1.x cannot resolve)
+        return value.item()
     if value is None or isinstance(value, (bool, int, float, complex, str, bytes, time.struct_time)):
         return value
-    if isinstance(value, np.generic):
-        return value.item()
     if isinstance(value, np.ndarray):
         return value if value.dtype != object else [_plain(v) for v in value]
     if isinstance(value, dict):

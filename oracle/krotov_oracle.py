@@ -22,6 +22,10 @@ What is restated (reference file:line, relative to /root/reference/src/krotov):
   * dH/d eps                            mu.py:123-140
   * overlap                             second_order.py:69-83
   * update shapes                       shapes.py:51-174
+  * DensityMatrixODEPropagator step     propagators.py:162-327 (``step_ode``: the same
+    ``scipy.integrate.ode`` 'zvode' call with the reference's defaults, re-initialised
+    every step as ``reentrant=True`` does; pinned by the reference's own result for it,
+    docs/notebooks/3states_opt_result.dump -> tests/golden/dump_3states.npz)
 
 The arithmetic below L1 lives in QuTiP 4.x / SciPy (not vendored in the
 reference).  The dense matrix exponential here is the published [13/13] Pade
@@ -65,6 +69,7 @@ __all__ = [
     'chis_hs',
     'initialize_controls',
     'step',
+    'step_ode',
     'forward_propagation',
     'backward_sweep',
     'forward_update_sweep',
@@ -277,11 +282,17 @@ class OracleProblem:
         tlist: (nt,) float64.
     """
 
-    def __init__(self, ops, init, target, tlist, is_super=False, weights=None):
-        self.ops = [
-            [None if o is None else np.asarray(o, dtype=np.complex128) for o in row]
-            for row in ops
-        ]
+    def __init__(self, ops, init, target, tlist, is_super=False, weights=None, ode=None):
+        # ``ode``: dict of DensityMatrixODEPropagator options (possibly empty) -> every step is
+        # ``step_ode`` on sparse (CSR) operators instead of the dense matrix exponential
+        self.ode = ode
+        if ode is not None:
+            self.ops = [[None if o is None else o.tocsr().astype(np.complex128) for o in row] for row in ops]
+        else:
+            self.ops = [
+                [None if o is None else np.asarray(o, dtype=np.complex128) for o in row]
+                for row in ops
+            ]
         self.init = np.asarray(init, dtype=np.complex128)
         self.target = np.asarray(target, dtype=np.complex128)
         self.tlist = np.asarray(tlist, dtype=np.float64)
@@ -297,6 +308,8 @@ class OracleProblem:
 
     def adjoint_ops(self):
         """Operators of the adjoint objectives (objectives.py:240-258)."""
+        if self.ode is not None:
+            return [[None if o is None else o.conj().T.tocsr() for o in row] for row in self.ops]
         return [
             [None if o is None else o.conj().T for o in row] for row in self.ops
         ]
@@ -366,6 +379,41 @@ def step(ops_k, eps_n, dt, state, is_super=False, backwards=False, use_scipy=Fal
     return expm_dense(A * dt, use_scipy) @ state
 
 
+_ODE_DEFAULTS = dict(method='adams', order=12, atol=1e-8, rtol=1e-6, nsteps=1000, first_step=0, min_step=0,
+                     max_step=0)  # propagators.py:181-191
+
+
+def step_ode(ops_k, eps_n, dt, state, options=None):
+    """One call of ``DensityMatrixODEPropagator(reentrant=True)`` (propagators.py:162-327): integrate
+    d/dt vec(rho) = (L0 + sum_l eps_l L_l) vec(rho) over ``dt`` with SciPy's 'zvode' (Adams, order 12, atol 1e-8,
+    rtol 1e-6), the integrator re-initialised for the step (:242-243, :308-327); the right-hand side is the sum of
+    coefficient x CSR matrix-vector products (:264-275).  ``backwards`` has no effect there (:216-220): the caller
+    passes the adjoint objective's operators."""
+    import scipy.integrate
+
+    opts = dict(_ODE_DEFAULTS)
+    opts.update(options or {})
+    terms = [(ops_k[0], 1.0)] + [(ops_k[l], eps_n[l - 1]) for l in range(1, len(ops_k)) if ops_k[l] is not None]
+
+    def rhs(t, rho):
+        out = np.zeros(rho.shape[0], dtype=complex)
+        for L, coeff in terms:
+            out += coeff * (L @ rho)
+        return out
+
+    r = scipy.integrate.ode(rhs)
+    r.set_integrator('zvode', **opts)
+    r.set_initial_value(np.asarray(state, dtype=np.complex128))
+    r.integrate(dt)
+    return np.array(r.y)
+
+
+def _step(problem, ops_k, eps_n, dt, state, backwards, use_scipy):
+    if problem.ode is not None:
+        return step_ode(ops_k, eps_n, dt, state, problem.ode)
+    return step(ops_k, eps_n, dt, state, problem.is_super, backwards, use_scipy)
+
+
 # --------------------------------------------------------------------------
 # control initialisation (optimize.py:641-704)
 # --------------------------------------------------------------------------
@@ -425,7 +473,7 @@ def forward_propagation(problem, pulses, store=False, use_scipy=False):
         for n in range(nt - 1):
             dt = tl[n + 1] - tl[n]
             eps = [p[n] for p in pulses]
-            state = step(problem.ops[k], eps, dt, state, problem.is_super, False, use_scipy)
+            state = _step(problem, problem.ops[k], eps, dt, state, False, use_scipy)
             if store:
                 out[k, n + 1] = state
         fw_T[k] = state
@@ -460,7 +508,7 @@ def backward_sweep(problem, chi_T, pulses, use_scipy=False, objectives=None):
         for n in range(nt - 2, -1, -1):
             dt = tl[n + 1] - tl[n]
             eps = [np.conjugate(p[n]) for p in pulses]
-            state = step(adj[k], eps, dt, state, problem.is_super, True, use_scipy)
+            state = _step(problem, adj[k], eps, dt, state, True, use_scipy)
             out[i, n] = state
     return out
 
@@ -520,7 +568,7 @@ def forward_update_sweep(problem, chi_store, chi_norms, guess_pulses, shapes, la
             g_a[l] += (S_t / lambdas[l]) * abs(d1) ** 2 * dt
         eps = [p[n] for p in opt]
         for k in range(K):
-            fw[k] = step(problem.ops[k], eps, dt, fw[k], problem.is_super, False, use_scipy)
+            fw[k] = _step(problem, problem.ops[k], eps, dt, fw[k], False, use_scipy)
             if second_order:
                 delta[k] = fw[k] - fw_prev[k, n + 1]  # optimize.py:494-497
             if store:

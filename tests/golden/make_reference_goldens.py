@@ -175,6 +175,39 @@ def make_dump_fixtures():
     )
     print('dump_transmon17: iters[:8]', st['iters'][:8])
 
+    # --- two transmons in Liouville space, 625-dim sparse Liouvillian, K=3, L=2 (notebook 06) ----------
+    # The reference's one result for its DensityMatrixODEPropagator (propagators.py:162-327).  The dump holds the
+    # objectives themselves (QuTiP objects): this package's own Result.load rebuilds them as arrays; the super-
+    # operators are kept in CSR form (a few entries per row).  The run was continued from iteration 3
+    # (notebook cell 54), so `guess_controls` are the controls AT iteration 3.
+    import scipy.sparse as sp
+
+    import krotov_amd
+
+    res = krotov_amd.result.Result.load(os.path.join(REF, 'docs/notebooks/3states_opt_result.dump'))
+    objs = res.objectives
+    L_ops = [np.asarray(objs[0].H[0])] + [np.asarray(objs[0].H[i][0]) for i in (1, 2)]
+    for o in objs[1:]:  # all three objectives share the Liouvillian
+        assert all(np.array_equal(np.asarray(o.H[0] if i == 0 else o.H[i][0]), L_ops[i]) for i in range(3))
+    csr = [sp.csr_matrix(A) for A in L_ops]
+    for c in csr:
+        c.sum_duplicates()
+        c.eliminate_zeros()
+    arrays = {}
+    for i, c in enumerate(csr):
+        arrays['L%d_data' % i], arrays['L%d_indices' % i], arrays['L%d_indptr' % i] = c.data, c.indices, c.indptr
+    np.savez_compressed(
+        os.path.join(HERE, 'dump_3states.npz'),
+        tlist=np.asarray(res.tlist), N=625,
+        rho0=np.array([np.asarray(o.initial_state) for o in objs]),    # (3, 25, 25)
+        rho_tgt=np.array([np.asarray(o.target) for o in objs]),
+        weights=np.array([o.weight for o in objs]),
+        controls_it3=np.array(res.guess_controls),                     # (2, 2000) on the time grid
+        tau_vals=np.array(res.tau_vals[:12]), info_vals=np.array(res.info_vals[:12], dtype=np.float64),
+        iters=np.array(res.iters[:12]), lambda_a=1.0, t_rise=20.0,
+        **arrays)
+    print('dump_3states: nnz', [c.nnz for c in csr], 'iters[:6]', res.iters[:6], 'J_T[:6]', res.info_vals[:6])
+
 
 # ---------------------------------------------------------------------------
 # B. the real reference loop under stub third-party modules
@@ -283,7 +316,16 @@ REF_CASES = {
     'ref_c5_small': (lambda c: c.config_c5(K=6, N=16, nt=201, L=1), 2),
     'ref_c5_small_L3': (lambda c: c.config_c5(K=5, N=12, nt=151, L=3, distinct=True), 2),
     'ref_c5_n64': (lambda c: c.config_c5(K=8, N=64, nt=401, L=1), 2),
+    # chis_hs (functionals.py:389-437): the boundary co-state depends on rho(T) itself, not only on tau
+    # (config_c2_liouville is no use here: one of its three states is invariant, chi_k(T) = 0, and the reference
+    # divides by its norm -- NaN pulses)
+    'ref_c4_small_hs': (lambda c: _with_chi(c.config_c4(d=5, nt=201, n_logical=2), 'hs'), 2),
 }
+
+
+def _with_chi(spec, chi):
+    spec.chi = chi
+    return spec
 
 
 def make_ref_fixtures(names=None):

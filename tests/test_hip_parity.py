@@ -539,7 +539,14 @@ GOLDEN_CASES = {
     'ref_c5_small': lambda: configs.config_c5(K=6, N=16, nt=201, L=1),
     'ref_c5_small_L3': lambda: configs.config_c5(K=5, N=12, nt=151, L=3, distinct=True),
     'ref_c5_n64': lambda: configs.config_c5(K=8, N=64, nt=401, L=1),
+    # chis_hs from the reference's own loop (functionals.py:389-437): chi_k(T) = w/2K (rho_tgt - rho(T))
+    'ref_c4_small_hs': lambda: _with_chi(configs.config_c4(d=5, nt=201, n_logical=2), 'hs'),
 }
+
+
+def _with_chi(spec, chi):
+    spec.chi = chi
+    return spec
 
 
 def _optimize_on_device(spec, iters, **kw):
@@ -577,7 +584,7 @@ def test_optimize_pulses_vs_reference_loop_goldens(name):
     spec = GOLDEN_CASES[name]()
     res = _optimize_on_device(spec, int(g['iter_stop']))
     got = np.array([np.array(p) for p in res.all_pulses])
-    tol = 2e-11 if name == 'ref_c4_small' else 2e-12
+    tol = 1e-10 if name == 'ref_c4_small_hs' else (2e-11 if name == 'ref_c4_small' else 2e-12)
     scale = max(1.0, np.abs(g['all_pulses']).max())
     assert np.abs(got - g['all_pulses']).max() < tol * scale
     assert np.abs(np.array(res.tau_vals) - g['tau_vals']).max() < tol
@@ -650,6 +657,95 @@ def test_ensemble_dump_on_device():
     res = krotov_amd.optimize_pulses(objs, opts, g['tlist'], propagator=krotov_amd.propagators.expm,
                                      chi_constructor=krotov_amd.functionals.chis_re, iter_stop=4)
     assert np.abs(np.array(res.tau_vals) - g['tau_vals'][12:17]).max() < 1e-9
+
+
+def _lambda_dump_on_device(g, controls, lambda_a, iters):
+    """The Lambda system of the reference's notebooks 02 / 03 (one objective, N = 3, four controls) from a dump
+    fixture's controls, `iters` iterations on the GPU."""
+    ctrls = [np.array(c, dtype=np.float64) for c in controls]
+    T = g['tlist'][-1]
+    S = lambda t: krotov_amd.shapes.flattop(t, 0.0, T, 0.3, func='sinsq')  # noqa: E731
+    H = [g['H0']] + [[g['Hc'][l], ctrls[l]] for l in range(4)]
+    obj = krotov_amd.Objective(initial_state=np.array([1, 0, 0], dtype=complex), target=g['target'], H=H)
+    opts = {id(c): dict(lambda_a=lambda_a, update_shape=S) for c in ctrls}
+    return krotov_amd.optimize_pulses([obj], opts, g['tlist'], propagator=krotov_amd.propagators.expm,
+                                      chi_constructor=krotov_amd.functionals.chis_re, iter_stop=iters)
+
+
+def test_nonherm_dump_on_device():
+    """reference docs/notebooks/non_herm_opt_result.dump, iterations 40 -> 45: H0 has an anti-Hermitian part (decay of
+    the intermediate level), so this is the fixture that pins the backward step exp(+i H^dagger dt) -- on
+    the device through the adjoint operators the engine stages, and through the Taylor series (no real spectrum)."""
+    g = golden('dump_nonherm')
+    res = _lambda_dump_on_device(g, g['controls_it40'], float(g['lambda_a']), 5)
+    assert np.abs(np.array(res.tau_vals) - g['tau_vals'][40:46]).max() < 1e-9
+    from krotov_amd.engine import LAST_ENGINE
+
+    assert LAST_ENGINE().kernel.startswith('tile64')
+
+
+@pytest.mark.parametrize('kernel', [None, 'generic'])
+def test_nonherm_dump_kernel_families(kernel, monkeypatch):
+    """... and the same through the generic kernels (the register-tile family runs by default)."""
+    if kernel is not None:
+        monkeypatch.setenv('KH_KERNEL', kernel)
+    g = golden('dump_nonherm')
+    res = _lambda_dump_on_device(g, g['controls_it40'], float(g['lambda_a']), 2)
+    assert np.abs(np.array(res.tau_vals) - g['tau_vals'][40:43]).max() < 1e-9
+
+
+def test_lambda_rwa_dump_on_device():
+    """reference docs/notebooks/lambda_rwa_opt_result.dump: all 12 iterations from the true guess (N = 3, L = 4)."""
+    g = golden('dump_lambda_rwa')
+    res = _lambda_dump_on_device(g, g['guess_controls'], 0.5, 12)
+    assert np.abs(np.array(res.tau_vals) - g['tau_vals']).max() < 1e-9
+    # and where the reference ended up: its optimized controls (on the time grid)
+    assert np.abs(np.array(res.optimized_controls) - g['optimized_controls']).max() < 1e-8
+
+
+def _three_states_problem():
+    """The reference's notebook 06 from tests/golden/dump_3states.npz: two coupled 5-level transmons in Liouville space
+    (625-dim sparse Liouvillian, 4.8-6.4 entries per row), sqrt(iSWAP) by the three-states method with weights, two
+    controls (Re / Im of the drive), 2000 grid points; controls at iteration 3 of the reference's run."""
+    import scipy.sparse as sp
+
+    g = golden('dump_3states')
+    N = int(g['N'])
+    L = [sp.csr_matrix((g['L%d_data' % i], g['L%d_indices' % i], g['L%d_indptr' % i]), shape=(N, N)) for i in range(3)]
+    ctrls = [np.array(c, dtype=np.float64) for c in g['controls_it3']]
+    T = g['tlist'][-1]
+    S = lambda t: krotov_amd.shapes.flattop(t, 0.0, T, float(g['t_rise']))  # noqa: E731  (notebook cell 50)
+    objs = []
+    for k in range(3):
+        obj = krotov_amd.Objective(initial_state=g['rho0'][k], target=g['rho_tgt'][k], H=[L[0], [L[1], ctrls[0]], [L[2], ctrls[1]]])
+        obj.weight = float(g['weights'][k])
+        objs.append(obj)
+    opts = {id(c): dict(lambda_a=float(g['lambda_a']), update_shape=S) for c in ctrls}
+    return g, objs, opts
+
+
+def test_three_states_dump_sparse_propagator_on_device():
+    """reference docs/notebooks/3states_opt_result.dump -- the reference's ONE result for its
+    DensityMatrixODEPropagator (propagators.py:162-327) -- iterations 3 -> 6 on the CSR path of the engine
+    (kh_engine_create_csr).  The reference integrates with zvode at rtol 1e-6 / atol 1e-8; the engine takes the exact
+    exponential action, so the agreement is the ODE solver's accuracy (measured here: see the assertion), not round-off.
+    The oracle's restatement of the zvode step reproduces the dump to 2e-12 (tests/test_oracle_golden.py)."""
+    g, objs, opts = _three_states_problem()
+    res = krotov_amd.optimize_pulses(
+        objs, opts, g['tlist'], propagator=krotov_amd.propagators.DensityMatrixODEPropagator(reentrant=True),
+        chi_constructor=krotov_amd.functionals.chis_re,
+        info_hook=krotov_amd.info_hooks.print_table(J_T=krotov_amd.functionals.J_T_re, out=open(os.devnull, 'w')),
+        iter_stop=3)
+    from krotov_amd.engine import LAST_ENGINE
+
+    assert LAST_ENGINE().kernel.endswith('csr')
+    tau = np.array(res.tau_vals)
+    assert np.abs(tau - g['tau_vals'][3:7]).max() < 1e-5
+    assert np.abs(np.array(res.info_vals) - g['info_vals'][3:7]).max() < 1e-5
+    # the optimisation moves: iteration 6 is not iteration 3
+    assert np.abs(g['tau_vals'][6] - g['tau_vals'][3]).max() > 50e-5
+    print("3states: max |d tau| = %.2e, max |d J_T| = %.2e" % (
+        np.abs(tau - g['tau_vals'][3:7]).max(), np.abs(np.array(res.info_vals) - g['info_vals'][3:7]).max()))
 
 
 def test_runs_are_bitwise_repeatable():

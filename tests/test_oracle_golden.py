@@ -132,6 +132,31 @@ def test_transmon17_dump_iterations_5_to_8():
         assert np.abs(tau - g['tau_vals'][it]).max() < 1e-8, it
 
 
+def test_three_states_dump_ode_propagator_iteration_3_to_4():
+    """reference docs/notebooks/3states_opt_result.dump (notebook 06): the reference's only result for its
+    DensityMatrixODEPropagator -- 625-dim sparse Liouvillian, K = 3 weighted density matrices, L = 2, 2000 grid points,
+    trace norm of the co-states (Qobj.norm() default).  The oracle restates the propagator's zvode step (``step_ode``),
+    so one whole iteration -- continued from the controls at iteration 3 as the reference's run was -- lands on the
+    dump's tau and J_T_re of iteration 4 to round-off (measured 2e-12), far inside the solver's own rtol = 1e-6."""
+    sp = pytest.importorskip('scipy.sparse')
+    g = golden('dump_3states')
+    N = int(g['N'])
+    L = [sp.csr_matrix((g['L%d_data' % i], g['L%d_indices' % i], g['L%d_indptr' % i]), shape=(N, N)) for i in range(3)]
+    rho0 = np.array([r.ravel(order='F') for r in g['rho0']])
+    tgt = np.array([r.ravel(order='F') for r in g['rho_tgt']])
+    tl = g['tlist']
+    prob = ko.OracleProblem([L] * 3, rho0, tgt, tl, is_super=True, weights=g['weights'], ode={})
+    pulses = [ko.control_onto_interval(c) for c in g['controls_it3']]
+    S = np.clip(ko.control_onto_interval(ko.discretize(
+        lambda t: ko.flattop(t, 0.0, tl[-1], float(g['t_rise'])), tl, args=(), via_midpoints=True)), 0, 1)
+    # chis_re needs neither phi(T) nor tau: the iteration starts from the controls alone
+    _, _, tau, _ = ko.krotov_iteration(prob, pulses, [S, S], [float(g['lambda_a'])] * 2, None, None, ko.chis_re)
+    assert np.abs(tau - g['tau_vals'][4]).max() < 1e-9
+    J_T_re = 1 - np.sum(g['weights'] * tau.real) / 3  # functionals.py:256-290 with weights
+    assert abs(J_T_re - g['info_vals'][4]) < 1e-9
+    assert np.abs(g['tau_vals'][4] - g['tau_vals'][3]).max() > 1e-4  # (the iteration moved)
+
+
 REF_CASES = {
     'ref_c1_tls': lambda: configs.config_c1(),
     'ref_c2_hilbert': lambda: configs.config_c2_hilbert(),
@@ -141,7 +166,13 @@ REF_CASES = {
     'ref_c5_small': lambda: configs.config_c5(K=6, N=16, nt=201, L=1),
     'ref_c5_small_L3': lambda: configs.config_c5(K=5, N=12, nt=151, L=3, distinct=True),
     'ref_c5_n64': lambda: configs.config_c5(K=8, N=64, nt=401, L=1),
+    'ref_c4_small_hs': lambda: _with_chi(configs.config_c4(d=5, nt=201, n_logical=2), 'hs'),
 }
+
+
+def _with_chi(spec, chi):
+    spec.chi = chi
+    return spec
 
 
 @pytest.mark.parametrize('name', sorted(REF_CASES))
@@ -157,7 +188,9 @@ def test_against_real_reference_loop(name, use_scipy):
     g = golden(name)
     spec = REF_CASES[name]()
     out = oracle_optimize(spec, int(g['iter_stop']), use_scipy=use_scipy)
-    tol = 1e-13 if use_scipy else (1e-11 if name == 'ref_c4_small' else 1e-12)
+    tol = 1e-13 if use_scipy else (1e-11 if name.startswith('ref_c4_small') else 1e-12)
+    if name == 'ref_c4_small_hs' and not use_scipy:
+        tol = 5e-11  # (pulses grow to 4.6: the stiffest of the Liouville cases; measured 1.0e-10 / 4.6)
     scale = max(1.0, np.abs(g['all_pulses']).max())
     assert np.abs(out['all_pulses'] - g['all_pulses']).max() < tol * scale
     assert np.abs(out['tau_vals'] - g['tau_vals']).max() < tol

@@ -65,6 +65,26 @@ def test_reference_format_dump_names_only_reference_classes(name, tmp_path):
     assert np.array_equal(np.asarray(stored.objectives[0].H[0]), np.asarray(objectives[0].H[0]))
 
 
+def test_reference_format_dump_turns_numpy_scalars_into_python_scalars(tmp_path):
+    """np.float64 / np.complex128 inherit from float / complex; left alone they are pickled under
+    numpy._core.multiarray.scalar, which a NumPy-1.x (QuTiP 4) environment cannot resolve."""
+    spec = configs.config_c1(nt=40)
+    objectives, res = _run_here(spec, 1)
+    res.info_vals = [np.float64(0.25), (np.float32(1.5), np.int64(3), [np.complex128(1 - 2j)])]
+    res.tau_vals = [[np.complex128(0.5 + 0.25j)], np.array([np.complex128(1j)], dtype=object)]
+    res.iter_seconds = [np.int32(0), np.float64(2.0)]
+    path = str(tmp_path / 'scalars.dump')
+    res.dump(path, reference=True)
+    names = {arg for op, arg, _ in pickletools.genops(open(path, 'rb').read()) if op.name == 'GLOBAL'}
+    assert names <= ALLOWED_GLOBALS, names - ALLOWED_GLOBALS
+    back = krotov_amd.result.Result.load(path, objectives=objectives)
+    assert type(back.info_vals[0]) is float and back.info_vals[0] == 0.25
+    assert [type(v) for v in back.info_vals[1][:2]] == [float, int] and type(back.info_vals[1][2][0]) is complex
+    assert type(back.tau_vals[0][0]) is complex and back.tau_vals[0][0] == 0.5 + 0.25j
+    assert type(back.tau_vals[1][0]) is complex and back.tau_vals[1][0] == 1j
+    assert [type(v) for v in back.iter_seconds] == [int, float]
+
+
 _CHILD = textwrap.dedent('''
     import sys
     sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r}); sys.path.insert(0, {golden!r})
