@@ -76,23 +76,48 @@ def algorithmic_bytes(K, N, nt, L):
     return chi + ops + 8.0 * L * (nt - 1), chi + ops + 3 * 8.0 * L * (nt - 1)
 
 
+def build_id():
+    """What the kernels were built from: kh_version() + the first 16 hex digits of the SHA-256 over the kernel sources
+    (krotov_amd/csrc/*, include/*.h, sorted by name).  A git hash would do the same job but the GPU box has no .git."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'krotov_amd', 'csrc', '*')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        with open(path, 'rb') as fh:
+            h.update(os.path.basename(path).encode() + b'\0' + fh.read())
+    try:
+        from krotov_amd import _lib
+
+        version = _lib.load().kh_version().decode().split(' (')[0]
+    except Exception:
+        version = 'krotov_hip ?'
+    return '%s %s' % (version, h.hexdigest()[:16])
+
+
 def pmc_traffic(kernel, K_loc, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/pmc_latest.json, written by scripts/collect_profiles.sh: separate
-    FETCH_SIZE and WRITE_SIZE passes, KB units, FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md), or None when no matching record exists."""
+    """(HBM bytes per launch of `kernel`, where they come from) from the committed rocprofv3 PMC passes
+    (profiles/pmc_latest.json, written by scripts/collect_profiles.sh + summarize_profiles.py: separate FETCH_SIZE and
+    WRITE_SIZE passes, KB units, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  The record is
+    keyed on the workload AND on the build (build_id()): counters of another build of the kernels do not ride along --
+    (None, why) then."""
     path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
     try:
         rec = json.load(open(path))
     except Exception:
-        return None
+        return None, 'no profiles/pmc_latest.json'
     cfg = rec.get('config', {})
     if (cfg.get('K'), cfg.get('N'), cfg.get('nt'), cfg.get('L')) != (K_loc, args.N, args.nt, args.L):
-        return None
+        return None, 'profiles/pmc_latest.json holds another workload'
+    if rec.get('build') != build_id():
+        return None, 'profiles/pmc_latest.json is from another build of the kernels (%s; this one: %s): not used' % (
+            rec.get('build'), build_id())
     k = rec.get('kernels', {}).get(kernel)
     if not k:
-        return None
-    return (2.0 * k['FETCH_SIZE_KB'] + k['WRITE_SIZE_KB']) * 1024.0
+        return None, 'profiles/pmc_latest.json has no record of %s' % kernel
+    return ((2.0 * k['FETCH_SIZE_KB'] + k['WRITE_SIZE_KB']) * 1024.0,
+            '%s: rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE) of an earlier run of this command on THIS build '
+            '(%s), not measured in this run' % (rec.get('source', 'profiles/pmc_latest.json'), rec.get('build')))
 
 
 def cpu_baseline(args):
@@ -143,12 +168,32 @@ def cpu_baseline(args):
         'host_cores_visible': cores,
         'pilot_props_per_s_by_process_count': {str(k): v for k, v in pilots.items()},
         'cpu_model': _cpu_model(),
+        # the REAL reference (krotov.optimize_pulses, serial_map, numpy mode) on this very workload at full size: wall
+        # time recorded by the committed fixture generator when it produced tests/golden/ref_c5_full.npz -- iteration 0
+        # (one forward propagation) + one Krotov iteration = 3 sweeps of K x (nt-1) propagations, single process, in the
+        # BUILD container (not on this box): the true baseline next to the generous one above
+        'reference_loop': _reference_loop_record(args),
         'expm': 'scipy.linalg.expm %s' % _scipy_version() if _scipy_version() else "oracle's own Pade-13 (NumPy)",
         'note': 'per-core cost in the sample vs alone: what P processes sharing the memory system and one '
                 'synchronisation per time interval (the reference\'s parallel_map_fw_prop_step structure) cost on '
                 'top of the arithmetic (backward_props_per_s: the sweep with no per-interval synchronisation; '
                 'update_props_per_s: the one with it); scripts/cpu_probe.py prints the pieces on the box',
     }
+
+
+def _reference_loop_record(args):
+    if (args.K, args.N, args.nt, args.L) != (256, 64, 4001, 1) or args.distinct:
+        return None
+    try:
+        import numpy as np
+
+        secs = float(np.load(os.path.join(ROOT, 'tests', 'golden', 'ref_c5_full.npz'))['seconds'])
+    except Exception:
+        return None
+    props = 256 * 4000 * 3
+    return {'props_per_s': props / secs, 'seconds': secs, 'sweeps': 3, 'processes': 1,
+            'cpu_model': 'Intel(R) Xeon(R) Processor @ 2.10GHz (build container)',
+            'source': 'tests/golden/make_reference_goldens.py c5full -> ref_c5_full.npz["seconds"]'}
 
 
 def _cpu_model():
@@ -336,6 +381,12 @@ def main():
             ms_per_step = elapsed / args.steps * 1e3
             dominant = 'update' if t_up >= t_bw else 'backward'
             f_dom, t_dom = (f_up, t_up) if dominant == 'update' else (f_bw, t_bw)
+            dom_kernel = kernel_names[0] if dominant == 'update' else kernel_names[1]
+            traffic, traffic_source = pmc_traffic(dom_kernel, K_loc, args)
+            # flops the dominant kernel really executed (its own count of matrix-vector products; the update sweep's is the
+            # one kh_last_stats holds after an iteration): the A^2 chain and the shorter series issue fewer than credited
+            executed = stats['matvecs'] * 8.0 * args.N * args.N if dominant == 'update' else None
+            mfma_kernel = eng.kernel == 'coop16/mfma'
             out = {
                 'metric': 'state*timestep propagations/s (Krotov iterations/s in iterations_per_sec), ' +
                           ('16-objective N=400 Liouvillian (variant)' if args.workload == 'c4' else
@@ -370,18 +421,24 @@ def main():
                     'kernel': eng.kernel,
                 },
                 'roofline': {
-                    # the contract's vocabulary is "hbm" | "mfma": the register-tile kernels are bound by the fp64 FMA pipe, whose
-                    # peak IS the dense fp64 MFMA peak (one pipe: scripts/ubench_hybrid.hip) -- "mfma", with the pipe named
-                    'bound': 'mfma',
-                    'pipe': 'fp64 MFMA' if eng.kernel == 'coop16/mfma' else 'fp64 vector FMA (same pipe and same peak as the fp64 MFMA)',
-                    'kernel': kernel_names[0] if dominant == 'update' else kernel_names[1],
+                    # what the kernel is bound by, said truthfully: the register-tile kernels do their matrix-vector
+                    # products with fp64 VECTOR FMAs (no MFMA in the propagation loop); only the cooperative kernels of
+                    # config 4 are MFMA kernels.  The contract's vocabulary ("hbm" | "mfma") is kept in `contract_bound`:
+                    # the fp64 vector peak and the dense fp64 MFMA peak are one pipe and one number on gfx950.
+                    'bound': 'mfma' if mfma_kernel else 'fp64-valu',
+                    'contract_bound': 'mfma',
+                    'pipe': 'fp64 MFMA' if mfma_kernel else 'fp64 vector FMA (same pipe and same peak as the fp64 MFMA: scripts/ubench_hybrid.hip)',
+                    'kernel': dom_kernel,
                     'achieved': f_dom / t_dom / 1e12,
                     'peak': FP64_PEAK_TFLOPS,
                     'unit': 'TFLOP/s',
                     'frac': f_dom / t_dom / 1e12 / FP64_PEAK_TFLOPS,
-                    'traffic': pmc_traffic(kernel_names[0] if dominant == 'update' else kernel_names[1], K_loc, args),
-                    'traffic_source': 'profiles/pmc_latest.json: rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE) of an '
-                                      'earlier run of this command on the same build, NOT measured in this run',
+                    # the same fraction on EXECUTED flops (credited: the algorithmic formula of SURVEY.md 8d, degree 14)
+                    'executed': None if executed is None else executed / t_dom / 1e12,
+                    'executed_frac': None if executed is None else executed / t_dom / 1e12 / FP64_PEAK_TFLOPS,
+                    'traffic': traffic,
+                    'traffic_source': traffic_source,
+                    'build': build_id(),
                     'note': ('fp64 MFMA (v_mfma_f64_16x16x4): the objectives share the operators, so a Taylor term is a '
                              'dense (N x N)(N x K) product; latency-bound by one cross-workgroup exchange per term. '
                              'Credited flops as below with m = 14 per propagation (SURVEY.md 8d), whatever was issued. '
@@ -428,7 +485,7 @@ def main():
                 'workload': line['config']['workload'], 'ms_per_step': line['ms_per_step'], 'value': line['value'],
                 'unit': line['unit'], 'steps': line['steps'], 'kernel': line['config']['kernel'],
                 'parallelism': line['config']['parallelism'],
-                'roofline': {k: line['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac')},
+                'roofline': {k: line['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'executed_frac')},
                 'kernels': {k: line['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')
                             if k in line['kernels']}}
             return rec
@@ -462,8 +519,11 @@ def main():
         import threading
 
         def give_up(why=None):
+            # (rc stays 0: the headline measurement above is complete and valid, and a non-zero exit would throw it away
+            # with the side measurement; the line says so itself -- "degraded": true plus the leg's "error")
             if rank == 0:
                 out[name] = {'error': why or 'no result within %d s' % seconds}
+                out['degraded'] = True
                 print(json.dumps(out), flush=True)
             os._exit(0)
 
@@ -499,6 +559,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+            if out['cpu_baseline'].get('reference_loop'):
+                out['speedup_vs_reference_loop_single_process'] = out['value'] / out['cpu_baseline']['reference_loop']['props_per_s']
     headline_shape = args.workload == 'c5' and args.K == 256 and args.N == 64 and args.L == 1 and not args.distinct
     if world == 1 and group is None and headline_shape:
         if not args.no_config4:
@@ -512,6 +574,8 @@ def main():
             out['L4'] = leg(L=4, steps=3, warmup=1)
             out['distinct'] = leg(distinct=True, steps=3, warmup=1)
     if rank == 0:
+        if any(isinstance(v, dict) and 'error' in v for v in out.values()):
+            out['degraded'] = True  # a side measurement was replaced by its error (the headline itself is complete)
         print(json.dumps(out), flush=True)
     if group is not None:
         torch.distributed.barrier()

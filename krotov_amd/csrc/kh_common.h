@@ -370,6 +370,7 @@ struct KhExchange {
     kh_u64 *my_window;
     int world, rank;
     unsigned int epoch_base;
+    int fail_at;  // test hook (KH_P2P_FAIL_AT): this rank withholds its GPU's sum at that interval; < 0: never
 };
 
 // Called by (at least) the first 2*L lanes of one wave: one 8-byte store each.
@@ -512,8 +513,17 @@ __device__ __forceinline__ bool kh_gather_one(const KhExchange &ex, int parity, 
 }
 
 // ---- cross-GPU stage -------------------------------------------------------
-__device__ __forceinline__ void kh_p2p_publish(const KhExchange &ex, int parity, int L, int lane,
+// (kh_launder: the lane index as the optimiser cannot see through it.  The per-lane window addresses of the cross-GPU
+// stage are loop-invariant; left visible they are hoisted out of the interval loop and -- in kernels that sit at the
+// register limit -- carried across the whole sweep in scratch: 20 B/lane in kh_q2_forward_update<false, true, false>)
+__device__ __forceinline__ int kh_launder(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ void kh_p2p_publish(const KhExchange &ex, int parity, int L, int lane_in,
                                                const double *values, unsigned int epoch) {
+    const int lane = kh_launder(lane_in);
     // lane -> (peer, l, half): world * L * 2 <= 64 stores, one per lane
     const int per_peer = 2 * L;
     if (lane < ex.world * per_peer) {
@@ -527,8 +537,9 @@ __device__ __forceinline__ void kh_p2p_publish(const KhExchange &ex, int parity,
 
 // one full wave; lane -> (rank r, control l) for lane < world * L; total in rank order
 template <int MAXL>
-__device__ __forceinline__ bool kh_p2p_gather(const KhExchange &ex, int parity, int L, unsigned int epoch, int lane,
+__device__ __forceinline__ bool kh_p2p_gather(const KhExchange &ex, int parity, int L, unsigned int epoch, int lane_in,
                                               double (&out)[MAXL]) {
+    const int lane = kh_launder(lane_in);
     const int pairs = ex.world * L;
     const bool active = lane < pairs;
     const kh_u64 *g = ex.my_window + ((size_t)parity * ex.world * L + (active ? lane : 0)) * 2;
@@ -591,7 +602,7 @@ __device__ __forceinline__ bool kh_exchange_collect(const KhExchange &ex, int n,
     if (!kh_gather<MAXL, CH>(ex, parity, L, (unsigned)(n + 1), lane, out)) return false;
     if (P2P && ex.world > 1) {
         const unsigned int epoch = ex.epoch_base + (unsigned)(n + 1);
-        if (wg == 0) kh_p2p_publish(ex, parity, L, lane, out, epoch);
+        if (wg == 0 && n != ex.fail_at) kh_p2p_publish(ex, parity, L, lane, out, epoch);
         if (!kh_p2p_gather<MAXL>(ex, parity, L, epoch, lane, out)) return false;
     }
     return true;

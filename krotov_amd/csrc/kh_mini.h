@@ -284,7 +284,7 @@ kh_mini_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpda
             if (w == 0) {
                 const unsigned int epoch = ex.epoch_base + (unsigned)(n + 1);
                 double D[1] = {d1};
-                kh_p2p_publish(ex, par, 1, lane, D, epoch);
+                if (n != ex.fail_at) kh_p2p_publish(ex, par, 1, lane, D, epoch);
                 const bool ok = kh_p2p_gather<1>(ex, par, 1, epoch, lane, D);
                 if (lane == 0) {
                     s.D[par][0] = D[0];
@@ -528,7 +528,7 @@ kh_quad_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpda
         if (ex.world > 1) {  // objectives sharded over GPUs: second stage through the peer windows
             const unsigned int epoch = ex.epoch_base + (unsigned)(n + 1);
             double D[1] = {d1};
-            kh_p2p_publish(ex, par, 1, lane, D, epoch);
+            if (n != ex.fail_at) kh_p2p_publish(ex, par, 1, lane, D, epoch);
             if (!kh_p2p_gather<1>(ex, par, 1, epoch, lane, D)) return;
             d1 = D[0];
         }

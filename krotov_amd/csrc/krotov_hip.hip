@@ -131,6 +131,15 @@ struct kh_engine {
     bool quad = false;           // mini with N <= 4, K <= 4: the whole problem in one wave
     double *d_q2_theta = nullptr, *d_q2_c0 = nullptr, *d_q2_rows = nullptr, *d_ratios = nullptr;  // series tables of the register-tile kernels
     long long timeout_ticks = 100000000LL;  // KH_TIMEOUT_MS: bound on any in-kernel wait (100 MHz ticks; 1 s)
+    bool timeout_set = false;    // ... given in the environment (the cross-GPU sweeps then keep it instead of their 10 s)
+    // switches read from the environment ONCE, at creation (not per launch, not per process: engines with different
+    // settings coexist)
+    bool coop_launch = true;     // KH_COOP_LAUNCH=0: plain launches instead of cooperative ones (A/B timing)
+    bool q2_single = true;       // KH_Q2_SINGLE=0: the instantiations with the cross-GPU stage on one GPU too (A/B)
+    bool tile_single = true;     // KH_TILE_SINGLE=0: the same for the one-term-per-phase kernels
+    // fault injection for the sharded protocol (tests): rank KH_P2P_FAIL_RANK withholds its GPU's sum at interval
+    // KH_P2P_FAIL_AT of its KH_P2P_FAIL_SWEEP-th update sweep through the peer windows (1-based; default 1)
+    int p2p_fail_at = -1, p2p_fail_rank = 0, p2p_fail_sweep = 1, p2p_sweeps = 0;
 };
 
 // Kernels with more than 64 KiB of dynamic LDS need the limit raised once per device: remembered per
@@ -150,11 +159,10 @@ static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
 // partial start, which the bounded in-kernel waits turn into KH_ERR_TIMEOUT and the caller into a repeat of the
 // sweep with one launch per interval (krotov_amd/optimize.py).
 // KH_COOP_LAUNCH=0 keeps plain launches (A/B timing: a cooperative launch costs ~15-20 us of host time).
-static bool g_coop_launch = true;  // (re-read from the environment by every kh_engine_create)
-
 template <class... Params, class... Args>
-static int launch_persistent(void (*kernel)(Params...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
-    if (!g_coop_launch || grid.x * grid.y * grid.z == 1) {
+static int launch_persistent(const kh_engine *e, void (*kernel)(Params...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                             Args... args) {
+    if (!e->coop_launch || grid.x * grid.y * grid.z == 1) {
         hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
         return KH_OK;
     }
@@ -409,10 +417,12 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     e->kind = KIND_GENERIC;
     const int max_wgs = e->num_cus < 64 * KH_GATHER_CHUNKS ? e->num_cus : 64 * KH_GATHER_CHUNKS;
     e->grid_update = e->K < max_wgs ? e->K : max_wgs;
-    {
-        const char *d = getenv("KH_COOP_LAUNCH");
-        g_coop_launch = d == nullptr || atoi(d) != 0;
-    }
+    if (const char *d = getenv("KH_COOP_LAUNCH")) e->coop_launch = atoi(d) != 0;
+    if (const char *d = getenv("KH_Q2_SINGLE")) e->q2_single = atoi(d) != 0;
+    if (const char *d = getenv("KH_TILE_SINGLE")) e->tile_single = atoi(d) != 0;
+    if (const char *d = getenv("KH_P2P_FAIL_AT")) e->p2p_fail_at = atoi(d);
+    if (const char *d = getenv("KH_P2P_FAIL_RANK")) e->p2p_fail_rank = atoi(d);
+    if (const char *d = getenv("KH_P2P_FAIL_SWEEP")) e->p2p_fail_sweep = atoi(d);
     if (const char *d = getenv("KH_Q4")) e->use_q4 = atoi(d) != 0;
     if (const char *d = getenv("KH_POLL_DELAY")) {
         e->poll_delay = atoi(d);
@@ -421,7 +431,10 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     if (const char *d = getenv("KH_ADJ_DELAY")) e->adj_poll_delay = atoi(d);
     if (const char *d = getenv("KH_COOP_DELAY")) e->coop_poll_delay = atoi(d);
     if (const char *d = getenv("KH_TIMEOUT_MS"))  // e.g. under a profiler that slows the kernels down
-        if (atoll(d) > 0) e->timeout_ticks = atoll(d) * 100000LL;
+        if (atoll(d) > 0) {
+            e->timeout_ticks = atoll(d) * 100000LL;
+            e->timeout_set = true;
+        }
     const char *force = getenv("KH_KERNEL");  // "generic" | "tile256" | "tile512" | "q2" | "coop" (testing)
     const bool tile_ok = csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 && e->K <= max_wgs;
     // More objectives than CUs, one control: 256-thread workgroups (one wave per SIMD, 256 VGPRs) fit two per
@@ -704,11 +717,14 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         // every workgroup of the single-launch update sweep must be resident at once: ask the occupancy of the kernel
         // as built (registers, LDS) instead of assuming one per CU; if it does not fit, the generic kernels (which
         // loop over objectives inside at most #CUs workgroups) take over
-        int rc = check_residency(e, (const void *)kh_q2_forward_update<false, true>, KH_Q2_THREADS, kh_q2_lds_bytes(), e->K,
-                                 "kh_q2_forward_update");
-        if (rc == KH_OK)
-            rc = check_residency(e, (const void *)kh_q2_forward_update<true, false>, KH_Q2_THREADS, kh_q2_lds_bytes(), e->K,
-                                 "kh_q2_forward_update (second order)");
+        // (every instantiation a sweep of this engine may launch: one GPU / sharded, first / second order, sums on
+        // either side -- their register footprints differ)
+        const void *forms[] = {(const void *)kh_q2_forward_update<false, true, true>, (const void *)kh_q2_forward_update<false, false, true>,
+                               (const void *)kh_q2_forward_update<true, false, true>, (const void *)kh_q2_forward_update<false, true>,
+                               (const void *)kh_q2_forward_update<false, false>,      (const void *)kh_q2_forward_update<true, false>};
+        int rc = KH_OK;
+        for (const void *f : forms)
+            if (rc == KH_OK) rc = check_residency(e, f, KH_Q2_THREADS, kh_q2_lds_bytes(), e->K, "kh_q2_forward_update");
         if (rc != KH_OK) {
             e->kind = KIND_GENERIC;  // (the plain sweeps keep the q2 kernel: its workgroups do not wait for each other)
             e->grid_update = e->K < max_wgs ? e->K : max_wgs;
@@ -853,7 +869,7 @@ static int launch_c4_store(kh_engine *e, const KhSweepArgs &p, const double *pul
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
     return launch_coop_placed(e, [&](dim3 grid) {
-        return launch_persistent(kh_c4_sweep_store<MAXG>, grid, dim3(KH_C4_THREADS), lds, st, p, c4_args(e, direction < 0),
+        return launch_persistent(e, kh_c4_sweep_store<MAXG>, grid, dim3(KH_C4_THREADS), lds, st, p, c4_args(e, direction < 0),
                                  exchange_args(e, true), pulses, in, store, out, direction);
     });
 }
@@ -872,9 +888,9 @@ static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *p
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
     return launch_coop_placed(e, [&](dim3 grid) {
         if (sq)
-            return launch_persistent(kh_coop_sweep_store<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
+            return launch_persistent(e, kh_coop_sweep_store<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
                                      coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
-        return launch_persistent(kh_coop_sweep_store<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
+        return launch_persistent(e, kh_coop_sweep_store<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
                                  coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
     });
 }
@@ -883,6 +899,16 @@ template <int MAXKS, int COLS>
 static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdateArgs &u_in, const KhExchange &ex,
                               hipStream_t st) {
     KhUpdateArgs u = u_in;
+    if (e->coop_adj && u.sigma == nullptr && e->L == 1 && e->d_coop_sq_fw != nullptr && e->d_coop_adj == nullptr) {
+        // V = H_1^+ X needs a second buffer of the co-state store's size; it is an optimisation (one round per interval
+        // less): without the memory the sweep takes the sums by one more round, as it did before the form existed
+        const size_t bytes = sizeof(cplx) * (size_t)e->K * e->nt * e->N;
+        if (hipMalloc(&e->d_coop_adj, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            e->d_coop_adj = nullptr;
+            e->coop_adj = false;
+        }
+    }
     const bool adj = e->coop_adj && u.sigma == nullptr && e->L == 1 && e->d_coop_sq_fw != nullptr;
     const bool sq = e->d_coop_sq_fw != nullptr;
     const void *func = u.sigma != nullptr ? (sq ? (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, true>
@@ -896,12 +922,6 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     if (adj) {
         // V = H_1^+ X over the whole co-state store, block-sparse on the matrix cores (kh_coop.h)
         const long long M = (long long)e->K * e->nt;
-        if (e->d_coop_adj == nullptr) {
-            if (hipMalloc(&e->d_coop_adj, sizeof(cplx) * (size_t)M * e->N) != hipSuccess) {
-                (void)hipGetLastError();
-                return kh_fail(KH_ERR_NOMEM, "no memory for H_1^+ chi (%zu bytes)", sizeof(cplx) * (size_t)M * e->N);
-            }
-        }
         const unsigned blocks = (unsigned)((M + 63) / 64);
         kh_coop_adjoint_side<<<blocks, KH_COOP_ADJ_THREADS, 0, st>>>(e->coop_adj_op, e->d_coop_adj_nz, u.chi_store, e->d_coop_adj,
                                                                      e->N, e->coop_G, M);
@@ -914,14 +934,14 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
         const size_t lds = kh_coop_lds_bytes(e->coop_ks, COLS);
         const KhCoopArgs ca = coop_args(e, false);
         if (adj && ex.world == 1)
-            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, true, true, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
-        if (adj) return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, true, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+            return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, false, true, true, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        if (adj) return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, false, true, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         if (u.sigma != nullptr && sq)
-            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true, false, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+            return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, true, false, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         if (u.sigma != nullptr)
-            return launch_persistent(kh_coop_forward_update<MAXKS, COLS, true, false, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
-        if (sq) return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, false, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
-        return launch_persistent(kh_coop_forward_update<MAXKS, COLS, false, false, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+            return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, true, false, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        if (sq) return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, false, false, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, false, false, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
     });
 }
 
@@ -1024,18 +1044,18 @@ static int launch_tile_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     // so the stores get a longer head start -- measured best on config-5 shapes: 24 / 28 / 32 x 64 cycles for L = 2 / 3 / 4
     // (update sweep 7.47 / - / 9.86 us per interval against 7.92 / - / 11.21 with 16)
     if (LT >= 2 && !e->poll_delay_set) exl.first_poll_delay = 24 + 4 * (LT - 2);
-    if (exl.world == 1 && exl.G > 1 && !(getenv("KH_TILE_SINGLE") && atoi(getenv("KH_TILE_SINGLE")) == 0)) {
+    if (exl.world == 1 && exl.G > 1 && e->tile_single) {
         const void *fs = u.sigma != nullptr ? (const void *)kh_tile_forward_update<RPT, LT, true, true>
                                             : (const void *)kh_tile_forward_update<RPT, LT, false, true>;
         const int rcs = ensure_dynamic_lds(e, fs, lds);
         if (rcs != KH_OK) return rcs;
         if (u.sigma != nullptr)
-            return launch_persistent(kh_tile_forward_update<RPT, LT, true, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
-        return launch_persistent(kh_tile_forward_update<RPT, LT, false, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+            return launch_persistent(e, kh_tile_forward_update<RPT, LT, true, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+        return launch_persistent(e, kh_tile_forward_update<RPT, LT, false, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
     }
     if (u.sigma != nullptr)
-        return launch_persistent(kh_tile_forward_update<RPT, LT, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
-    return launch_persistent(kh_tile_forward_update<RPT, LT, false>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+        return launch_persistent(e, kh_tile_forward_update<RPT, LT, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+    return launch_persistent(e, kh_tile_forward_update<RPT, LT, false>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
 }
 
 static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
@@ -1046,13 +1066,15 @@ static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
     ex.timeout_ticks = e->timeout_ticks;
     // across GPUs the ranks are separate processes: a host-side hiccup of one of them (garbage collection, page
     // faults) must not look like a lost peer and demote the whole run to the per-interval path
-    if (e->p2p_ready && internal_exchange && ex.timeout_ticks < 1000000000LL) ex.timeout_ticks = 1000000000LL;  // 10 s
+    if (e->p2p_ready && internal_exchange && !e->timeout_set && ex.timeout_ticks < 1000000000LL)
+        ex.timeout_ticks = 1000000000LL;  // 10 s
     ex.peer_windows = e->d_p2p_peers;
     ex.my_window = e->p2p_window;
     ex.world = (e->p2p_ready && internal_exchange) ? e->p2p_world : 1;
     ex.rank = e->p2p_rank;
     ex.epoch_base = e->p2p_epoch_base;
     ex.first_poll_delay = e->poll_delay;
+    ex.fail_at = (ex.world > 1 && e->p2p_rank == e->p2p_fail_rank && e->p2p_sweeps + 1 == e->p2p_fail_sweep) ? e->p2p_fail_at : -1;
     return ex;
 }
 
@@ -1078,22 +1100,22 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
         const dim3 g(e->K), b(KH_Q2_THREADS);
         // (KH_Q2_SINGLE=0: the instantiations with the cross-GPU stage on one GPU too -- A/B switch)
-        const bool single = ex.world == 1 && !(getenv("KH_Q2_SINGLE") && atoi(getenv("KH_Q2_SINGLE")) == 0);
+        const bool single = ex.world == 1 && e->q2_single;
         if (u.sigma != nullptr && single)
-            rc = launch_persistent(kh_q2_forward_update<true, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+            rc = launch_persistent(e, kh_q2_forward_update<true, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else if (u.sigma != nullptr)
-            rc = launch_persistent(kh_q2_forward_update<true, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+            rc = launch_persistent(e, kh_q2_forward_update<true, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else if (u.adj_sign != 0.0) {
             KhExchange exa = ex;
             exa.first_poll_delay = e->adj_poll_delay;
             if (single)  // (the default form on one GPU: an instantiation without the cross-GPU stage)
-                rc = launch_persistent(kh_q2_forward_update<false, true, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
+                rc = launch_persistent(e, kh_q2_forward_update<false, true, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
             else
-                rc = launch_persistent(kh_q2_forward_update<false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
+                rc = launch_persistent(e, kh_q2_forward_update<false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
         } else if (single)
-            rc = launch_persistent(kh_q2_forward_update<false, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+            rc = launch_persistent(e, kh_q2_forward_update<false, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else
-            rc = launch_persistent(kh_q2_forward_update<false, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+            rc = launch_persistent(e, kh_q2_forward_update<false, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_COOP && !stepwise) {
         if (e->coop_cols == 2)
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 2>(e, p, u, ex, st) : launch_coop_update<16, 2>(e, p, u, ex, st);
@@ -1116,7 +1138,7 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         if (rc == KH_OK && !u.internal_exchange)
             kh_gen_forward_update<<<e->grid_update, KH_GEN_THREADS, lds, st>>>(p, u, ex);
         else if (rc == KH_OK)
-            rc = launch_persistent(kh_gen_forward_update, dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, p, u, ex);
+            rc = launch_persistent(e, kh_gen_forward_update, dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, p, u, ex);
     }
     if (rc != KH_OK) return rc;
     KH_HIP(hipGetLastError());
@@ -1186,7 +1208,10 @@ extern "C" int kh_forward_update(kh_engine *e, const kh_cdouble *chi_store_dev, 
         update_args(e, chi_store_dev, chi_norms_dev, guess_dev, shape_dev, lambda_dev, opt_dev, g_a_dev);
     int rc = launch_update(e, u, st);
     if (rc != KH_OK) return rc;
-    if (e->p2p_ready) e->p2p_epoch_base += (unsigned int)e->nt;  // every rank advances identically
+    if (e->p2p_ready) {
+        e->p2p_epoch_base += (unsigned int)e->nt;  // every rank advances identically
+        e->p2p_sweeps += 1;
+    }
     KH_HIP(hipMemcpyAsync(psi_T_dev, e->d_phi, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice, st));
     e->last_intervals = e->nt - 1;
     e->last_wgs = e->grid_update;
@@ -1382,6 +1407,7 @@ extern "C" int kh_p2p_selftest(kh_engine *e, int32_t rounds, void *stream) {
     ex.my_window = e->p2p_window;
     ex.world = e->p2p_world;
     ex.rank = e->p2p_rank;
+    ex.fail_at = -1;
     int *d_res = nullptr;
     KH_HIP(hipMalloc(&d_res, sizeof(int)));
     KH_HIP(hipMemsetAsync(d_res, 0, sizeof(int), st));

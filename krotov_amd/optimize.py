@@ -650,6 +650,7 @@ class _HipBackend:
             else:
                 self.p2p = False
                 eng.disable_p2p()
+                eng._p2p_fell_back = True  # (stays with the per-interval transport from here on)
         if not done:
             def all_reduce(x):
                 self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM, group=self.group)

@@ -21,5 +21,6 @@ for line in out.splitlines():
     if 'error' in line:
         print(line)
 for name, r in rows.items():
-    print('%-60s VGPR %3d AGPR %3d spill %3d occ %d LDS %6d' % (name[:60], r.get('VGPRs', -1), r.get('AGPRs', -1),
-          r.get('VGPRs Spill', -1), r.get('Occupancy [waves/SIMD]', -1), r.get('LDS Size [bytes/block]', -1)))
+    print('%-66s VGPR %3d AGPR %3d spill %3d scratch %4d B/lane  SGPR spill %3d occ %d' % (
+        name[:66], r.get('VGPRs', -1), r.get('AGPRs', -1), r.get('VGPRs Spill', -1), r.get('ScratchSize [bytes/lane]', -1),
+        r.get('SGPRs Spill', -1), r.get('Occupancy [waves/SIMD]', -1)))

@@ -31,8 +31,12 @@ for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_lds'):
             summary.setdefault(kern, {})[c] = {'avg_per_launch': sum(v) / len(v), 'launches': len(v)}
 json.dump(summary, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
 cfg = bench['config']
+sys.path.insert(0, ROOT)
+import bench as _bench  # (build_id(): kh_version + hash of the kernel sources -- the record is only used by the same build)
+
 latest = {
     'source': 'profiles/%s/pmc_summary.json' % tag,
+    'build': bench.get('roofline', {}).get('build') or _bench.build_id(),
     'config': {'K': cfg['objectives'], 'N': cfg['N'], 'nt': cfg['time_steps'] + 1, 'L': cfg['controls']},
     'kernels': {},
 }
