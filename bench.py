@@ -294,6 +294,11 @@ def main():
         # RCCL refuses two ranks on one device: with fewer GPUs than ranks (a test set-up) the host-side
         # collectives go through gloo; the in-kernel peer windows do not care
         backend = os.environ.get('KH_DIST_BACKEND', 'nccl' if n_dev >= world else 'gloo')
+        if n_dev < world:
+            # ... and the cooperative kernels must not pin their column groups to XCDs: every rank would claim the SAME
+            # XCDs (group y -> XCD y) of the one GPU, more workgroups than those XCDs have CUs, and ranks that wait for
+            # each other's sums inside their kernels would never all be resident (one rank per GPU: no such conflict)
+            os.environ.setdefault('KH_COOP_XCD', '0')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:

@@ -9,6 +9,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <climits>
 #include <cstring>
 #include <map>
 #include <set>
@@ -30,6 +32,7 @@
 #include "../../scripts/experiments/kh_coop4w.h"
 #endif
 #include "kh_mini.h"
+#include "kh_ell.h"
 
 static thread_local std::string g_last_error;
 
@@ -51,7 +54,7 @@ static int kh_fail(int code, const char *fmt, ...) {
                            __FILE__, __LINE__);                                               \
     } while (0)
 
-enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3, KIND_COOP = 4 };
+enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3, KIND_COOP = 4, KIND_ELL = 5 };
 
 struct kh_engine {
     int K, N, L, nt, is_super;
@@ -86,6 +89,10 @@ struct kh_engine {
     double *d_deg_theta = nullptr;    // [KH_MAX_DEGREE+1] degree thresholds for tol
     KhCsr *d_csr_fw = nullptr;        // [K*(1+L)] sparse operators (kh_engine_create_csr), else NULL
     KhCsr *d_csr_bw = nullptr;        // [K*(1+L)] their conjugate transposes
+    KhEll *d_ell_fw = nullptr, *d_ell_bw = nullptr;  // [K] sparse operators in padded row form (kh_ell.h), or NULL
+    int *d_ell_off = nullptr;         // ... their column offsets and values (one pool each)
+    cplx *d_ell_vals = nullptr;
+    int ell_E = 0;                    // widest row over all objectives and both directions (picks the instantiation)
     const cplx **d_coop_fops_fw = nullptr, **d_coop_fops_bw = nullptr;  // [1+L] fragment-ordered operator copies
     const cplx **d_coop_sq_fw = nullptr, **d_coop_sq_bw = nullptr;      // [3] the same for P0, P1, P2 (one control)
     const cplx **d_sq_fw = nullptr;   // [K*3] P0, P1, P2 of A^2 (q2 kernels), forward operators
@@ -194,7 +201,7 @@ static int check_residency(const kh_engine *e, const void *func, int threads, si
     return KH_OK;
 }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.4 (gfx950; tile64q2, tile64, mini16, mini4, coop16/mfma, generic, generic/csr kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.5 (gfx950; tile64q2, tile64, mini16, mini4, coop16/mfma, ell/csr, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
@@ -203,6 +210,7 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
         case KIND_TILE_RPT1: return e->stepwise_only ? "tile64/512 per interval" : "tile64/512";
         case KIND_TILE_Q2: return e->mini ? (e->quad ? "mini4/wave" : "mini16/wave") : "tile64q2/512";
         case KIND_COOP: return "coop16/mfma";
+        case KIND_ELL: return "ell/csr";
         default: return e->d_csr_fw != nullptr ? "generic/csr" : "generic";
     }
 }
@@ -251,6 +259,10 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_ratios);
     (void)hipFree(e->d_csr_fw);
     (void)hipFree(e->d_csr_bw);
+    (void)hipFree(e->d_ell_fw);
+    (void)hipFree(e->d_ell_bw);
+    (void)hipFree(e->d_ell_off);
+    (void)hipFree(e->d_ell_vals);
     (void)hipFree((void *)e->d_coop_fops_fw);
     (void)hipFree((void *)e->d_coop_fops_bw);
     (void)hipFree((void *)e->d_coop_sq_fw);
@@ -275,6 +287,152 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->p2p_window);
     (void)hipFree((void *)e->d_p2p_peers);
     delete e;
+}
+
+// ---------------------------------------------------------------------------
+// sparse operators: host-side analysis and the padded row form of kh_ell.h
+// ---------------------------------------------------------------------------
+struct HostCsr {  // canonical: column indices sorted within a row, duplicates summed, explicit zeros dropped
+    std::vector<int> indptr, indices;
+    std::vector<cplx> data;
+};
+
+static hipError_t fetch_csr(const kh_csr &c, int N, HostCsr &out) {
+    std::vector<int> indptr(N + 1), indices((size_t)c.nnz);
+    std::vector<cplx> data((size_t)c.nnz);
+    hipError_t err = hipMemcpy(indptr.data(), c.indptr, sizeof(int) * (N + 1), hipMemcpyDeviceToHost);
+    if (err == hipSuccess && c.nnz > 0) err = hipMemcpy(indices.data(), c.indices, sizeof(int) * (size_t)c.nnz, hipMemcpyDeviceToHost);
+    if (err == hipSuccess && c.nnz > 0) err = hipMemcpy(data.data(), c.data, sizeof(cplx) * (size_t)c.nnz, hipMemcpyDeviceToHost);
+    if (err != hipSuccess) return err;
+    out.indptr.assign(N + 1, 0);
+    out.indices.clear();
+    out.data.clear();
+    std::vector<std::pair<int, cplx>> row;
+    for (int r = 0; r < N; ++r) {
+        row.clear();
+        const int lo = indptr[r], hi = indptr[r + 1];
+        if (lo < 0 || hi < lo || hi > c.nnz) return hipErrorInvalidValue;
+        for (int j = lo; j < hi; ++j) {
+            if (indices[j] < 0 || indices[j] >= N) return hipErrorInvalidValue;
+            row.emplace_back(indices[j], data[j]);
+        }
+        std::stable_sort(row.begin(), row.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+        for (size_t j = 0; j < row.size();) {
+            cplx v = row[j].second;
+            size_t q = j + 1;
+            for (; q < row.size() && row[q].first == row[j].first; ++q) {
+                v.x += row[q].second.x;
+                v.y += row[q].second.y;
+            }
+            if (v.x != 0.0 || v.y != 0.0) {
+                out.indices.push_back(row[j].first);
+                out.data.push_back(v);
+            }
+            j = q;
+        }
+        out.indptr[r + 1] = (int)out.indices.size();
+    }
+    return hipSuccess;
+}
+
+// does b equal sign * a, entry for entry?
+static bool csr_equal(const HostCsr &a, const HostCsr &b, double sign) {
+    if (a.indptr != b.indptr || a.indices != b.indices) return false;
+    for (size_t j = 0; j < a.data.size(); ++j)
+        if (b.data[j].x != sign * a.data[j].x || b.data[j].y != sign * a.data[j].y) return false;
+    return true;
+}
+
+// || (a + sign adj) / 2 ||_F^2 with adj the conjugate transpose of a, as supplied by the caller
+static double csr_part_fro2(const HostCsr &a, const HostCsr &adj, double sign) {
+    double acc = 0.0;
+    const int N = (int)a.indptr.size() - 1;
+    for (int r = 0; r < N; ++r) {
+        int i = a.indptr[r], j = adj.indptr[r];
+        const int ie = a.indptr[r + 1], je = adj.indptr[r + 1];
+        while (i < ie || j < je) {
+            double re = 0.0, im = 0.0;
+            const int ci = i < ie ? a.indices[i] : INT32_MAX, cj = j < je ? adj.indices[j] : INT32_MAX;
+            if (ci <= cj) {
+                re += a.data[i].x;
+                im += a.data[i].y;
+            }
+            if (cj <= ci) {
+                re += sign * adj.data[j].x;
+                im += sign * adj.data[j].y;
+            }
+            if (ci <= cj) ++i;
+            if (cj <= ci) ++j;
+            acc += 0.25 * (re * re + im * im);
+        }
+    }
+    return acc;
+}
+
+// One operator list (drift + L controls, canonical host copies; NULL: absent) in the padded row form of kh_ell.h:
+// the union of the patterns, entries some control touches first.  Returns false when a row is wider than the kernels'
+// register budget (KH_ELL_EMAX entries with one row per lane, KH_ELL_EMAX2 with two).
+static bool build_ell_host(const std::vector<const HostCsr *> &ops, int N, std::vector<int> &off, std::vector<cplx> &vals,
+                           int &E, int &Ec) {
+    const int Lp1 = (int)ops.size();
+    std::vector<std::vector<std::pair<int, int>>> rows(N);  // (column, touched by a control)
+    E = Ec = 0;
+    std::map<int, int> cols;
+    for (int r = 0; r < N; ++r) {
+        cols.clear();
+        for (int o = 0; o < Lp1; ++o) {
+            if (ops[o] == nullptr) continue;
+            for (int j = ops[o]->indptr[r]; j < ops[o]->indptr[r + 1]; ++j) {
+                int &flag = cols[ops[o]->indices[j]];
+                if (o > 0) flag = 1;
+            }
+        }
+        int nc = 0;
+        for (const auto &kv : cols)
+            if (kv.second) rows[r].emplace_back(kv.first, 1), ++nc;
+        for (const auto &kv : cols)
+            if (!kv.second) rows[r].emplace_back(kv.first, 0);
+        E = std::max(E, (int)rows[r].size());
+        Ec = std::max(Ec, nc);
+    }
+    const int emax = N <= KH_ELL_THREADS ? KH_ELL_EMAX : KH_ELL_EMAX2;
+    if (E > emax) return false;
+    // every row: its control-touched entries in slots [0, Ec), the others behind them from slot Ec on (so that a rebuild
+    // of slots [0, Ec) never touches a drift-only entry); padding: value 0, the lane's own row
+    int width = 0;
+    for (int r = 0; r < N; ++r) {
+        int nc = 0;
+        for (const auto &cv : rows[r]) nc += cv.second;
+        width = std::max(width, Ec + ((int)rows[r].size() - nc));
+    }
+    if (width > emax) return false;
+    E = (std::max(width, 1) + 3) / 4 * 4;    // the kernels work on groups of four entries
+    const int Ec_true = Ec;
+    Ec = (Ec + 3) / 4 * 4;                   // (slots [Ec_true, Ec): drift-only entries or padding -- rebuilt to themselves)
+    off.assign((size_t)E * KH_ELL_NMAX, 0);
+    vals.assign((size_t)Lp1 * E * KH_ELL_NMAX, make_double2(0.0, 0.0));
+    for (int t = 0; t < KH_ELL_NMAX; ++t)
+        for (int e = 0; e < E; ++e) off[(size_t)e * KH_ELL_NMAX + t] = (t < N ? t : 0) * (int)sizeof(cplx);
+    auto value_at = [](const HostCsr *m, int r, int c, cplx &v) {
+        if (m == nullptr) return false;
+        const auto lo = m->indices.begin() + m->indptr[r], hi = m->indices.begin() + m->indptr[r + 1];
+        const auto it = std::lower_bound(lo, hi, c);
+        if (it == hi || *it != c) return false;
+        v = m->data[it - m->indices.begin()];
+        return true;
+    };
+    for (int r = 0; r < N; ++r) {
+        int slot_c = 0, slot_d = Ec_true;
+        for (const auto &cv : rows[r]) {
+            const int slot = cv.second ? slot_c++ : slot_d++;
+            off[(size_t)slot * KH_ELL_NMAX + r] = cv.first * (int)sizeof(cplx);
+            for (int o = 0; o < Lp1; ++o) {
+                cplx v;
+                if (value_at(ops[o], r, cv.first, v)) vals[((size_t)o * E + slot) * KH_ELL_NMAX + r] = v;
+            }
+        }
+    }
+    return true;
 }
 
 // csr_fw / csr_bw: [K*(1+L)] sparse operators and their conjugate transposes (pr->ops then holds their
@@ -398,6 +556,94 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         KH_HIP_E(hipMemcpy(e->d_csr_fw, csr_fw, sizeof(KhCsr) * nops, hipMemcpyHostToDevice));
         KH_HIP_E(hipMemcpy(e->d_csr_bw, csr_bw, sizeof(KhCsr) * nops, hipMemcpyHostToDevice));
     }
+    bool ell_ok = false;
+    if (csr_fw != nullptr) {
+        // canonical host copies of every distinct operator and of its conjugate transpose (small: a few entries per row)
+        std::map<const void *, HostCsr> host_fw, host_bw;
+        for (size_t i = 0; i < nops; ++i) {
+            if (fw[i] == nullptr || host_fw.count(fw[i])) continue;
+            KH_HIP_E(fetch_csr(csr_fw[i], e->N, host_fw[fw[i]]));
+            KH_HIP_E(fetch_csr(csr_bw[i], e->N, host_bw[fw[i]]));
+        }
+        // what the dense engines ask the device (kh_adjoint_sign_kernel, kh_herm_defect_kernel): is every generator
+        // Hermitian (real spectrum), or anti-Hermitian up to a small part of the drift?  -> the shorter series
+        if (e->L >= 1) {
+            bool ctl_plus = true, ctl_minus = true, drift_plus = true;
+            double fro2 = 0.0;
+            for (size_t i = 0; i < nops; ++i) {
+                if (fw[i] == nullptr) continue;
+                const HostCsr &a = host_fw[fw[i]], &b = host_bw[fw[i]];
+                if (i % (size_t)(1 + e->L) == 0) {
+                    drift_plus = drift_plus && csr_equal(a, b, 1.0);
+                    fro2 = std::max(fro2, csr_part_fro2(a, b, e->is_super ? 1.0 : -1.0));
+                } else {
+                    ctl_plus = ctl_plus && csr_equal(a, b, 1.0);
+                    ctl_minus = ctl_minus && csr_equal(a, b, -1.0);
+                }
+            }
+            e->adj_sign = ctl_plus ? 1.0 : (ctl_minus ? -1.0 : 0.0);
+            e->real_spectrum = ctl_plus && drift_plus && !e->is_super;
+            if (e->is_super ? ctl_minus : ctl_plus) {
+                double dt_max = 0.0;
+                for (int n = 0; n < e->nt - 1; ++n) dt_max = pr->dt[n] > dt_max ? pr->dt[n] : dt_max;
+                e->imag_defect = sqrt(fro2) * dt_max;
+            }
+            if (const char *d = getenv("KH_TAYLOR"))
+                if (atoi(d) != 0) {
+                    e->real_spectrum = false;
+                    e->imag_defect = -1.0;
+                }
+        }
+        // the padded row form (kh_ell.h): one structure per distinct operator list and direction
+        const char *force_k = getenv("KH_KERNEL");
+        if (e->N <= KH_ELL_NMAX && !(force_k && strcmp(force_k, "generic") == 0)) {
+            ell_ok = true;
+            std::map<std::vector<const void *>, std::pair<KhEll, KhEll>> made;
+            std::vector<KhEll> ell_fw(e->K), ell_bw(e->K);
+            std::vector<int> off_pool;
+            std::vector<cplx> vals_pool;
+            for (int k = 0; k < e->K && ell_ok; ++k) {
+                std::vector<const void *> key(fw.begin() + (size_t)k * (1 + e->L), fw.begin() + (size_t)(k + 1) * (1 + e->L));
+                auto it = made.find(key);
+                if (it == made.end()) {
+                    KhEll pair[2];
+                    for (int dir = 0; dir < 2 && ell_ok; ++dir) {
+                        std::vector<const HostCsr *> ops_h;
+                        for (const void *ptr : key)
+                            ops_h.push_back(ptr == nullptr ? nullptr : (dir == 0 ? &host_fw[ptr] : &host_bw[ptr]));
+                        std::vector<int> off;
+                        std::vector<cplx> vals;
+                        int E = 0, Ec = 0;
+                        if (!build_ell_host(ops_h, e->N, off, vals, E, Ec)) {
+                            ell_ok = false;
+                            break;
+                        }
+                        pair[dir].off_at = (long long)off_pool.size();
+                        pair[dir].vals_at = (long long)vals_pool.size();
+                        off_pool.insert(off_pool.end(), off.begin(), off.end());
+                        vals_pool.insert(vals_pool.end(), vals.begin(), vals.end());
+                        pair[dir].E = E;
+                        pair[dir].Ec = Ec;
+                        e->ell_E = std::max(e->ell_E, E);
+                    }
+                    if (!ell_ok) break;
+                    it = made.emplace(key, std::make_pair(pair[0], pair[1])).first;
+                }
+                ell_fw[k] = it->second.first;
+                ell_bw[k] = it->second.second;
+            }
+            if (ell_ok) {
+                KH_HIP_E(hipMalloc(&e->d_ell_off, sizeof(int) * off_pool.size()));
+                KH_HIP_E(hipMalloc(&e->d_ell_vals, sizeof(cplx) * vals_pool.size()));
+                KH_HIP_E(hipMemcpy(e->d_ell_off, off_pool.data(), sizeof(int) * off_pool.size(), hipMemcpyHostToDevice));
+                KH_HIP_E(hipMemcpy(e->d_ell_vals, vals_pool.data(), sizeof(cplx) * vals_pool.size(), hipMemcpyHostToDevice));
+                KH_HIP_E(hipMalloc(&e->d_ell_fw, sizeof(KhEll) * e->K));
+                KH_HIP_E(hipMalloc(&e->d_ell_bw, sizeof(KhEll) * e->K));
+                KH_HIP_E(hipMemcpy(e->d_ell_fw, ell_fw.data(), sizeof(KhEll) * e->K, hipMemcpyHostToDevice));
+                KH_HIP_E(hipMemcpy(e->d_ell_bw, ell_bw.data(), sizeof(KhEll) * e->K, hipMemcpyHostToDevice));
+            }
+        }
+    }
     if (pr->op_norms != nullptr) {
         KH_HIP_E(hipMemcpy(e->d_norms, pr->op_norms, sizeof(double) * nops, hipMemcpyHostToDevice));
     } else {
@@ -512,9 +758,21 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             if (!(pr->theta_max > 0.0)) e->theta_max = 4.0;
         }
     }
+    // Sparse operators in the padded row form: one 1024-thread workgroup per objective, the matrix in registers
+    // (kh_ell.h).  The update sweep exchanges the sums in-kernel, so all K workgroups must be resident (one per CU);
+    // with more objectives it stays with the generic CSR kernels, the plain sweeps take their objectives in turns.
+    if (ell_ok) {
+        if (e->K <= max_wgs) {
+            e->kind = KIND_ELL;
+            e->grid_update = e->K;
+        }
+        // a term of the series costs a workgroup-wide round whatever it multiplies: fewer, longer sub-steps pay, as
+        // for the cooperative kernels (theta <= 4: round-off ~ e^theta eps per step, far inside the parity budget)
+        if (!(pr->theta_max > 0.0)) e->theta_max = 4.0;
+    }
     // The plain sweeps have no cross-objective coupling, so the register-tile kernel serves them for any
     // number of objectives (workgroups simply run in turns) even when the update sweep needs the generic one.
-    e->kind_store = e->kind;
+    e->kind_store = ell_ok ? KIND_ELL : e->kind;
     if (e->kind == KIND_GENERIC && csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 &&
         !(force && strcmp(force, "generic") == 0))
         e->kind_store = KIND_TILE_RPT1;
@@ -675,6 +933,11 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         e->coop_series = e->kind == KIND_COOP && coop_sq && e->imag_defect >= 0.0 && e->imag_defect <= 0.05;
         if (e->coop_series) {
             kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data(), 4.0, e->imag_defect);
+        } else if (ell_ok && (e->real_spectrum || (e->imag_defect >= 0.0 && e->imag_defect <= 0.05)) &&
+                   !(getenv("KH_NEAR_IMAG") && atoi(getenv("KH_NEAR_IMAG")) == 0)) {
+            // sparse operators in the padded row form: like the cooperative kernels, the Chebyshev form up to theta = 4
+            kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data(), 4.0,
+                                        e->real_spectrum ? 0.0 : e->imag_defect);
         } else if (e->real_spectrum) {
             kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data());
         } else if (e->imag_defect > 0.0 && e->imag_defect <= 0.05 && !(getenv("KH_NEAR_IMAG") && atoi(getenv("KH_NEAR_IMAG")) == 0)) {
@@ -962,6 +1225,23 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
             kh_q4_sweep_store<<<e->K, KH_Q4_THREADS, kh_q4_lds_bytes(), st>>>(
                 p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
 #endif
+    } else if (e->kind_store == KIND_ELL) {
+        const KhEll *ells = backward ? e->d_ell_bw : e->d_ell_fw;
+        const int grid = e->K < 4 * e->num_cus ? e->K : 4 * e->num_cus;
+        const size_t lds = kh_ell_lds_bytes();
+#define KH_ELL_STORE(R, EM) \
+    kh_ell_sweep_store<R, EM><<<grid, KH_ELL_THREADS, lds, st>>>(p, ells, e->d_ell_off, e->d_ell_vals, pulses, in, store, out, direction)
+        if (e->N <= KH_ELL_THREADS) {
+            if (e->ell_E <= 8) KH_ELL_STORE(1, 8);
+            else if (e->ell_E <= 16) KH_ELL_STORE(1, 16);
+            else if (e->ell_E <= 24) KH_ELL_STORE(1, 24);
+            else KH_ELL_STORE(1, 32);
+        } else {
+            if (e->ell_E <= 8) KH_ELL_STORE(2, 8);
+            else if (e->ell_E <= 12) KH_ELL_STORE(2, 12);
+            else KH_ELL_STORE(2, 16);
+        }
+#undef KH_ELL_STORE
     } else if (e->kind_store == KIND_TILE_Q2) {
         kh_q2_sweep_store<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(
             p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
@@ -1123,7 +1403,21 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 4>(e, p, u, ex, st) : launch_coop_update<16, 4>(e, p, u, ex, st);
         else
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 16>(e, p, u, ex, st) : launch_coop_update<16, 16>(e, p, u, ex, st);
-    } else if (e->kind != KIND_GENERIC && e->kind != KIND_COOP) {
+    } else if (e->kind == KIND_ELL && !stepwise) {
+        const dim3 g(e->K), b(KH_ELL_THREADS);
+        const size_t lds = kh_ell_lds_bytes();
+        const bool so = u.sigma != nullptr;
+#define KH_ELL_UPDATE(R, EM)                                                                                                     \
+    (so ? launch_persistent(e, kh_ell_forward_update<R, EM, true>, g, b, lds, st, p, (const KhEll *)e->d_ell_fw,                    \
+                            (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex)                                       \
+        : launch_persistent(e, kh_ell_forward_update<R, EM, false>, g, b, lds, st, p, (const KhEll *)e->d_ell_fw,                   \
+                            (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex))
+        if (e->N <= KH_ELL_THREADS)
+            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(1, 8) : e->ell_E <= 16 ? KH_ELL_UPDATE(1, 16) : e->ell_E <= 24 ? KH_ELL_UPDATE(1, 24) : KH_ELL_UPDATE(1, 32);
+        else
+            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(2, 8) : e->ell_E <= 12 ? KH_ELL_UPDATE(2, 12) : KH_ELL_UPDATE(2, 16);
+#undef KH_ELL_UPDATE
+    } else if (e->kind != KIND_GENERIC && e->kind != KIND_COOP && e->kind != KIND_ELL) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
         switch (e->L) {
             case 1: rc = rpt2 ? launch_tile_update<2, 1>(e, p, u, ex, st) : launch_tile_update<1, 1>(e, p, u, ex, st); break;

@@ -196,8 +196,29 @@ def make_dump_fixtures():
     arrays = {}
     for i, c in enumerate(csr):
         arrays['L%d_data' % i], arrays['L%d_indices' % i], arrays['L%d_indptr' % i] = c.data, c.indices, c.indptr
+    # The reference integrates with zvode at rtol = 1e-6 / atol = 1e-8, and over 2 000 steps that is what its tau values
+    # are good to (~1e-4).  For a tight comparison with an EXACT exponential action the fixture also holds the same
+    # propagator's result with its tolerances tightened to rtol = 1e-11 / atol = 1e-13 -- through the oracle's
+    # restatement of the propagator's zvode step (oracle/krotov_oracle.py: step_ode), which reproduces the dump at the
+    # default tolerances to 2e-12 (the propagator itself needs QuTiP): tau at iteration 3 (one forward propagation
+    # under `controls_it3`) and after one more Krotov iteration.
+    from oracle import krotov_oracle as ko
+
+    tl = np.asarray(res.tlist)
+    rho0 = np.array([np.asarray(o.initial_state).ravel(order='F') for o in objs])
+    tgt = np.array([np.asarray(o.target).ravel(order='F') for o in objs])
+    prob = ko.OracleProblem([csr] * 3, rho0, tgt, tl, is_super=True, weights=np.array([o.weight for o in objs]),
+                            ode=dict(rtol=1e-11, atol=1e-13))
+    pulses3 = [ko.control_onto_interval(c) for c in np.array(res.guess_controls)]
+    S = np.clip(ko.control_onto_interval(ko.discretize(lambda t: ko.flattop(t, 0.0, tl[-1], 20.0), tl, args=(),
+                                                       via_midpoints=True)), 0, 1)
+    tau3 = ko.tau_vals(prob, ko.forward_propagation(prob, pulses3))
+    _, _, tau4, _ = ko.krotov_iteration(prob, pulses3, [S, S], [1.0, 1.0], None, None, ko.chis_re)
+    print('dump_3states: tau(it 3) dump - tight zvode', np.abs(np.array(res.tau_vals[3]) - tau3).max(),
+          ' tau(it 4)', np.abs(np.array(res.tau_vals[4]) - tau4).max())
     np.savez_compressed(
         os.path.join(HERE, 'dump_3states.npz'),
+        tau_tight_it3=tau3, tau_tight_it4=tau4,
         tlist=np.asarray(res.tlist), N=625,
         rho0=np.array([np.asarray(o.initial_state) for o in objs]),    # (3, 25, 25)
         rho_tgt=np.array([np.asarray(o.target) for o in objs]),

@@ -332,6 +332,7 @@ def test_objective_propagate_on_device():
 SECOND_ORDER_CASES = [
     ('c3', None), ('c5_n16', None), ('c3', 'mini'), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
     ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c2l', None),
+    ('lindblad', 'sparse'), ('c5_n12_L3', 'sparse'),
     ('c4_d9', None), ('shared_n96_L2', None), ('c3', 'coop'), ('shared_n96_L2', 'coop16cols'), ('shared_n96_L2', 'coop2cols'), ('c4_d9', 'coop2cols'),
 ]
 
@@ -343,14 +344,20 @@ def test_second_order_update_sweep(name, kernel, monkeypatch):
     stored states, with phi_prev from a different pulse so that Delta phi != 0."""
     import torch
 
-    spec = SMALL[name]()
+    spec = configs.config_sparse_lindblad() if name == 'lindblad' else SMALL[name]()
     prob = spec_to_oracle(spec)
     gp, S, lam = oracle_controls(spec)
     if kernel in ('coop16cols', 'coop2cols'):  # the cooperative kernels with 16 / 2 (instead of 4) objectives per workgroup
         monkeypatch.setenv('KH_COOP_COLS', kernel[4:-4])
-    elif kernel is not None:
+    elif kernel is not None and kernel != 'sparse':
         monkeypatch.setenv('KH_KERNEL', kernel)
-    eng = _engine(spec)
+    if kernel == 'sparse':  # operators in CSR form: the matrix-in-registers kernels (kh_ell.h)
+        from krotov_amd.engine import HipKrotovEngine
+
+        eng = HipKrotovEngine(configs.sparse_ops(spec), np.diff(spec.tlist), is_super=spec.is_super)
+        assert eng.kernel == 'ell/csr'
+    else:
+        eng = _engine(spec)
     pulses = np.array(gp)
     rng = np.random.default_rng(5)
     older = [p * (1.0 + 0.2 * rng.standard_normal(p.shape)) for p in gp]  # the "previous iteration"
@@ -432,21 +439,48 @@ def test_second_order_optimize_pulses_vs_reference_loop():
         assert np.abs(probe[key].reshape(-1) - want).max() < 1e-12
 
 
-@pytest.mark.parametrize('name', ['lindblad', 'c5_n33', 'c5_n12_L3'])
-def test_sparse_operator_sweeps(name):
+def _tiled(spec, times):
+    """The same objectives `times` times over (operators shared): more objectives than the GPU has CUs."""
+    return configs.ProblemSpec(
+        name=spec.name + '_x%d' % times, H0=list(spec.H0) * times, Hc=list(spec.Hc) * times, is_super=spec.is_super,
+        init=np.tile(spec.init, (times, 1)), target=np.tile(spec.target, (times, 1)), tlist=spec.tlist,
+        controls=spec.controls, update_shape=spec.update_shape, lambda_a=spec.lambda_a, chi=spec.chi)
+
+
+SPARSE_CASES = {
+    # name: (spec, kernel family the engine picks by itself)
+    'lindblad': (lambda: configs.config_sparse_lindblad(), 'ell/csr'),            # N = 144, ~7 entries per row
+    'lindblad_n625': (lambda: configs.config_sparse_lindblad(d=25, nt=9, K=2), 'ell/csr'),   # two rows per lane (N > 512)
+    'lindblad_k300': (lambda: _tiled(configs.config_sparse_lindblad(d=5, nt=13, K=5), 60), 'generic/csr'),  # more objectives than CUs
+    'c5_n33': (lambda: SMALL['c5_n33'](), 'generic/csr'),                         # 33 entries per row: too wide for registers
+    'c5_n12_L3': (lambda: SMALL['c5_n12_L3'](), 'ell/csr'),                       # three controls, distinct drifts, full rows
+    'c5_n16': (lambda: SMALL['c5_n16'](), 'ell/csr'),                             # Hermitian: the real-spectrum series
+}
+
+
+@pytest.mark.parametrize('force_generic', [False, True])
+@pytest.mark.parametrize('name', sorted(SPARSE_CASES))
+def test_sparse_operator_sweeps(name, force_generic, monkeypatch):
     """kh_engine_create_csr: operators in CSR form (the regime of the
     reference's DensityMatrixODEPropagator, propagators.py:162-327) -- every sweep vs the oracle
-    on a sparse Lindbladian (7 entries per row on average) and on fully populated rows."""
+    on sparse Lindbladians (~7 entries per row; one or two rows per lane) and on fully populated rows, through the
+    matrix-in-registers kernels (kh_ell.h) and through the generic CSR kernels (KH_KERNEL=generic)."""
     from krotov_amd.engine import HipKrotovEngine
 
-    spec = configs.config_sparse_lindblad() if name == 'lindblad' else SMALL[name]()
+    builder, family = SPARSE_CASES[name]
+    if force_generic:
+        if family == 'generic/csr':
+            pytest.skip("already the generic kernels")
+        monkeypatch.setenv('KH_KERNEL', 'generic')
+        family = 'generic/csr'
+    spec = builder()
     ops = configs.sparse_ops(spec)
     if name == 'lindblad':
         assert ops[0][0].nnz < 0.06 * spec.N**2 and ops[0][0] is ops[1][0]
     prob = spec_to_oracle(spec)
     gp, S, lam = oracle_controls(spec)
     eng = HipKrotovEngine(ops, np.diff(spec.tlist), is_super=spec.is_super)
-    assert eng.kernel == 'generic/csr'
+    assert eng.kernel == family
     pulses = np.array(gp)
     fw_T, states = eng.forward(pulses, spec.init, store=True)
     ref_T, ref_states = ko.forward_propagation(prob, gp, store=True)
@@ -489,7 +523,7 @@ def test_density_matrix_ode_propagator_drop_in():
                                      propagator=krotov_amd.propagators.DensityMatrixODEPropagator(), **kw)
     from krotov_amd.engine import LAST_ENGINE
 
-    assert LAST_ENGINE().kernel == 'generic/csr'
+    assert LAST_ENGINE().kernel == 'ell/csr'
     ref = oracle_optimize(spec, 2)
     got = np.array([np.array(p) for p in res.all_pulses])
     assert np.abs(got - ref['all_pulses']).max() < 1e-12 * max(1.0, np.abs(ref['all_pulses']).max())
@@ -727,9 +761,14 @@ def _three_states_problem():
 def test_three_states_dump_sparse_propagator_on_device():
     """reference docs/notebooks/3states_opt_result.dump -- the reference's ONE result for its
     DensityMatrixODEPropagator (propagators.py:162-327) -- iterations 3 -> 6 on the CSR path of the engine
-    (kh_engine_create_csr).  The reference integrates with zvode at rtol 1e-6 / atol 1e-8; the engine takes the exact
-    exponential action, so the agreement is the ODE solver's accuracy (measured here: see the assertion), not round-off.
-    The oracle's restatement of the zvode step reproduces the dump to 2e-12 (tests/test_oracle_golden.py)."""
+    (kh_engine_create_csr).  Two comparisons:
+    * with the dump itself.  The reference integrates with zvode at rtol 1e-6 / atol 1e-8 and is itself only good to
+      ~1e-4 after 2 000 steps (its tau of iteration 3 is 7.6e-5 off the converged value, 1.5e-4 at iteration 6), while
+      the engine takes the exact exponential action: agreement to 5e-4, the solver's accuracy;
+    * with the SAME propagator at tightened tolerances (rtol 1e-11 / atol 1e-13; `tau_tight_it3/4` of the fixture, from
+      the oracle's restatement of the zvode step, which reproduces the dump at the default tolerances to 2e-12,
+      tests/test_oracle_golden.py): 1e-8 -- the difference to the dump is the reference's integration error, not the
+      engine's."""
     g, objs, opts = _three_states_problem()
     res = krotov_amd.optimize_pulses(
         objs, opts, g['tlist'], propagator=krotov_amd.propagators.DensityMatrixODEPropagator(reentrant=True),
@@ -738,14 +777,16 @@ def test_three_states_dump_sparse_propagator_on_device():
         iter_stop=3)
     from krotov_amd.engine import LAST_ENGINE
 
-    assert LAST_ENGINE().kernel.endswith('csr')
+    assert LAST_ENGINE().kernel == 'ell/csr'
     tau = np.array(res.tau_vals)
-    assert np.abs(tau - g['tau_vals'][3:7]).max() < 1e-5
-    assert np.abs(np.array(res.info_vals) - g['info_vals'][3:7]).max() < 1e-5
-    # the optimisation moves: iteration 6 is not iteration 3
-    assert np.abs(g['tau_vals'][6] - g['tau_vals'][3]).max() > 50e-5
-    print("3states: max |d tau| = %.2e, max |d J_T| = %.2e" % (
-        np.abs(tau - g['tau_vals'][3:7]).max(), np.abs(np.array(res.info_vals) - g['info_vals'][3:7]).max()))
+    d_dump = np.abs(tau - g['tau_vals'][3:7]).max()
+    d_J = np.abs(np.array(res.info_vals) - g['info_vals'][3:7]).max()
+    d_tight = max(np.abs(tau[0] - g['tau_tight_it3']).max(), np.abs(tau[1] - g['tau_tight_it4']).max())
+    print("3states: max |d tau| vs dump %.2e, |d J_T| %.2e; vs the tight-tolerance propagator %.2e" % (d_dump, d_J, d_tight))
+    assert d_dump < 5e-4 and d_J < 5e-4
+    assert d_tight < 1e-8
+    # the optimisation moves by more than the comparison's tolerance: iteration 6 is not iteration 3
+    assert np.abs(g['tau_vals'][6] - g['tau_vals'][3]).max() > 1.5e-3
 
 
 def test_runs_are_bitwise_repeatable():
