@@ -215,6 +215,95 @@ def _scipy_version():
         return None
 
 
+def sparse_leg(steps=3, warmup=1):
+    """The sparse-operator row of the path on the reference's own workload for it: notebook 06
+    (docs/notebooks/06_example_3states.ipynb: two coupled 5-level transmons in Liouville space, 625-dim Liouvillian with
+    4.8-6.4 entries per row, 3 weighted density matrices, 2 controls, 2000 grid points, propagator=
+    DensityMatrixODEPropagator), operators and controls from tests/golden/dump_3states.npz, through
+    ``optimize_pulses``; plus the engine-level sweep times of the 16-density-matrix ladder scripts/perf_sparse.py has
+    tracked since round 1.  Roofline: a term of the series is one gather of 16 bytes and one complex multiply-add per
+    matrix entry -- bound by the LDS gather (128 B/clk per CU); credited per propagation: m_alg = 14 terms x nnz."""
+    import numpy as np
+    import scipy.sparse as sp
+    import torch
+
+    import krotov_amd
+    from krotov_amd import configs, engine as _engine_mod
+
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'dump_3states.npz'))
+    N = int(g['N'])
+    Lops = [sp.csr_matrix((g['L%d_data' % i], g['L%d_indices' % i], g['L%d_indptr' % i]), shape=(N, N)) for i in range(3)]
+    ctrls = [np.array(c, dtype=np.float64) for c in g['controls_it3']]
+    T = g['tlist'][-1]
+    S = lambda t: krotov_amd.shapes.flattop(t, 0.0, T, float(g['t_rise']))  # noqa: E731
+    objs = []
+    for k in range(3):
+        obj = krotov_amd.Objective(initial_state=g['rho0'][k], target=g['rho_tgt'][k],
+                                   H=[Lops[0], [Lops[1], ctrls[0]], [Lops[2], ctrls[1]]])
+        obj.weight = float(g['weights'][k])
+        objs.append(obj)
+    opts = {id(c): dict(lambda_a=float(g['lambda_a']), update_shape=S) for c in ctrls}
+    marks, n_iter = {}, warmup + steps
+
+    def hook(**kw):
+        if kw['iteration'] == warmup:
+            _engine_mod.LAST_ENGINE().kernel_times_ms(reset=True)
+            torch.cuda.synchronize()
+            marks['t0'] = time.perf_counter()
+        elif kw['iteration'] == n_iter:
+            torch.cuda.synchronize()
+            marks['t1'] = time.perf_counter()
+
+    krotov_amd.optimize_pulses(objs, opts, g['tlist'], propagator=krotov_amd.propagators.DensityMatrixODEPropagator(),
+                               chi_constructor=krotov_amd.functionals.chis_re, info_hook=hook, iter_stop=n_iter)
+    eng = _engine_mod.LAST_ENGINE()
+    times = eng.kernel_times_ms(reset=True)
+    stats = eng.stats()
+    K, nt = 3, len(g['tlist'])
+    elapsed = marks['t1'] - marks['t0']
+    nnz_union = int((abs(Lops[0]) + abs(Lops[1]) + abs(Lops[2])).nnz)
+    t_up = float(np.mean(times['update'][-steps:])) * 1e-3
+    t_bw = float(np.mean(times['backward'][-steps:])) * 1e-3
+    terms_per_step = stats['matvecs'] / (K * (nt - 1))  # (incl. the L control products of the update sums)
+    lds_peak = K * 128.0 * 2.4  # GB/s: the K CUs this job occupies
+    credited_bytes = K * (nt - 1) * TAYLOR_DEGREE * nnz_union * 16.0
+    rec = {
+        'workload': "reference notebook 06 (3states): K=3 density matrices, N=625 sparse Liouvillian (%d entries on the union "
+                    "pattern, %.1f per row), L=2, %d time steps, chis_re with weights; propagator=DensityMatrixODEPropagator"
+                    % (nnz_union, nnz_union / N, nt - 1),
+        'kernel': eng.kernel, 'steps': steps, 'ms_per_step': elapsed / steps * 1e3,
+        'value': K * (nt - 1) * 2 * steps / elapsed, 'unit': 'props/s',
+        'us_per_propagation': elapsed / steps / (K * (nt - 1) * 2) * 1e6,
+        'kernels': {'backward_sweep_ms': t_bw * 1e3, 'update_sweep_ms': t_up * 1e3},
+        'terms_per_step_update_sweep': terms_per_step,
+        'us_per_term': t_up / ((nt - 1) * terms_per_step) * 1e6,
+        'roofline': {'bound': 'lds-gather', 'kernel': 'kh_ell_forward_update',
+                     'achieved': credited_bytes / t_up / 1e9, 'peak': lds_peak, 'unit': 'GB/s',
+                     'frac': credited_bytes / t_up / 1e9 / lds_peak,
+                     'note': 'credited: 14 terms x nnz x 16 B of LDS gather per propagation (SURVEY.md 8d: m = 14), over the '
+                             'LDS bandwidth of the K = 3 CUs the job can use (128 B/clk x 2.4 GHz each); the chain of terms '
+                             'is serial and one objective cannot be spread over CUs without a cross-CU exchange per term'},
+        'reference_recorded': 'the reference ran this optimisation at 23 s per iteration (12 h 53 min for 2000, notebook cell 55)',
+    }
+    # the 16-density-matrix ladder of scripts/perf_sparse.py (N = 625, 5.8 entries per row, 500 intervals), engine level
+    spec = configs.config_sparse_lindblad(d=25, nt=501, K=16)
+    tl = spec.tlist
+    pulses = np.array([[spec.controls[0](t + 0.5 * (tl[1] - tl[0]), None) for t in tl[:-1]]])
+    e2 = _engine_mod.HipKrotovEngine(configs.sparse_ops(spec), np.diff(tl), is_super=True)
+    e2.profile = True
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    for _ in range(3):
+        chi = e2.backward(chi_T, pulses)
+        e2.forward_update(chi, np.full(16, 1.0 / 32), spec.init, pulses, np.ones((1, 500)), np.full(1, 2.0))
+    e2.check()
+    t2 = e2.kernel_times_ms()
+    rec['ladder_16x625'] = {'kernel': e2.kernel, 'backward_sweep_ms': min(t2['backward']), 'update_sweep_ms': min(t2['update']),
+                            'us_per_propagation': (min(t2['backward']) + min(t2['update'])) * 1e3 / (16 * 500 * 2),
+                            'round_3': '202 / 221 ms per sweep, 25 us per propagation (generic CSR kernels)'}
+    e2.close()
+    return rec
+
+
 def self_launch(n):
     """``python bench.py --gpus N`` without a launcher: run this very command line under
     ``torch.distributed.run`` (one rank per GPU, rendezvous on 127.0.0.1, a free port) and return its exit code."""
@@ -256,6 +345,9 @@ def main():
                          'single-GPU line carries under "config4"')
     ap.add_argument('--no-variants', action='store_true',
                     help='skip the short L=4 and distinct-drift runs the default single-GPU line carries under "L4" / "distinct"')
+    ap.add_argument('--no-sparse', action='store_true',
+                    help='skip the sparse-operator leg the default single-GPU line carries under "sparse" (the reference\'s '
+                         'notebook 06 through DensityMatrixODEPropagator)')
     ap.add_argument('--no-rccl-leg', action='store_true',
                     help='multi-rank runs: skip the extra measurement with one RCCL all-reduce per time interval ("rccl")')
     ap.add_argument('--rccl-leg-timeout', type=int, default=240, help='seconds the "rccl" side measurement may take')
@@ -578,6 +670,11 @@ def main():
             # "L=1 (also report L=4)" and "a second variant with K distinct random H0_k"
             out['L4'] = leg(L=4, steps=3, warmup=1)
             out['distinct'] = leg(distinct=True, steps=3, warmup=1)
+        if not args.no_sparse:
+            try:
+                out['sparse'] = sparse_leg()
+            except Exception as exc:  # (the headline line must not depend on a side measurement)
+                out['sparse'] = {'error': repr(exc)[:200]}
     if rank == 0:
         if any(isinstance(v, dict) and 'error' in v for v in out.values()):
             out['degraded'] = True  # a side measurement was replaced by its error (the headline itself is complete)

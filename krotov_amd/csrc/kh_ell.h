@@ -20,7 +20,7 @@
 #include "kh_common.h"
 #include "kh_generic.h"
 
-#define KH_ELL_THREADS 512
+#define KH_ELL_THREADS 512  // (default workgroup; the kernels are templates on the thread count: 512, 768, 1024)
 #define KH_ELL_NMAX 1024  // rows: one per lane up to 512, two per lane (tid, tid + 512) up to 1024
 #define KH_ELL_EMAX 32    // widest padded row with one row per lane; with two rows per lane: KH_ELL_EMAX2
 #define KH_ELL_EMAX2 16
@@ -38,7 +38,7 @@ struct KhEll {
 
 struct KhEllLds {
     double *ratio;  // [KH_RATIO_STRIDE] the series' ratios of the current degree
-    double *red;    // [8 waves][KH_MAX_L]
+    double *red;    // [16 waves][KH_MAX_L]
     double *D;      // [KH_MAX_L]
     double *ok;     // [KH_MAX_L + 1]
     double *deg;    // [KH_MAX_DEGREE + 1] copy of the degree-threshold table
@@ -49,14 +49,14 @@ struct KhEllLds {
 
 __host__ __device__ inline size_t kh_ell_lds_bytes() {
     return (size_t)2 * KH_ELL_XB_BYTES +
-           (KH_RATIO_STRIDE + 8 * KH_MAX_L + KH_MAX_L + KH_MAX_L + 1 + KH_MAX_DEGREE + 1 + 2 * KH_MAX_L) * sizeof(double) + 64;
+           (KH_RATIO_STRIDE + 16 * KH_MAX_L + KH_MAX_L + KH_MAX_L + 1 + KH_MAX_DEGREE + 1 + 2 * KH_MAX_L) * sizeof(double) + 64;
 }
 
 __device__ __forceinline__ KhEllLds kh_ell_carve(char *smem) {
     KhEllLds s;
     s.ratio = (double *)(smem + 2 * KH_ELL_XB_BYTES);
     s.red = s.ratio + KH_RATIO_STRIDE;
-    s.D = s.red + 8 * KH_MAX_L;
+    s.D = s.red + 16 * KH_MAX_L;
     s.ok = s.D + KH_MAX_L;
     s.deg = s.ok + KH_MAX_L + 1;
     s.eps = s.deg + KH_MAX_DEGREE + 1;
@@ -64,16 +64,16 @@ __device__ __forceinline__ KhEllLds kh_ell_carve(char *smem) {
     return s;
 }
 
-// this lane's rows of an ELL structure: offsets and the drift's values (all E entries); row slot i is row tid + 512 i.
+// this lane's rows of an ELL structure: offsets and the drift's values (all E entries); row slot i is row tid + T i.
 // (Four entries at a time, with a scheduling barrier between the groups: left to itself the compiler issues every load
 // of a row at once and needs a second set of registers for the values in flight -- the kernels then spill.)
-template <int RPL, int EMAX>
+template <int T, int RPL, int EMAX>
 __device__ __forceinline__ void kh_ell_load(const KhEll &el, const int *__restrict__ offs, const cplx *__restrict__ vals,
                                             int tid, cplx (&a)[RPL][EMAX], int (&off)[RPL][EMAX]) {
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
         // (uniform base pointers + an unsigned 32-bit lane index: scalar-base addressing, no 64-bit address per entry)
-        const unsigned row = (unsigned)(tid + KH_ELL_THREADS * i);
+        const unsigned row = (unsigned)(tid + T * i);
 #pragma unroll
         for (int e0 = 0; e0 < EMAX; e0 += 4) {
 #pragma unroll
@@ -96,7 +96,7 @@ __device__ __forceinline__ void kh_ell_load(const KhEll &el, const int *__restri
 }
 
 // a_e = v_0e + sum_l eps_l v_le for the entries the controls touch (e < Ec, a multiple of four)
-template <int RPL, int EMAX>
+template <int T, int RPL, int EMAX>
 __device__ __forceinline__ void kh_ell_rebuild(const KhEll &el, const cplx *__restrict__ vals, int tid, int L,
                                                const double *eps, cplx (&a)[RPL][EMAX]) {
     const long long plane = (long long)el.E * KH_ELL_NMAX;
@@ -105,7 +105,7 @@ __device__ __forceinline__ void kh_ell_rebuild(const KhEll &el, const cplx *__re
     const int tid_l = kh_launder(tid);
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
-        const unsigned row = (unsigned)(tid_l + KH_ELL_THREADS * i);
+        const unsigned row = (unsigned)(tid_l + T * i);
 #pragma unroll
         for (int e0 = 0; e0 < EMAX; e0 += 4) {
             if (e0 < el.Ec) {
@@ -175,7 +175,7 @@ __device__ __forceinline__ void kh_ell_load_ratios(const KhSweepArgs &p, const K
 
 // state <- exp(f A dt) state: nsub sub-steps of the engine's degree-m series, term by term (T_j = ratio_j f h A T_{j-1}).
 // `state`: this lane's rows, in registers on entry and on exit.  All threads of the workgroup call this.
-template <int RPL, int EMAX>
+template <int T, int RPL, int EMAX>
 __device__ __forceinline__ int kh_ell_expm_action(const cplx (&a)[RPL][EMAX], const int (&off)[RPL][EMAX], cplx (&state)[RPL],
                                                   char *smem, const double *ratio, double fre, double fim, double dt,
                                                   int nsub, int m, int tid, int N) {
@@ -186,7 +186,7 @@ __device__ __forceinline__ int kh_ell_expm_action(const cplx (&a)[RPL][EMAX], co
         const cplx coef = c_make(fre * hj, fim * hj);
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const int row = tid + KH_ELL_THREADS * i;
+            const int row = tid + T * i;
             if (row < N) {
                 const cplx t = c_mul(coef, kh_ell_row(a[i], off[i], xin));
                 ((cplx *)xout)[row] = t;
@@ -200,7 +200,7 @@ __device__ __forceinline__ int kh_ell_expm_action(const cplx (&a)[RPL][EMAX], co
         const double c0 = ratio[0];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const int row = tid + KH_ELL_THREADS * i;
+            const int row = tid + T * i;
             if (row < N) ((cplx *)xa)[row] = state[i];  // the chain starts from v itself, the sum from T_0 = c_0 v
             state[i] = c_make(c0 * state[i].x, c0 * state[i].y);
         }
@@ -217,8 +217,8 @@ __device__ __forceinline__ int kh_ell_expm_action(const cplx (&a)[RPL][EMAX], co
 // ---------------------------------------------------------------------------
 // plain propagation with storage (backward sweep / iteration-0 forward sweep)
 // ---------------------------------------------------------------------------
-template <int RPL, int EMAX>
-__global__ void __launch_bounds__(KH_ELL_THREADS)
+template <int T, int RPL, int EMAX>
+__global__ void __launch_bounds__(T)
 kh_ell_sweep_store(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__restrict__ offs, const cplx *__restrict__ vals,
                    const double *__restrict__ pulses, const cplx *__restrict__ state_in, cplx *__restrict__ store,
                    cplx *__restrict__ state_out, int direction) {
@@ -234,16 +234,16 @@ kh_ell_sweep_store(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__r
         const double *norms_k = p.op_norms + (size_t)k * (1 + L);
         cplx a[RPL][EMAX];
         int off[RPL][EMAX];
-        kh_ell_load<RPL, EMAX>(el, offs, vals, tid, a, off);
+        kh_ell_load<T, RPL, EMAX>(el, offs, vals, tid, a, off);
         cplx state[RPL];
         auto put = [&](cplx *dst) {
 #pragma unroll
             for (int i = 0; i < RPL; ++i)
-                if (tid + KH_ELL_THREADS * i < N) dst[tid + KH_ELL_THREADS * i] = state[i];
+                if (tid + T * i < N) dst[tid + T * i] = state[i];
         };
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const int row = tid + KH_ELL_THREADS * i;
+            const int row = tid + T * i;
             state[i] = row < N ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
         }
         if (store != nullptr) put(store + ((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N);
@@ -258,14 +258,14 @@ kh_ell_sweep_store(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__r
             }
             const double dt = p.dt[n];
             __syncthreads();  // (s.eps; also: the previous interval's last term has been read by everybody)
-            kh_ell_rebuild<RPL, EMAX>(el, vals, tid, L, s.eps, a);
+            kh_ell_rebuild<T, RPL, EMAX>(el, vals, tid, L, s.eps, a);
             int nsub, m;
             kh_degree_cached(theta * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
             if (m != m_cur) {
                 kh_ell_load_ratios(p, s, m, tid);
                 m_cur = m;
             }
-            matvecs += kh_ell_expm_action<RPL, EMAX>(a, off, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
+            matvecs += kh_ell_expm_action<T, RPL, EMAX>(a, off, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
             if (store != nullptr) put(store + ((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N);
         }
         if (state_out != nullptr) put(state_out + (size_t)k * N);
@@ -276,8 +276,8 @@ kh_ell_sweep_store(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__r
 // ---------------------------------------------------------------------------
 // forward sweep with sequential pulse update (optimize.py:444-508): ONE launch, grid == K, sums exchanged in-kernel
 // ---------------------------------------------------------------------------
-template <int RPL, int EMAX, bool SO>
-__global__ void __launch_bounds__(KH_ELL_THREADS)
+template <int T, int RPL, int EMAX, bool SO>
+__global__ void __launch_bounds__(T)
 kh_ell_forward_update(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__restrict__ offs,
                       const cplx *__restrict__ vals, KhUpdateArgs u, KhExchange ex) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -289,11 +289,11 @@ kh_ell_forward_update(KhSweepArgs p, const KhEll *__restrict__ ells, const int *
     const double chi_norm = u.chi_norms[k];
     cplx a[RPL][EMAX];
     int off[RPL][EMAX];
-    kh_ell_load<RPL, EMAX>(el, offs, vals, tid, a, off);
+    kh_ell_load<T, RPL, EMAX>(el, offs, vals, tid, a, off);
     cplx state[RPL];
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
-        const int row = tid + KH_ELL_THREADS * i;
+        const int row = tid + T * i;
         state[i] = row < N ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
         if (SO && row < N) u.fw_store[((size_t)k * nt) * N + row] = state[i];
     }
@@ -309,7 +309,7 @@ kh_ell_forward_update(KhSweepArgs p, const KhEll *__restrict__ ells, const int *
         cplx bra[RPL];
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const int row = tid + KH_ELL_THREADS * i;
+            const int row = tid + T * i;
             bra[i] = c_make(0.0, 0.0);
             if (row < N) {
                 bra[i] = u.chi_store[((size_t)k * nt + n) * N + row];
@@ -327,7 +327,7 @@ kh_ell_forward_update(KhSweepArgs p, const KhEll *__restrict__ ells, const int *
             double v = 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
-                const int row = tid + KH_ELL_THREADS * i;
+                const int row = tid + T * i;
                 if (row < N) {
                     const cplx z = kh_ell_control_row<EMAX>(el, vals, l, (unsigned)row, off[i], smem);
                     cplx ov = c_make(0.0, 0.0);
@@ -351,7 +351,7 @@ kh_ell_forward_update(KhSweepArgs p, const KhEll *__restrict__ ells, const int *
             for (int l = 0; l < KH_MAX_L; ++l) {
                 double acc = 0.0;
                 if (l < L)
-                    for (int w = 0; w < KH_ELL_THREADS / 64; ++w) acc += s.red[w * KH_MAX_L + l];
+                    for (int w = 0; w < T / 64; ++w) acc += s.red[w * KH_MAX_L + l];
                 part[l] = chi_norm * acc;
             }
             if (ex.G == 1) {
@@ -414,25 +414,25 @@ kh_ell_forward_update(KhSweepArgs p, const KhEll *__restrict__ ells, const int *
         }
         __syncthreads();
         // ---- propagate over interval n with the updated pulses (optimize.py:479-491) ----
-        kh_ell_rebuild<RPL, EMAX>(el, vals, tid, L, s.eps, a);
+        kh_ell_rebuild<T, RPL, EMAX>(el, vals, tid, L, s.eps, a);
         int nsub, m;
         kh_degree_cached(theta * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
         if (m != m_cur) {
             kh_ell_load_ratios(p, s, m, tid);
             m_cur = m;
         }
-        matvecs += kh_ell_expm_action<RPL, EMAX>(a, off, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
+        matvecs += kh_ell_expm_action<T, RPL, EMAX>(a, off, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
         if constexpr (SO) {
 #pragma unroll
             for (int i = 0; i < RPL; ++i)
-                if (tid + KH_ELL_THREADS * i < N) u.fw_store[((size_t)k * nt + n + 1) * N + tid + KH_ELL_THREADS * i] = state[i];
+                if (tid + T * i < N) u.fw_store[((size_t)k * nt + n + 1) * N + tid + T * i] = state[i];
         }
         // ---- partial sums of the next interval ----
         if (n + 1 < nt - 1) partial_pieces(n + 1);
     }
 #pragma unroll
     for (int i = 0; i < RPL; ++i)
-        if (tid + KH_ELL_THREADS * i < N) u.phi[(size_t)k * N + tid + KH_ELL_THREADS * i] = state[i];
+        if (tid + T * i < N) u.phi[(size_t)k * N + tid + T * i] = state[i];
     if (k == 0 && tid < L) u.g_a[tid] = s.g_a[tid];
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }

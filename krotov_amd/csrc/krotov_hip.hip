@@ -1229,17 +1229,23 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         const KhEll *ells = backward ? e->d_ell_bw : e->d_ell_fw;
         const int grid = e->K < 4 * e->num_cus ? e->K : 4 * e->num_cus;
         const size_t lds = kh_ell_lds_bytes();
-#define KH_ELL_STORE(R, EM) \
-    kh_ell_sweep_store<R, EM><<<grid, KH_ELL_THREADS, lds, st>>>(p, ells, e->d_ell_off, e->d_ell_vals, pulses, in, store, out, direction)
-        if (e->N <= KH_ELL_THREADS) {
-            if (e->ell_E <= 8) KH_ELL_STORE(1, 8);
-            else if (e->ell_E <= 16) KH_ELL_STORE(1, 16);
-            else if (e->ell_E <= 24) KH_ELL_STORE(1, 24);
-            else KH_ELL_STORE(1, 32);
+#define KH_ELL_STORE(T, R, EM) \
+    kh_ell_sweep_store<T, R, EM><<<grid, T, lds, st>>>(p, ells, e->d_ell_off, e->d_ell_vals, pulses, in, store, out, direction)
+        // one row per lane where the rows' entries fit the register budget of that many waves (512 threads: 256 VGPRs,
+        // 768: 168, 1024: 128), else two rows per lane of a 512-thread workgroup
+        if (e->N <= 512) {
+            if (e->ell_E <= 8) KH_ELL_STORE(512, 1, 8);
+            else if (e->ell_E <= 16) KH_ELL_STORE(512, 1, 16);
+            else if (e->ell_E <= 24) KH_ELL_STORE(512, 1, 24);
+            else KH_ELL_STORE(512, 1, 32);
+        } else if (e->N <= 768 && e->ell_E <= 16) {
+            if (e->ell_E <= 8) KH_ELL_STORE(768, 1, 8);
+            else KH_ELL_STORE(768, 1, 16);
+        } else if (e->ell_E <= 8) {
+            KH_ELL_STORE(1024, 1, 8);
         } else {
-            if (e->ell_E <= 8) KH_ELL_STORE(2, 8);
-            else if (e->ell_E <= 12) KH_ELL_STORE(2, 12);
-            else KH_ELL_STORE(2, 16);
+            if (e->ell_E <= 12) KH_ELL_STORE(512, 2, 12);
+            else KH_ELL_STORE(512, 2, 16);
         }
 #undef KH_ELL_STORE
     } else if (e->kind_store == KIND_TILE_Q2) {
@@ -1404,18 +1410,23 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         else
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 16>(e, p, u, ex, st) : launch_coop_update<16, 16>(e, p, u, ex, st);
     } else if (e->kind == KIND_ELL && !stepwise) {
-        const dim3 g(e->K), b(KH_ELL_THREADS);
+        const dim3 g(e->K);
         const size_t lds = kh_ell_lds_bytes();
         const bool so = u.sigma != nullptr;
-#define KH_ELL_UPDATE(R, EM)                                                                                                     \
-    (so ? launch_persistent(e, kh_ell_forward_update<R, EM, true>, g, b, lds, st, p, (const KhEll *)e->d_ell_fw,                    \
+#define KH_ELL_UPDATE(T, R, EM)                                                                                                  \
+    (so ? launch_persistent(e, kh_ell_forward_update<T, R, EM, true>, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,           \
                             (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex)                                       \
-        : launch_persistent(e, kh_ell_forward_update<R, EM, false>, g, b, lds, st, p, (const KhEll *)e->d_ell_fw,                   \
+        : launch_persistent(e, kh_ell_forward_update<T, R, EM, false>, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,          \
                             (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex))
-        if (e->N <= KH_ELL_THREADS)
-            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(1, 8) : e->ell_E <= 16 ? KH_ELL_UPDATE(1, 16) : e->ell_E <= 24 ? KH_ELL_UPDATE(1, 24) : KH_ELL_UPDATE(1, 32);
+        if (e->N <= 512)
+            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(512, 1, 8) : e->ell_E <= 16 ? KH_ELL_UPDATE(512, 1, 16)
+                 : e->ell_E <= 24 ? KH_ELL_UPDATE(512, 1, 24) : KH_ELL_UPDATE(512, 1, 32);
+        else if (e->N <= 768 && e->ell_E <= 16)
+            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(768, 1, 8) : KH_ELL_UPDATE(768, 1, 16);
+        else if (e->ell_E <= 8)
+            rc = KH_ELL_UPDATE(1024, 1, 8);
         else
-            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(2, 8) : e->ell_E <= 12 ? KH_ELL_UPDATE(2, 12) : KH_ELL_UPDATE(2, 16);
+            rc = e->ell_E <= 12 ? KH_ELL_UPDATE(512, 2, 12) : KH_ELL_UPDATE(512, 2, 16);
 #undef KH_ELL_UPDATE
     } else if (e->kind != KIND_GENERIC && e->kind != KIND_COOP && e->kind != KIND_ELL) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG/variants
 mkdir -p $OUT
 cd $R
-run() { name=$1; shift; timeout 600 python bench.py --no-cpu-baseline --no-config4 --no-variants --steps 4 --warmup 1 "$@" 2>/dev/null | tail -1 > $OUT/$name.json; cut -c1-160 $OUT/$name.json; }
+run() { name=$1; shift; timeout 600 python bench.py --no-cpu-baseline --no-config4 --no-variants --no-sparse --steps 4 --warmup 1 "$@" 2>/dev/null | tail -1 > $OUT/$name.json; cut -c1-160 $OUT/$name.json; }
 run distinct --distinct
 run L2 --L 2
 run L3 --L 3

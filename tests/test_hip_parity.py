@@ -447,10 +447,35 @@ def _tiled(spec, times):
         controls=spec.controls, update_shape=spec.update_shape, lambda_a=spec.lambda_a, chi=spec.chi)
 
 
+def _banded(N, bands, nt, K=2):
+    """Hermitian banded drift (`bands` diagonals) and a banded control on N levels: a sparse Hilbert-space problem."""
+    rng = np.random.default_rng(11)
+    half = bands // 2
+
+    def band(width, scale):
+        A = np.zeros((N, N), dtype=np.complex128)
+        for d in range(width + 1):
+            v = rng.standard_normal(N - d) + (1j * rng.standard_normal(N - d) if d else 0)
+            A += np.diag(v, d) + (np.diag(v.conj(), -d) if d else 0)
+        return scale * A / np.linalg.norm(A, 2)
+
+    H0, H1 = band(half, 3.0), band(half - 1, 1.0)
+    init = np.zeros((K, N), dtype=np.complex128)
+    init[np.arange(K), np.arange(K)] = 1.0
+    target = np.roll(init, 1, axis=1)
+    T = 0.3
+    return configs.ProblemSpec(
+        name='banded_n%d' % N, H0=[H0] * K, Hc=[[H1]] * K, is_super=False, init=init, target=target,
+        tlist=np.linspace(0, T, nt), controls=[lambda t, args: 0.7 * np.sin(np.pi * t / T) ** 2 + 0.1],
+        update_shape=lambda t: 1.0, lambda_a=2.0, chi='re')
+
+
 SPARSE_CASES = {
     # name: (spec, kernel family the engine picks by itself)
     'lindblad': (lambda: configs.config_sparse_lindblad(), 'ell/csr'),            # N = 144, ~7 entries per row
     'lindblad_n625': (lambda: configs.config_sparse_lindblad(d=25, nt=9, K=2), 'ell/csr'),   # two rows per lane (N > 512)
+    'lindblad_n900': (lambda: configs.config_sparse_lindblad(d=30, nt=4, K=1), 'ell/csr'),   # 1024-thread form (N > 768, E <= 8)
+    'banded_n800': (lambda: _banded(800, 11, nt=4), 'ell/csr'),   # two rows per lane of 512 threads (N > 768, 8 < E <= 16)
     'lindblad_k300': (lambda: _tiled(configs.config_sparse_lindblad(d=5, nt=13, K=5), 60), 'generic/csr'),  # more objectives than CUs
     'c5_n33': (lambda: SMALL['c5_n33'](), 'generic/csr'),                         # 33 entries per row: too wide for registers
     'c5_n12_L3': (lambda: SMALL['c5_n12_L3'](), 'ell/csr'),                       # three controls, distinct drifts, full rows
