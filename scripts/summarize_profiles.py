@@ -89,3 +89,26 @@ if os.path.isdir(cdir):
     json.dump(c4sum, open(os.path.join(dst, 'pmc_config4.json'), 'w'), indent=1, sort_keys=True)
     for kern, c in c4sum.items():
         print(kern, {k: '%.3g' % v['avg_per_launch'] for k, v in c.items()})
+
+# PMC passes of the kernels the headline does not launch (scripts/collect_tile_pmc.sh <tag>) -> profiles/<tag>/pmc_tile.json
+tdir = os.path.join(src, 'tile_pmc')
+if os.path.isdir(tdir):
+    tsum = {}
+    for sub in sorted(os.listdir(tdir)):
+        path = os.path.join(tdir, sub, 'b_counter_collection.csv')
+        if not os.path.exists(path):
+            continue
+        case = sub.rsplit('_', 1)[0]
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(path)):
+            agg[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
+        for kern, ctrs in agg.items():
+            if kern.startswith(('kh_tile', 'kh_q2', 'kh_ell', 'kh_gen')):
+                for c, v in ctrs.items():
+                    tsum.setdefault(case, {}).setdefault(kern, {})[c] = {'avg_per_launch': sum(v) / len(v), 'launches': len(v)}
+    json.dump(tsum, open(os.path.join(dst, 'pmc_tile.json'), 'w'), indent=1, sort_keys=True)
+    for case, kerns in tsum.items():
+        for kern, c in kerns.items():
+            if 'SQ_WAVE_CYCLES' in c:
+                wc = c['SQ_WAVE_CYCLES']['avg_per_launch']
+                print(case, kern, {k: round(100 * v['avg_per_launch'] / wc, 1) for k, v in c.items() if k.startswith('SQ_') and k not in ('SQ_WAVE_CYCLES',)})
