@@ -463,6 +463,7 @@ def main():
             'mini4/wave': ('kh_quad_forward_update', 'kh_quad_sweep_store'),
             'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
             'coop16/mfma': ('kh_coop_forward_update', 'kh_coop_sweep_store'),
+            'tile128/512': ('kh_tn_forward_update', 'kh_tn_sweep_store'),
         }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
         if group is not None and not getattr(eng, '_p2p_used', False) and eng.kernel != 'generic':
             # per-interval launches (RCCL path) run the two-tile kernel, see krotov_hip.hip:launch_update
@@ -670,6 +671,8 @@ def main():
             # "L=1 (also report L=4)" and "a second variant with K distinct random H0_k"
             out['L4'] = leg(L=4, steps=3, warmup=1)
             out['distinct'] = leg(distinct=True, steps=3, warmup=1)
+            # per-objective operators beyond the N <= 64 register tiles (kh_tilen.h: the generator in registers up to N = 128)
+            out['N96'] = leg(N=96, steps=3, warmup=1)
         if not args.no_sparse:
             try:
                 out['sparse'] = sparse_leg()

@@ -10,7 +10,10 @@
 //     one LDS write per row, one barrier;
 //   * per interval A is ADVANCED, A += sum_l (eps_l - eps_l') H_l, from lane-linear copies of the control operators
 //     (kh_tn_permute at engine creation: 1 KiB per wave-level load), and restarts from H0 every 64 intervals;
-//   * the update sweep's <chi|H_l phi> stream the same copies once more (no room to keep them across the exchange).
+//   * the update sweep's <chi|H_l phi> stream the same copies once more (no room to keep them across the exchange);
+//   * ONE control and N <= 96 (H1REG): the control operator stays in registers next to A (2 x 24 elements per lane), so
+//     neither the advance nor the partial sums read memory -- with 256 objectives of N = 96 the two streams are 75 MB per
+//     interval, i.e. the sweep ran at the memory system's speed, not the CU's.
 // Series: the engine's one-term-per-phase ratios (Taylor, or the Chebyshev form for Hermitian / nearly anti-Hermitian
 // generators).  Bound: LDS read (512 lanes x N/4 x 16 B per term) and fp64 FMA issue, about equal.
 #pragma once
@@ -156,7 +159,7 @@ __device__ __forceinline__ int kh_tn_expm_action(const cplx (&a)[EPL], cplx &sta
 }
 
 // tabs: [K*(1+L)] lane-order copies of this direction's operators (NULL: control absent)
-template <int EPL>
+template <int EPL, bool H1REG>
 __global__ void __launch_bounds__(KH_TN_THREADS)
 kh_tn_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ tabs, const double *__restrict__ pulses,
                   const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out, int direction) {
@@ -170,7 +173,8 @@ kh_tn_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ tabs, const dou
     for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
         const cplx *const *tab_k = tabs + (size_t)k * (1 + L);
         const double *norms_k = p.op_norms + (size_t)k * (1 + L);
-        cplx a[EPL];
+        cplx a[EPL], h1[H1REG ? EPL : 1];
+        if constexpr (H1REG) kh_tn_load<EPL>(tab_k[1], tid, h1);  // (L == 1, operator present: checked by the host)
         cplx state = active ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
         if (store != nullptr && writer) store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + row] = state;
         KhDegreeCache dc = {12, 1.0, 0.0};
@@ -189,9 +193,18 @@ kh_tn_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ tabs, const dou
                 }
                 const double dt = p.dt[n];
                 __syncthreads();
-                for (int l = 0; l < L; ++l) {
-                    const double e = s.eps[l], d = e - s.eps_prev[l];
-                    if (tab_k[1 + l] != nullptr && d != 0.0) kh_tn_axpy<EPL>(tab_k[1 + l], d, tid, a);
+                if constexpr (H1REG) {
+                    const double d = s.eps[0] - s.eps_prev[0];
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) {
+                        a[j].x = fma(d, h1[j].x, a[j].x);
+                        a[j].y = fma(d, h1[j].y, a[j].y);
+                    }
+                } else {
+                    for (int l = 0; l < L; ++l) {
+                        const double e = s.eps[l], d = e - s.eps_prev[l];
+                        if (tab_k[1 + l] != nullptr && d != 0.0) kh_tn_axpy<EPL>(tab_k[1 + l], d, tid, a);
+                    }
                 }
                 int nsub, m;
                 kh_degree_cached(theta * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
@@ -212,7 +225,7 @@ kh_tn_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ tabs, const dou
 }
 
 // forward sweep with sequential pulse update (optimize.py:444-508): ONE launch, grid == K <= #CUs
-template <int EPL, bool SO>
+template <int EPL, bool SO, bool H1REG>
 __global__ void __launch_bounds__(KH_TN_THREADS)
 kh_tn_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpdateArgs u, KhExchange ex) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -225,7 +238,8 @@ kh_tn_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
     const double chi_norm = u.chi_norms[k];
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.q2_theta[tid];
     if (tid < KH_MAX_L) s.g_a[tid] = 0.0;
-    cplx a[EPL];
+    cplx a[EPL], h1[H1REG ? EPL : 1];
+    if constexpr (H1REG) kh_tn_load<EPL>(tab_k[1], tid, h1);
     cplx state = active ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     if (SO && writer) u.fw_store[((size_t)k * nt) * N + row] = state;
     double matvecs = 0.0;
@@ -248,8 +262,13 @@ kh_tn_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
         __syncthreads();
         for (int l = 0; l < L; ++l) {
             double v = 0.0;
-            if (tab_k[1 + l] != nullptr) {
-                const cplx z = active ? kh_tn_row_streamed<EPL>(tab_k[1 + l], tid, s.buf[0], cg) : c_make(0.0, 0.0);
+            if (H1REG || tab_k[1 + l] != nullptr) {
+                cplx z = c_make(0.0, 0.0);
+                if constexpr (H1REG) {
+                    if (active) z = kh_tn_row(h1, s.buf[0], cg);
+                } else {
+                    if (active) z = kh_tn_row_streamed<EPL>(tab_k[1 + l], tid, s.buf[0], cg);
+                }
                 if (writer) {
                     cplx ov = c_make(0.0, 0.0);
                     c_fma_conj(ov, bra, z);
@@ -340,9 +359,18 @@ kh_tn_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
             }
             __syncthreads();
             // ---- propagate over interval n with the updated pulses (optimize.py:479-491) ----
-            for (int l = 0; l < L; ++l) {
-                const double d = s.eps[l] - s.eps_prev[l];
-                if (tab_k[1 + l] != nullptr && d != 0.0) kh_tn_axpy<EPL>(tab_k[1 + l], d, tid, a);
+            if constexpr (H1REG) {
+                const double d = s.eps[0] - s.eps_prev[0];
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    a[j].x = fma(d, h1[j].x, a[j].x);
+                    a[j].y = fma(d, h1[j].y, a[j].y);
+                }
+            } else {
+                for (int l = 0; l < L; ++l) {
+                    const double d = s.eps[l] - s.eps_prev[l];
+                    if (tab_k[1 + l] != nullptr && d != 0.0) kh_tn_axpy<EPL>(tab_k[1 + l], d, tid, a);
+                }
             }
             int nsub, m;
             kh_degree_cached(theta * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);

@@ -33,6 +33,7 @@
 #endif
 #include "kh_mini.h"
 #include "kh_ell.h"
+#include "kh_tilen.h"
 
 static thread_local std::string g_last_error;
 
@@ -54,7 +55,7 @@ static int kh_fail(int code, const char *fmt, ...) {
                            __FILE__, __LINE__);                                               \
     } while (0)
 
-enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3, KIND_COOP = 4, KIND_ELL = 5 };
+enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3, KIND_COOP = 4, KIND_ELL = 5, KIND_TILEN = 6 };
 
 struct kh_engine {
     int K, N, L, nt, is_super;
@@ -97,6 +98,8 @@ struct kh_engine {
     const cplx **d_coop_sq_fw = nullptr, **d_coop_sq_bw = nullptr;      // [3] the same for P0, P1, P2 (one control)
     const cplx **d_sq_fw = nullptr;   // [K*3] P0, P1, P2 of A^2 (q2 kernels), forward operators
     const cplx **d_sq_bw = nullptr;   // [K*3] the same for the adjoint operators
+    const cplx **d_tn_fw = nullptr, **d_tn_bw = nullptr;  // [K*(1+L)] lane-order operator copies (kh_tilen.h), or NULL
+    bool tn_h1reg = false;            // ... one control, present in every objective, N <= 96: it stays in registers too
     std::vector<void *> owned;        // adjoint operator copies
     // workspaces
     cplx *d_phi = nullptr;            // [K][N]
@@ -201,7 +204,7 @@ static int check_residency(const kh_engine *e, const void *func, int threads, si
     return KH_OK;
 }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.5 (gfx950; tile64q2, tile64, mini16, mini4, coop16/mfma, ell/csr, generic, generic/csr kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.5 (gfx950; tile64q2, tile64, mini16, mini4, coop16/mfma, ell/csr, tile128, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
@@ -211,6 +214,7 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
         case KIND_TILE_Q2: return e->mini ? (e->quad ? "mini4/wave" : "mini16/wave") : "tile64q2/512";
         case KIND_COOP: return "coop16/mfma";
         case KIND_ELL: return "ell/csr";
+        case KIND_TILEN: return "tile128/512";
         default: return e->d_csr_fw != nullptr ? "generic/csr" : "generic";
     }
 }
@@ -273,6 +277,8 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree((void *)e->d_c4_sq_bw);
     (void)hipFree((void *)e->d_sq_fw);
     (void)hipFree((void *)e->d_sq_bw);
+    (void)hipFree((void *)e->d_tn_fw);
+    (void)hipFree((void *)e->d_tn_bw);
     (void)hipFree(e->d_phi);
     (void)hipFree(e->d_slots);
     (void)hipFree(e->d_abort);
@@ -758,6 +764,49 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             if (!(pr->theta_max > 0.0)) e->theta_max = 4.0;
         }
     }
+    // Per-objective operators with 64 < N <= 128: the generator in registers (kh_tilen.h) instead of the generic kernels'
+    // re-streaming of every operator for every term.  (Objectives sharing one operator list took the cooperative
+    // matrix-core kernels above; KH_KERNEL=tilen forces this family for them too: testing.)
+    bool tilen_ok = false;
+    {
+        const bool forced = force && strcmp(force, "tilen") == 0;
+        if (csr_fw == nullptr && e->N > KH_TILE_N && e->N <= KH_TN_NMAX && e->L >= 1 &&
+            ((e->kind == KIND_GENERIC && force == nullptr) || forced)) {
+            tilen_ok = true;
+            if (forced) {
+                e->kind = KIND_GENERIC;  // (undo the cooperative choice)
+                e->grid_update = e->K < max_wgs ? e->K : max_wgs;
+                if (!(pr->theta_max > 0.0)) e->theta_max = 1.0;
+            }
+            std::map<const void *, cplx *> perm_of;
+            for (int dir = 0; dir < 2; ++dir) {
+                const std::vector<const cplx *> &tab = dir == 0 ? fw : bw;
+                std::vector<const cplx *> out(nops, nullptr);
+                for (size_t i = 0; i < nops; ++i) {
+                    if (tab[i] == nullptr) continue;
+                    auto it = perm_of.find(tab[i]);
+                    if (it == perm_of.end()) {
+                        cplx *dst = nullptr;
+                        KH_HIP_E(hipMalloc(&dst, sizeof(cplx) * (KH_TN_NMAX / 4) * KH_TN_THREADS));
+                        e->owned.push_back(dst);
+                        kh_tn_permute<<<KH_TN_NMAX / 4, KH_TN_THREADS>>>(tab[i], dst, e->N);
+                        it = perm_of.emplace(tab[i], dst).first;
+                    }
+                    out[i] = it->second;
+                }
+                const cplx ***slot = dir == 0 ? &e->d_tn_fw : &e->d_tn_bw;
+                KH_HIP_E(hipMalloc((void **)slot, sizeof(cplx *) * nops));
+                KH_HIP_E(hipMemcpy((void *)*slot, out.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
+            }
+            KH_HIP_E(hipGetLastError());
+            e->tn_h1reg = e->L == 1 && e->N <= 96 && !(getenv("KH_TN_H1REG") && atoi(getenv("KH_TN_H1REG")) == 0);
+            for (int k = 0; k < e->K; ++k) e->tn_h1reg = e->tn_h1reg && fw[(size_t)k * 2 + 1] != nullptr;
+            if (e->K <= max_wgs) {
+                e->kind = KIND_TILEN;
+                e->grid_update = e->K;
+            }
+        }
+    }
     // Sparse operators in the padded row form: one 1024-thread workgroup per objective, the matrix in registers
     // (kh_ell.h).  The update sweep exchanges the sums in-kernel, so all K workgroups must be resident (one per CU);
     // with more objectives it stays with the generic CSR kernels, the plain sweeps take their objectives in turns.
@@ -772,7 +821,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     }
     // The plain sweeps have no cross-objective coupling, so the register-tile kernel serves them for any
     // number of objectives (workgroups simply run in turns) even when the update sweep needs the generic one.
-    e->kind_store = ell_ok ? KIND_ELL : e->kind;
+    e->kind_store = ell_ok ? KIND_ELL : (tilen_ok ? KIND_TILEN : e->kind);
     if (e->kind == KIND_GENERIC && csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 &&
         !(force && strcmp(force, "generic") == 0))
         e->kind_store = KIND_TILE_RPT1;
@@ -1225,6 +1274,21 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
             kh_q4_sweep_store<<<e->K, KH_Q4_THREADS, kh_q4_lds_bytes(), st>>>(
                 p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
 #endif
+    } else if (e->kind_store == KIND_TILEN) {
+        const cplx *const *tabs = backward ? e->d_tn_bw : e->d_tn_fw;
+        const int grid = e->K < e->num_cus ? e->K : e->num_cus;
+        const size_t lds = kh_tn_lds_bytes();
+#define KH_TN_STORE(EP, HR) kh_tn_sweep_store<EP, HR><<<grid, KH_TN_THREADS, lds, st>>>(p, tabs, pulses, in, store, out, direction)
+        if (e->N <= 80) {
+            if (e->tn_h1reg) KH_TN_STORE(20, true); else KH_TN_STORE(20, false);
+        } else if (e->N <= 96) {
+            if (e->tn_h1reg) KH_TN_STORE(24, true); else KH_TN_STORE(24, false);
+        } else if (e->N <= 112) {
+            KH_TN_STORE(28, false);
+        } else {
+            KH_TN_STORE(32, false);
+        }
+#undef KH_TN_STORE
     } else if (e->kind_store == KIND_ELL) {
         const KhEll *ells = backward ? e->d_ell_bw : e->d_ell_fw;
         const int grid = e->K < 4 * e->num_cus ? e->K : 4 * e->num_cus;
@@ -1409,6 +1473,20 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 4>(e, p, u, ex, st) : launch_coop_update<16, 4>(e, p, u, ex, st);
         else
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 16>(e, p, u, ex, st) : launch_coop_update<16, 16>(e, p, u, ex, st);
+    } else if (e->kind == KIND_TILEN && !stepwise) {
+        const dim3 g(e->K), b(KH_TN_THREADS);
+        const size_t lds = kh_tn_lds_bytes();
+        const bool so = u.sigma != nullptr;
+#define KH_TN_UPDATE(EP, HR)                                                                                                  \
+    (so ? launch_persistent(e, kh_tn_forward_update<EP, true, HR>, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex) \
+        : launch_persistent(e, kh_tn_forward_update<EP, false, HR>, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex))
+        if (e->N <= 80)
+            rc = e->tn_h1reg ? KH_TN_UPDATE(20, true) : KH_TN_UPDATE(20, false);
+        else if (e->N <= 96)
+            rc = e->tn_h1reg ? KH_TN_UPDATE(24, true) : KH_TN_UPDATE(24, false);
+        else
+            rc = e->N <= 112 ? KH_TN_UPDATE(28, false) : KH_TN_UPDATE(32, false);
+#undef KH_TN_UPDATE
     } else if (e->kind == KIND_ELL && !stepwise) {
         const dim3 g(e->K);
         const size_t lds = kh_ell_lds_bytes();
@@ -1428,7 +1506,7 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         else
             rc = e->ell_E <= 12 ? KH_ELL_UPDATE(512, 2, 12) : KH_ELL_UPDATE(512, 2, 16);
 #undef KH_ELL_UPDATE
-    } else if (e->kind != KIND_GENERIC && e->kind != KIND_COOP && e->kind != KIND_ELL) {
+    } else if (e->kind != KIND_GENERIC && e->kind != KIND_COOP && e->kind != KIND_ELL && e->kind != KIND_TILEN) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
         switch (e->L) {
             case 1: rc = rpt2 ? launch_tile_update<2, 1>(e, p, u, ex, st) : launch_tile_update<1, 1>(e, p, u, ex, st); break;

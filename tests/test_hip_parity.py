@@ -34,7 +34,10 @@ SMALL = {
     'c5_n12_L3': lambda: configs.config_c5(K=5, N=12, nt=81, L=3, distinct=True),
     'c5_n64': lambda: configs.config_c5(K=8, N=64, nt=61),
     'c5_n64_L2': lambda: configs.config_c5(K=4, N=64, nt=41, L=2, distinct=True),
+    # per-objective operators with 64 < N <= 128: the generator in registers, N / 4 elements per lane (kh_tilen.h)
     'c5_n80': lambda: configs.config_c5(K=3, N=80, nt=31, L=2),
+    'c5_n100': lambda: configs.config_c5(K=4, N=100, nt=21, L=1, distinct=True),
+    'c5_n128': lambda: configs.config_c5(K=2, N=128, nt=11, L=1),
     'c5_n33': lambda: configs.config_c5(K=5, N=33, nt=41),
     # more objectives than CUs: two 256-thread workgroups per CU
     'c5_k300': lambda: configs.config_c5(K=300, N=16, nt=21),
@@ -98,6 +101,7 @@ def test_sweeps_match_oracle(name):
     assert (eng.kernel == 'tile64/256') == (name == 'c5_k300')
     assert (eng.kernel == 'tile64/512 per interval') == (name in ('c5_k600', 'c5_k300_L2'))
     assert (eng.kernel == 'coop16/mfma') == (name.startswith('c4_d') and spec.N > 64 or name.startswith('shared'))
+    assert (eng.kernel == 'tile128/512') == (name in ('c5_n80', 'c5_n100', 'c5_n128'))
     eng.close()
 
 
@@ -153,6 +157,38 @@ def test_kernel_families_agree(name, kernel, monkeypatch):
     ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
     assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * max(1.0, np.abs(np.array(ref_opt)).max())
     assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+    eng.close()
+
+
+@pytest.mark.parametrize('name', ['c4_d9', 'c4_d10_k9', 'c5_n80', 'c5_n128'])
+@pytest.mark.parametrize('kernel', ['tilen', 'generic'])
+def test_register_generator_kernels_for_n_up_to_128(name, kernel, monkeypatch):
+    """64 < N <= 128 with the generator in registers (kh_tilen.h; KH_KERNEL=tilen forces it also where the objectives
+    share their operators and the cooperative kernels would run) and the generic kernels it replaces there: the three
+    sweeps vs the oracle, Hilbert and Liouville space."""
+    spec = SMALL[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    monkeypatch.setenv('KH_KERNEL', kernel)
+    eng = _engine(spec)
+    assert eng.kernel == ('tile128/512' if kernel == 'tilen' else 'generic')
+    pulses = np.array(gp)
+    fw_T, states = eng.forward(pulses, spec.init, store=True)
+    ref_T, ref_states = ko.forward_propagation(prob, gp, store=True)
+    tol = 1e-11 if name.startswith('c4_d') else 1e-12
+    assert np.abs(states.cpu().numpy() - ref_states).max() < tol
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.02 if name.startswith('c4_d') else 0.37)
+    chi = eng.backward(chi_T, pulses)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    assert np.abs(chi.cpu().numpy() - ref_chi).max() < tol
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < tol * scale
+    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < tol
+    assert np.abs(g_a.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
     eng.close()
 
 
@@ -331,7 +367,7 @@ def test_objective_propagate_on_device():
 
 SECOND_ORDER_CASES = [
     ('c3', None), ('c5_n16', None), ('c3', 'mini'), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
-    ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c2l', None),
+    ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c5_n80', 'generic'), ('c5_n100', None), ('c4_d9', 'tilen'), ('c2l', None),
     ('lindblad', 'sparse'), ('c5_n12_L3', 'sparse'),
     ('c4_d9', None), ('shared_n96_L2', None), ('c3', 'coop'), ('shared_n96_L2', 'coop16cols'), ('shared_n96_L2', 'coop2cols'), ('c4_d9', 'coop2cols'),
 ]
@@ -973,6 +1009,8 @@ def _two_rank_spec(case):
         return spec
     if case in ('c4w4', 'c4w8'):  # BASELINE config 4's partition: 16 density matrices as 4 x 4 / 8 x 2 (N = 81 here)
         return configs.config_c4(d=9, nt=41, n_logical=4)
+    if case == 'n80':  # per-objective operators, N = 80, two controls: the register-generator kernels, 3 + 3 objectives
+        return configs.config_c5(K=6, N=80, nt=31, L=2)
     if case == 'c4full':  # BASELINE config 4 at full size (debugging the 8-rank bench leg; not in a test list)
         return configs.config_c4()
     if case == 'c5w4L2':  # two controls (one-term-per-phase kernels), 4 x 5
@@ -1025,7 +1063,7 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'c4k25', 'k1100'])
+@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'c4k25', 'k1100', 'n80'])
 def test_two_ranks_sharded_on_one_gpu(case):
     import socket
 
@@ -1051,11 +1089,12 @@ def test_two_ranks_sharded_on_one_gpu(case):
         ref = oracle_optimize(spec, 2, sigma=SigmaA(0.0, 2e-3))
     else:
         ref = oracle_optimize(spec, 2)
-    tol = 1e-12 if case in ('c5', 'c3', 'k1100') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
+    tol = 1e-12 if case in ('c5', 'c3', 'k1100', 'n80') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
     for _, pulses, tau, used_p2p, kernel in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
-        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/512 per interval'}.get(case, 'coop16/mfma')
+        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/512 per interval',
+                          'n80': 'tile128/512'}.get(case, 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
     # the path this test is here for: the sums crossed the ranks inside the persistent kernels, through the
     # peer-mapped windows -- not through the per-interval fallback
