@@ -78,12 +78,12 @@ def algorithmic_bytes(K, N, nt, L):
 
 def build_id():
     """What the kernels were built from: kh_version() + the first 16 hex digits of the SHA-256 over the kernel sources
-    (krotov_amd/csrc/*, include/*.h, sorted by name).  A git hash would do the same job but the GPU box has no .git."""
+    (krotov_amd/csrc/*, sorted by name).  A git hash would do the same job but the GPU box has no .git."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, 'krotov_amd', 'csrc', '*')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'krotov_amd', 'csrc', '*'))):
         with open(path, 'rb') as fh:
             h.update(os.path.basename(path).encode() + b'\0' + fh.read())
     try:
