@@ -303,6 +303,8 @@ struct HostCsr {  // canonical: column indices sorted within a row, duplicates s
     std::vector<cplx> data;
 };
 
+static bool canonical_csr(const int *indptr, const int *indices, const cplx *data, long long nnz, int N, HostCsr &out);
+
 static hipError_t fetch_csr(const kh_csr &c, int N, HostCsr &out) {
     std::vector<int> indptr(N + 1), indices((size_t)c.nnz);
     std::vector<cplx> data((size_t)c.nnz);
@@ -310,6 +312,11 @@ static hipError_t fetch_csr(const kh_csr &c, int N, HostCsr &out) {
     if (err == hipSuccess && c.nnz > 0) err = hipMemcpy(indices.data(), c.indices, sizeof(int) * (size_t)c.nnz, hipMemcpyDeviceToHost);
     if (err == hipSuccess && c.nnz > 0) err = hipMemcpy(data.data(), c.data, sizeof(cplx) * (size_t)c.nnz, hipMemcpyDeviceToHost);
     if (err != hipSuccess) return err;
+    return canonical_csr(indptr.data(), indices.data(), data.data(), c.nnz, N, out) ? hipSuccess : hipErrorInvalidValue;
+}
+
+// host arrays -> canonical form; false on inconsistent arrays
+static bool canonical_csr(const int *indptr, const int *indices, const cplx *data, long long nnz, int N, HostCsr &out) {
     out.indptr.assign(N + 1, 0);
     out.indices.clear();
     out.data.clear();
@@ -317,9 +324,9 @@ static hipError_t fetch_csr(const kh_csr &c, int N, HostCsr &out) {
     for (int r = 0; r < N; ++r) {
         row.clear();
         const int lo = indptr[r], hi = indptr[r + 1];
-        if (lo < 0 || hi < lo || hi > c.nnz) return hipErrorInvalidValue;
+        if (lo < 0 || hi < lo || hi > nnz) return false;
         for (int j = lo; j < hi; ++j) {
-            if (indices[j] < 0 || indices[j] >= N) return hipErrorInvalidValue;
+            if (indices[j] < 0 || indices[j] >= N) return false;
             row.emplace_back(indices[j], data[j]);
         }
         std::stable_sort(row.begin(), row.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
@@ -338,7 +345,7 @@ static hipError_t fetch_csr(const kh_csr &c, int N, HostCsr &out) {
         }
         out.indptr[r + 1] = (int)out.indices.size();
     }
-    return hipSuccess;
+    return true;
 }
 
 // does b equal sign * a, entry for entry?
@@ -1928,5 +1935,34 @@ extern "C" int kh_last_stats(kh_engine *e, double stats[4]) {
         fprintf(stderr, "\n");
     }
 #endif
+    return KH_OK;
+}
+
+extern "C" int kh_ell_layout(int32_t N, int32_t n_ops, const kh_csr *ops_host, int32_t *E_out, int32_t *Ec_out, int32_t *off_out,
+                             kh_cdouble *vals_out, int32_t E_cap) {
+    if (ops_host == nullptr || E_out == nullptr || Ec_out == nullptr || n_ops < 1 || N < 1)
+        return kh_fail(KH_ERR_INVALID, "bad argument");
+    if (N > KH_ELL_NMAX) return kh_fail(KH_ERR_UNSUPPORTED, "N = %d: the padded row form serves N <= %d", N, KH_ELL_NMAX);
+    std::vector<HostCsr> host(n_ops);
+    std::vector<const HostCsr *> ptrs(n_ops, nullptr);
+    for (int o = 0; o < n_ops; ++o) {
+        if (ops_host[o].data == nullptr) continue;
+        if (!canonical_csr(ops_host[o].indptr, ops_host[o].indices, (const cplx *)ops_host[o].data, ops_host[o].nnz, N, host[o]))
+            return kh_fail(KH_ERR_INVALID, "operator %d: inconsistent CSR arrays", o);
+        ptrs[o] = &host[o];
+    }
+    std::vector<int> off;
+    std::vector<cplx> vals;
+    int E = 0, Ec = 0;
+    if (!build_ell_host(ptrs, N, off, vals, E, Ec))
+        return kh_fail(KH_ERR_UNSUPPORTED, "rows wider than the kernels' register budget (%d entries; %d for N > %d)", KH_ELL_EMAX,
+                       KH_ELL_EMAX2, KH_ELL_THREADS);
+    *E_out = E;
+    *Ec_out = Ec;
+    if (off_out != nullptr || vals_out != nullptr) {
+        if (E_cap < E) return kh_fail(KH_ERR_INVALID, "E_cap = %d < E = %d", E_cap, E);
+        if (off_out != nullptr) memcpy(off_out, off.data(), sizeof(int) * off.size());
+        if (vals_out != nullptr) memcpy(vals_out, vals.data(), sizeof(cplx) * vals.size());
+    }
     return KH_OK;
 }

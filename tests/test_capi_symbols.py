@@ -208,3 +208,86 @@ def test_series_tables_defect_bound_at_the_corner_of_the_numerical_range():
                 assert err < 2.0 ** -53 * (2.0 + 0.5 * np.exp(theta)), (cap, defect, m, theta, err)
                 checked += 1
             assert checked >= 3, (cap, defect)
+
+
+def _ell_layout(ops, N):
+    """kh_ell_layout on scipy.sparse operators (None: absent) -> (E, Ec, off [E][1024], vals [n][E][1024])."""
+    import ctypes
+
+    import numpy as np
+
+    lib = _lib.load()
+    arr = (_lib.kh_csr * len(ops))()
+    keep = []
+    for o, m in enumerate(ops):
+        if m is None:
+            continue
+        indptr = np.ascontiguousarray(m.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(m.indices, dtype=np.int32)
+        data = np.ascontiguousarray(m.data, dtype=np.complex128)
+        keep.append((indptr, indices, data))
+        arr[o].nnz = len(data)
+        arr[o].indptr, arr[o].indices, arr[o].data = indptr.ctypes.data, indices.ctypes.data, data.ctypes.data
+    E, Ec = ctypes.c_int32(), ctypes.c_int32()
+    rc = lib.kh_ell_layout(N, len(ops), arr, ctypes.byref(E), ctypes.byref(Ec), None, None, 0)
+    if rc != 0:
+        return rc, None, None, None
+    off = np.zeros((E.value, 1024), dtype=np.int32)
+    vals = np.zeros((len(ops), E.value, 1024), dtype=np.complex128)
+    assert lib.kh_ell_layout(N, len(ops), arr, ctypes.byref(E), ctypes.byref(Ec), off.ctypes.data, vals.ctypes.data, E.value) == 0
+    return E.value, Ec.value, off, vals
+
+
+def test_sparse_row_form_reproduces_the_operators():
+    """kh_ell_layout (host code of the library, no GPU): the padded row form the sparse kernels keep in registers.  For
+    a drift and two controls with different patterns (one absent in a second list), unsorted column indices and
+    duplicate entries: sum_e vals[o][e][r] x[off[e][r] / 16] must be (A_o x)[r] for every operator, the entries the
+    controls touch sit in the first Ec slots of EVERY row, E and Ec are multiples of four, rows are padded with their own
+    row and value zero; too wide rows and N > 1024 are refused (those engines run the generic CSR kernels)."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(3)
+    N = 300
+
+    def rand_sparse(density):
+        m = sp.random(N, N, density=density, random_state=np.random.RandomState(int(rng.integers(1 << 30))), format='coo')
+        m = sp.coo_matrix((rng.standard_normal(m.nnz) + 1j * rng.standard_normal(m.nnz), (m.row, m.col)), shape=(N, N))
+        return m
+
+    A0, A1, A2 = rand_sparse(0.02), rand_sparse(0.008), rand_sparse(0.004)
+    dup = sp.coo_matrix((np.concatenate([A0.data, A0.data[:50]]), (np.concatenate([A0.row, A0.row[:50]]),
+                                                                   np.concatenate([A0.col, A0.col[:50]]))), shape=(N, N))
+    unsorted = sp.csr_matrix(dup)  # duplicates summed by scipy ...
+    raw = sp.csr_matrix(A0)
+    raw.indices = raw.indices.copy()
+    raw.has_sorted_indices = False
+    for r in range(N):  # ... and column indices handed over in reverse order
+        lo, hi = raw.indptr[r], raw.indptr[r + 1]
+        raw.indices[lo:hi] = raw.indices[lo:hi][::-1].copy()
+        raw.data[lo:hi] = raw.data[lo:hi][::-1].copy()
+    for ops in ([raw, sp.csr_matrix(A1), sp.csr_matrix(A2)], [unsorted, None, sp.csr_matrix(A2)]):
+        E, Ec, off, vals = _ell_layout(ops, N)
+        assert E % 4 == 0 and Ec % 4 == 0 and 0 < Ec <= E <= 32
+        x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+        cols = off[:, :N] // 16
+        assert (off % 16 == 0).all() and cols.min() >= 0 and cols.max() < N
+        assert (cols[:, :] == np.arange(N)[None, :])[np.abs(vals[:, :, :N]).sum(axis=0) == 0].all()  # padding: own row
+        assert np.abs(vals[:, :, N:]).max() == 0.0
+        for o, m in enumerate(ops):
+            want = np.zeros(N, dtype=complex) if m is None else sp.csr_matrix(m) @ x
+            got = (vals[o][:, :N] * x[cols]).sum(axis=0)
+            assert np.abs(got - want).max() < 1e-13
+        # nothing a control touches lies beyond slot Ec
+        for o in range(1, len(ops)):
+            assert np.abs(vals[o][Ec:]).max() == 0.0 if E > Ec else True
+        # every column appears once per row among the non-padding slots
+        for r in (0, 17, N - 1):
+            live = cols[:, r][np.abs(vals[:, :, r]).sum(axis=0) > 0]
+            assert len(set(live.tolist())) == len(live)
+    dense_rows = sp.csr_matrix(np.ones((40, 40), dtype=complex))
+    assert _ell_layout([dense_rows], 40)[0] == _lib.KH_ERR_UNSUPPORTED
+    assert b'wider' in _lib.load().kh_last_error()
+    wide16 = sp.csr_matrix(sp.random(600, 600, density=0.04, random_state=np.random.RandomState(1), format='csr') + sp.eye(600))
+    assert _ell_layout([wide16.astype(complex)], 600)[0] == _lib.KH_ERR_UNSUPPORTED  # > 16 entries per row, N > 512
+    assert _ell_layout([sp.eye(1025, format='csr', dtype=complex)], 1025)[0] == _lib.KH_ERR_UNSUPPORTED

@@ -1009,6 +1009,8 @@ def _two_rank_spec(case):
         return spec
     if case in ('c4w4', 'c4w8'):  # BASELINE config 4's partition: 16 density matrices as 4 x 4 / 8 x 2 (N = 81 here)
         return configs.config_c4(d=9, nt=41, n_logical=4)
+    if case == 'sparse':  # sparse Liouvillians through DensityMatrixODEPropagator: the matrix-in-registers kernels, 2 + 2
+        return configs.config_sparse_lindblad(d=9, nt=41, K=4)
     if case == 'n80':  # per-objective operators, N = 80, two controls: the register-generator kernels, 3 + 3 objectives
         return configs.config_c5(K=6, N=80, nt=31, L=2)
     if case == 'c4full':  # BASELINE config 4 at full size (debugging the 8-rank bench leg; not in a test list)
@@ -1043,6 +1045,19 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
         spec = _two_rank_spec(case)
         objectives, pulse_options = cfg.spec_to_objectives(spec, ka)
         prop = ka.propagators.HipExpm(liouville=True) if spec.is_super else ka.propagators.expm
+        if case == 'sparse':
+            import scipy.sparse as sp
+
+            made = {}
+            for obj in objectives:  # the same nested lists, operators as scipy.sparse matrices
+                for i, term in enumerate(obj.H):
+                    op = term[0] if isinstance(term, list) else term
+                    made.setdefault(id(op), (sp.csr_matrix(op), op))
+                    if isinstance(term, list):
+                        term[0] = made[id(op)][0]
+                    else:
+                        obj.H[i] = made[id(op)][0]
+            prop = ka.propagators.DensityMatrixODEPropagator()
         extra = {}
         if case == 'c4so':
             from helpers import product_sigma
@@ -1063,7 +1078,7 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'c4k25', 'k1100', 'n80'])
+@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'c4k25', 'k1100', 'n80', 'sparse'])
 def test_two_ranks_sharded_on_one_gpu(case):
     import socket
 
@@ -1089,12 +1104,12 @@ def test_two_ranks_sharded_on_one_gpu(case):
         ref = oracle_optimize(spec, 2, sigma=SigmaA(0.0, 2e-3))
     else:
         ref = oracle_optimize(spec, 2)
-    tol = 1e-12 if case in ('c5', 'c3', 'k1100', 'n80') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
+    tol = 1e-12 if case in ('c5', 'c3', 'k1100', 'n80', 'sparse') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
     for _, pulses, tau, used_p2p, kernel in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
         assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/512 per interval',
-                          'n80': 'tile128/512'}.get(case, 'coop16/mfma')
+                          'n80': 'tile128/512', 'sparse': 'ell/csr'}.get(case, 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
     # the path this test is here for: the sums crossed the ranks inside the persistent kernels, through the
     # peer-mapped windows -- not through the per-interval fallback
