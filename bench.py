@@ -602,14 +602,11 @@ def main():
 
     other = 'weak' if args.scaling == 'strong' else 'strong'
     out = measure(args.scaling)
-    second = measure(other) if world > 1 and args.workload == 'c5' else None
     if rank == 0:
         out['n_ranks_seen'] = torch.distributed.get_world_size() if group is not None else 1
-        if second is not None:
-            # the same job with the other partitioning of the objectives (see the module docstring)
-            out[other] = {k: second[k] for k in ('value', 'unit', 'iterations_per_sec', 'ms_per_step', 'scaling')}
-            out[other]['objectives'] = second['config']['objectives']
-            out[other]['kernels'] = {k: second['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')}
+    else:
+        out = {}
+
     def guarded(name, seconds, fn):
         """A side measurement of a sharded run under a watchdog: if it does not come back within `seconds` (a collective
         or an in-kernel wait that hangs cannot be interrupted from Python), every rank ends the process with the headline
@@ -635,6 +632,14 @@ def main():
         finally:
             watchdog.cancel()
 
+    if world > 1 and args.workload == 'c5':
+        # the same job with the other partitioning of the objectives (see the module docstring) -- like every side
+        # measurement of a sharded run under the watchdog: the headline line above must get out whatever happens here
+        second = guarded(other, args.rccl_leg_timeout, lambda: measure(other))
+        if rank == 0 and second is not None:
+            out[other] = {k: second[k] for k in ('value', 'unit', 'iterations_per_sec', 'ms_per_step', 'scaling')}
+            out[other]['objectives'] = second['config']['objectives']
+            out[other]['kernels'] = {k: second['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')}
     rccl = None
     if (world > 1 or args.force_dist) and args.workload == 'c5' and not args.no_rccl_leg:
         # the north star's transport: one RCCL all-reduce of the L update sums per time interval (kh_update_begin /
