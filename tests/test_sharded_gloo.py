@@ -55,9 +55,9 @@ def _worker(rank, world, port, K, queue):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('K', [4, 5])
-def test_two_rank_gloo_matches_single_process_oracle(K):
-    world = 2
+@pytest.mark.parametrize('K,world', [(4, 2), (5, 2), (7, 4)])
+def test_two_rank_gloo_matches_single_process_oracle(K, world):
+    """world 2 (even and uneven shards) and world 4 (7 objectives as 2 + 2 + 2 + 1)."""
     ctx = mp.get_context('spawn')
     queue = ctx.Queue()
     port = _free_port()
@@ -76,7 +76,7 @@ def test_two_rank_gloo_matches_single_process_oracle(K):
         assert np.abs(tau - ref['tau_vals']).max() < 1e-12
         assert np.abs(states - ref['fw_T']).max() < 1e-12
     # every rank derived bit-identical pulses (same all-reduced sums, same arithmetic)
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert all(np.array_equal(o[1], out[0][1]) and np.array_equal(o[2], out[0][2]) for o in out)
 
 
 def test_shard_range_covers_everything():
