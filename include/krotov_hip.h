@@ -292,7 +292,8 @@ int kh_series_tables(int32_t real_spectrum, double tol, double *theta /* [65] */
 /* The same tables of the Chebyshev form as an engine builds them for a generator f A dt that is anti-Hermitian only
  * up to a Hermitian part of norm <= `defect` (a weakly damped Liouvillian, a Hamiltonian with a small anti-Hermitian
  * part; the engine measures the defect of the drift, the controls must be exactly (anti-)self-adjoint), valid up to
- * theta <= `theta_cap` (2 for the register-tile kernels, 4 for the cooperative ones; Taylor beyond).  The truncation
+ * theta <= `theta_cap` (2 for the register-tile kernels, 4 for the cooperative ones, 6 for the sparse ones; at most 8;
+ * Taylor beyond).  The truncation
  * error is bounded on the numerical range, (1 + sqrt 2) 2 sum_{k>m} |J_k(theta)| cosh(k asinh(defect / theta)).
  * defect = 0 and theta_cap = 2 give kh_series_tables(1, ...).  Host only. */
 int kh_series_tables_defect(double tol, double theta_cap, double defect, double *theta /* [65] */,

@@ -24,6 +24,7 @@
 #define KH_ELL_NMAX 1024  // rows: one per lane up to 512, two per lane (tid, tid + 512) up to 1024
 #define KH_ELL_EMAX 32    // widest padded row with one row per lane; with two rows per lane: KH_ELL_EMAX2
 #define KH_ELL_EMAX2 16
+#define KH_ELL_THETA_CAP 6.0  // largest ||A dt|| of one sub-step with the Chebyshev-form series (krotov_hip.hip)
 
 // One distinct operator list, one direction: where its arrays start in the engine's two pools (kernel arguments, so the
 // loads are global loads; pointers inside a structure read from memory would make them FLAT ones)

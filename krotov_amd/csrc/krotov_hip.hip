@@ -824,7 +824,12 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         }
         // a term of the series costs a workgroup-wide round whatever it multiplies: fewer, longer sub-steps pay, as
         // for the cooperative kernels (theta <= 4: round-off ~ e^theta eps per step, far inside the parity budget)
-        if (!(pr->theta_max > 0.0)) e->theta_max = 4.0;
+        if (!(pr->theta_max > 0.0)) {
+            // (the long sub-steps only with the Chebyshev form's coefficients; Taylor's at theta <= 4 as before)
+            const bool cheb = e->real_spectrum || (e->imag_defect >= 0.0 && e->imag_defect <= 0.05);
+            e->theta_max = cheb && !(getenv("KH_NEAR_IMAG") && atoi(getenv("KH_NEAR_IMAG")) == 0) ? KH_ELL_THETA_CAP : 4.0;
+            if (const char *d = getenv("KH_ELL_CAP")) e->theta_max = atof(d) > 0.0 ? atof(d) : e->theta_max;
+        }
     }
     // The plain sweeps have no cross-objective coupling, so the register-tile kernel serves them for any
     // number of objectives (workgroups simply run in turns) even when the update sweep needs the generic one.
@@ -991,8 +996,14 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data(), 4.0, e->imag_defect);
         } else if (ell_ok && (e->real_spectrum || (e->imag_defect >= 0.0 && e->imag_defect <= 0.05)) &&
                    !(getenv("KH_NEAR_IMAG") && atoi(getenv("KH_NEAR_IMAG")) == 0)) {
-            // sparse operators in the padded row form: like the cooperative kernels, the Chebyshev form up to theta = 4
-            kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data(), 4.0,
+            // sparse operators in the padded row form: a term costs a workgroup-wide round, so one long sub-step beats
+            // several short ones: the Chebyshev form up to theta = 6.  Measured on the reference's three-states problem
+            // (scripts/exp_ell_cap.py, theta = 4.4 ... 7.9 per step, 3 iterations x 3 sweeps x 2000 steps): tau within
+            // 6e-14 and the pulses within 7e-15 of the same run with theta <= 1 per sub-step, for caps 4, 5, 6 and 8
+            // alike; KH_ELL_CAP: A/B switch
+            double cap = KH_ELL_THETA_CAP;
+            if (const char *d = getenv("KH_ELL_CAP")) cap = atof(d) > 0.0 ? atof(d) : cap;
+            kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data(), cap,
                                         e->real_spectrum ? 0.0 : e->imag_defect);
         } else if (e->real_spectrum) {
             kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data());
@@ -1880,8 +1891,8 @@ extern "C" int kh_series_tables(int32_t real_spectrum, double tol, double *theta
 
 extern "C" int kh_series_tables_defect(double tol, double theta_cap, double defect, double *theta, double *ratios) {
     if (theta == nullptr || ratios == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
-    if (!(theta_cap > 0.0) || theta_cap > 4.0 || !(defect >= 0.0))
-        return kh_fail(KH_ERR_INVALID, "theta_cap must be in (0, 4], defect >= 0");
+    if (!(theta_cap > 0.0) || theta_cap > 8.0 || !(defect >= 0.0))
+        return kh_fail(KH_ERR_INVALID, "theta_cap must be in (0, 8], defect >= 0");
     if (!(tol > 0.0)) tol = ldexp(1.0, -53);
     std::vector<double> c0(KH_MAX_DEGREE + 1), rows((size_t)(KH_MAX_DEGREE + 1) * KH_Q2_ROWS * 2);
     kh_build_real_spectrum_rows(tol, theta, c0.data(), rows.data(), ratios, theta_cap, defect);

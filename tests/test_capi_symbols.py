@@ -128,7 +128,7 @@ def test_series_tables_with_hermitian_defect():
     assert lib.kh_series_tables(1, 0.0, th_ref, ra_ref) == 0
     t0, r0 = tables(2.0, 0.0)
     assert np.array_equal(t0, np.array(th_ref)) and np.array_equal(r0, np.array(ra_ref).reshape(65, 65))
-    assert lib.kh_series_tables_defect(0.0, 5.0, 0.0, th_ref, ra_ref) == -1
+    assert lib.kh_series_tables_defect(0.0, 9.0, 0.0, th_ref, ra_ref) == -1
     defect = 3e-3
     tc, rc = tables(4.0, defect)
     assert np.all(np.diff(tc) >= 0)
@@ -176,7 +176,7 @@ def test_series_tables_defect_bound_at_the_corner_of_the_numerical_range():
     import numpy as np
 
     lib = _lib.load()
-    for cap in (2.0, 4.0):
+    for cap in (2.0, 4.0, 6.0):  # (register-tile kernels; cooperative kernels; sparse kernels)
         for defect in (0.05, 5e-3, 3e-4):
             th, ra = (ctypes.c_double * 65)(), (ctypes.c_double * (65 * 65))()
             assert lib.kh_series_tables_defect(0.0, cap, defect, th, ra) == 0
@@ -202,7 +202,8 @@ def test_series_tables_defect_bound_at_the_corner_of_the_numerical_range():
                     series += 2 * np.clongdouble((-1j) ** k) * np.longdouble(scipy.special.jv(k, theta)) * T_cur
                     T_prev, T_cur = T_cur, 2 * x * T_cur - T_prev
                 trunc = abs(complex(series - exact))
-                assert trunc < 4.0 * 2.0 ** -53, (cap, defect, m, theta, trunc)  # (jv is double precision: ~2e-16 of noise)
+                # (jv is double precision: ~2e-16 of noise, more where |T_k(x)| has grown: theta > 4)
+                assert trunc < (4.0 if theta <= 4.0 else 6.0) * 2.0 ** -53, (cap, defect, m, theta, trunc)
                 # (b) the tabulated polynomial itself: truncation + the rounding of its double-precision coefficient
                 # ratios, which grows like e^theta in the power form (the reason for the caps)
                 assert err < 2.0 ** -53 * (2.0 + 0.5 * np.exp(theta)), (cap, defect, m, theta, err)
