@@ -341,6 +341,11 @@ template <bool SO, bool ADJ, bool SINGLE = false>
 __global__ void __launch_bounds__(KH_Q2_THREADS)
 kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdateArgs u, KhExchange ex) {
     static_assert(!(SO && ADJ), "the second-order bra depends on the new state");
+#ifdef KH_Q2_NO_PREFETCH  // (A/B build)
+    constexpr bool PREFETCH = false;
+#else
+    constexpr bool PREFETCH = !SO;
+#endif
     if (u.n_dev != nullptr) {  // graph-replayed stepwise mode: interval index from device memory
         u.n_begin = *u.n_dev;
         u.n_end = u.n_begin + 1;
@@ -487,16 +492,20 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
                 kh_exchange_publish(ex, n, k, 1, lane, part);
 #endif
             }
-#ifndef KH_Q2_NO_PREFETCH
             // The P1 / P2 elements of the coming tile advance leave LDS now, while the sums cross the GPU (the
             // registers are free here: no product is in flight), instead of behind the exchange in front of the
-            // first phase (16 ds_read_b128 per lane = 128 KiB per workgroup and interval: ~1000 cycles of LDS pipe)
+            // first phase (16 ds_read_b128 per lane = 128 KiB per workgroup and interval: ~1000 cycles of LDS pipe).
+            // Not in the second-order instantiations: they carry phi_prev, sigma and the forward-side partial sums
+            // besides, and the 64 landing registers pushed 19-26 values into scratch -- one of them reloaded in every
+            // phase (second-order sweep 6.8 us per interval against 4.8 first order; without the prefetch: see
+            // docs/HISTORY.md R4.8)
+            if constexpr (PREFETCH) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                q1[j] = s.h0[j * KH_Q2_THREADS + tid];
-                q2[j] = s.p0[j * KH_Q2_THREADS + tid];
+                for (int j = 0; j < 8; ++j) {
+                    q1[j] = s.h0[j * KH_Q2_THREADS + tid];
+                    q2[j] = s.p0[j * KH_Q2_THREADS + tid];
+                }
             }
-#endif
             if constexpr (ADJ) {
                 if (n + 1 < nt - 1) adjoint_side();  // chib holds chi(t_{n+1})
             }
@@ -549,11 +558,10 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
             kh_q2_load_rows(p, s, m, tid);
             m_rows = m;
         }
-#ifndef KH_Q2_NO_PREFETCH
-        kh_q2_advance_reg(eps, eps_prev, h1, q1, q2, a, b);
-#else
-        kh_q2_advance(s, tid, eps, eps_prev, h1, a, b);
-#endif
+        if constexpr (PREFETCH)
+            kh_q2_advance_reg(eps, eps_prev, h1, q1, q2, a, b);
+        else
+            kh_q2_advance(s, tid, eps, eps_prev, h1, a, b);
         eps_prev = eps;
         stepw_next = kh_uniform(shape_next / lam);  // (under the LDS latency of the tile reads)
         cplx *fw_out = nullptr;
