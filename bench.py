@@ -464,6 +464,9 @@ def main():
             'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
             'coop16/mfma': ('kh_coop_forward_update', 'kh_coop_sweep_store'),
             'tile128/512': ('kh_tn_forward_update', 'kh_tn_sweep_store'),
+            # more objectives than the GPU keeps co-resident: the streaming update kernel (kh_tile64s.h); the plain sweeps
+            # take the objectives in turns
+            'tile64/stream': ('kh_stream_forward_update', 'kh_q2_sweep_store' if args.L == 1 else 'kh_tile_sweep_store'),
         }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
         if group is not None and not getattr(eng, '_p2p_used', False) and eng.kernel != 'generic':
             # per-interval launches (RCCL path) run the two-tile kernel, see krotov_hip.hip:launch_update
@@ -678,6 +681,8 @@ def main():
             out['distinct'] = leg(distinct=True, steps=3, warmup=1)
             # per-objective operators beyond the N <= 64 register tiles (kh_tilen.h: the generator in registers up to N = 128)
             out['N96'] = leg(N=96, steps=3, warmup=1)
+            # an ensemble that does not fit the GPU's co-resident workgroups: the operators are streamed (kh_tile64s.h)
+            out['K1024'] = leg(K=1024, steps=2, warmup=1)
         if not args.no_sparse:
             try:
                 out['sparse'] = sparse_leg()

@@ -128,8 +128,8 @@ typedef struct kh_problem_csr {
 
 int kh_engine_create_csr(const kh_problem_csr *problem, kh_engine **out);
 
-/* Which kernel family the engine selected: "tile64q2/512", "tile64/512", "tile64/256", "tile64/512 per interval",
- * "mini16/wave", "mini4/wave", "coop16/mfma", "tile128/512" (per-objective operators, 64 < N <= 128), "ell/csr"
+/* Which kernel family the engine selected: "tile64q2/512", "tile64/512", "tile64/256", "tile64/stream" (more objectives
+ * than stay co-resident: one launch, the operators streamed; KH_NO_STREAM=1: "tile64/512 per interval"), "mini16/wave", "mini4/wave", "coop16/mfma", "tile128/512" (per-objective operators, 64 < N <= 128), "ell/csr"
  * (sparse operators with the matrix in registers), "generic" or "generic/csr". */
 const char *kh_engine_kernel(const kh_engine *engine);
 

@@ -23,6 +23,7 @@
 #include "kh_common.h"
 #include "kh_generic.h"
 #include "kh_tile64.h"
+#include "kh_tile64s.h"
 #include "kh_tile64q2.h"
 #ifdef KH_WITH_Q4  // experiment build only (scripts/experiments/kh_tile64q4.h: 1024-thread plain sweep, measured 71 % slower)
 #include "../../scripts/experiments/kh_tile64q4.h"
@@ -136,6 +137,10 @@ struct kh_engine {
     bool coop_series = false;    // the cooperative kernels run the Chebyshev-form series (kh_common.h)
     bool use_q4 = false;         // KH_Q4=1 in a -DKH_WITH_Q4 build (experiment): plain sweeps with 1024-thread workgroups
     bool stepwise_only = false;  // more objectives than can be co-resident: kh_forward_update runs one launch per interval
+    // ... unless the streaming kernel takes them (kh_tile64s.h): ONE launch of stream_G co-resident workgroups, each
+    // walking through its objectives in every interval (one GPU; KH_NO_STREAM=1: the launch per interval, A/B)
+    bool stream = false;
+    int stream_G = 0;
     double *d_step_partial = nullptr;  // [L] the interval's sums on that path
     bool mini = false;           // kind q2, N <= 16, K <= 8: the one-wave-per-objective kernels (kh_mini.h)
     bool quad = false;           // mini with N <= 4, K <= 4: the whole problem in one wave
@@ -204,13 +209,13 @@ static int check_residency(const kh_engine *e, const void *func, int threads, si
     return KH_OK;
 }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.5 (gfx950; tile64q2, tile64, mini16, mini4, coop16/mfma, ell/csr, tile128, generic, generic/csr kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.5 (gfx950; tile64q2, tile64, tile64/stream, mini16, mini4, coop16/mfma, ell/csr, tile128, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
     switch (e->kind) {
         case KIND_TILE_RPT2: return "tile64/256";
-        case KIND_TILE_RPT1: return e->stepwise_only ? "tile64/512 per interval" : "tile64/512";
+        case KIND_TILE_RPT1: return e->stepwise_only ? (e->stream ? "tile64/stream" : "tile64/512 per interval") : "tile64/512";
         case KIND_TILE_Q2: return e->mini ? (e->quad ? "mini4/wave" : "mini16/wave") : "tile64q2/512";
         case KIND_COOP: return "coop16/mfma";
         case KIND_ELL: return "ell/csr";
@@ -715,6 +720,15 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         e->kind = KIND_TILE_RPT1;
         e->grid_update = e->K;
         e->stepwise_only = true;
+        // one workgroup per CU; as few workgroups as give everybody the same number of objectives (K = 384, two controls:
+        // 192 x 2 in 23.9 us per interval against 128 x 2 + 128 x 1 in 24.5)
+        int G = e->num_cus < 64 * KH_GATHER_CHUNKS ? e->num_cus : 64 * KH_GATHER_CHUNKS;
+        if (e->K > G) G = (e->K + (e->K + G - 1) / G - 1) / ((e->K + G - 1) / G);
+        if (const char *g = getenv("KH_STREAM_G"))  // testing
+            if (atoi(g) >= 1 && atoi(g) <= G) G = atoi(g);
+        if (G > e->K) G = e->K;
+        e->stream_G = G;
+        e->stream = (long long)G * KH_STREAM_MMAX >= e->K && !(getenv("KH_NO_STREAM") && atoi(getenv("KH_NO_STREAM")));
     }
     if (tile_ok && !(force && strcmp(force, "generic") == 0)) {
         // two waves per SIMD are needed to keep the fp64 FMA pipe issuing back to back
@@ -1455,7 +1469,26 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     // plain tile kernel (2 tiles) there -- measured 39 vs ~20 us per interval.
     const bool stepwise = !u.internal_exchange;
     int rc = KH_OK;
-    if (e->kind == KIND_TILE_Q2 && e->quad && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
+    if (e->stream && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
+        KhExchange exs = ex;
+        exs.G = e->stream_G;
+        exs.world = 1;
+        const dim3 g(e->stream_G), b(512);
+        const bool so = u.sigma != nullptr;
+#define KH_STREAM_UPDATE_N(LT, N64)                                                                                \
+    (so ? launch_persistent(e, kh_stream_forward_update<LT, true, N64>, g, b, 0, st, p, u, exs)                   \
+        : launch_persistent(e, kh_stream_forward_update<LT, false, N64>, g, b, 0, st, p, u, exs))
+#define KH_STREAM_UPDATE(LT) (e->N == KH_TILE_N ? KH_STREAM_UPDATE_N(LT, true) : KH_STREAM_UPDATE_N(LT, false))
+        switch (e->L) {
+            case 1: rc = KH_STREAM_UPDATE(1); break;
+            case 2: rc = KH_STREAM_UPDATE(2); break;
+            case 3: rc = KH_STREAM_UPDATE(3); break;
+            case 4: rc = KH_STREAM_UPDATE(4); break;
+            default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");
+        }
+#undef KH_STREAM_UPDATE
+#undef KH_STREAM_UPDATE_N
+    } else if (e->kind == KIND_TILE_Q2 && e->quad && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
         if (u.sigma != nullptr)
             kh_quad_forward_update<true><<<1, 64, 0, st>>>(p, e->d_sq_fw, u, ex);
         else
@@ -1585,7 +1618,7 @@ extern "C" int kh_forward_update(kh_engine *e, const kh_cdouble *chi_store_dev, 
     if (e->L < 1) return kh_fail(KH_ERR_INVALID, "no controls to update");
     if (opt_dev == guess_dev) return kh_fail(KH_ERR_INVALID, "opt_dev must not alias guess_dev");
     hipStream_t st = (hipStream_t)stream;
-    if (e->stepwise_only) {
+    if (e->stepwise_only && !e->stream) {
         // one launch per interval; on one GPU the "all-reduced" sums are the local ones (kh_reduce_partials has
         // summed the workgroups' pieces in a fixed order)
         KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));

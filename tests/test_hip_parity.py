@@ -42,9 +42,11 @@ SMALL = {
     # more objectives than CUs: two 256-thread workgroups per CU
     'c5_k300': lambda: configs.config_c5(K=300, N=16, nt=21),
     # more objectives than can be co-resident (one control: > 2 per CU; several controls: > 1 per CU): the update
-    # sweep runs the register-tile kernel with one launch per interval
+    # sweep runs the streaming register-tile kernel (kh_tile64s.h: every workgroup walks through several objectives
+    # per interval; 600 = 512 + 88: some workgroups own one objective, some two; 1100 with three controls: five and four)
     'c5_k600': lambda: configs.config_c5(K=600, N=8, nt=16),
     'c5_k300_L2': lambda: configs.config_c5(K=300, N=12, nt=16, L=2, distinct=True),
+    'c5_k1100_L3': lambda: configs.config_c5(K=1100, N=6, nt=9, L=3),
     # objectives sharing one operator list, N > 64: the cooperative matrix-core kernels
     'c4_d9': lambda: configs.config_c4(d=9, nt=41, n_logical=2),
     'c4_d10_k9': lambda: configs.config_c4(d=10, nt=21, n_logical=3),
@@ -99,7 +101,7 @@ def test_sweeps_match_oracle(name):
     quad = small and spec.N <= 4 and spec.K <= 4
     assert (eng.kernel == 'mini4/wave') == quad and (eng.kernel == 'mini16/wave') == (small and not quad)
     assert (eng.kernel == 'tile64/256') == (name == 'c5_k300')
-    assert (eng.kernel == 'tile64/512 per interval') == (name in ('c5_k600', 'c5_k300_L2'))
+    assert (eng.kernel == 'tile64/stream') == (name in ('c5_k600', 'c5_k300_L2', 'c5_k1100_L3'))
     assert (eng.kernel == 'coop16/mfma') == (name.startswith('c4_d') and spec.N > 64 or name.startswith('shared'))
     assert (eng.kernel == 'tile128/512') == (name in ('c5_n80', 'c5_n100', 'c5_n128'))
     eng.close()
@@ -368,7 +370,7 @@ def test_objective_propagate_on_device():
 SECOND_ORDER_CASES = [
     ('c3', None), ('c5_n16', None), ('c3', 'mini'), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
     ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c5_n80', 'generic'), ('c5_n100', None), ('c4_d9', 'tilen'), ('c2l', None),
-    ('lindblad', 'sparse'), ('c5_n12_L3', 'sparse'),
+    ('lindblad', 'sparse'), ('c5_n12_L3', 'sparse'), ('c5_k600', None), ('c5_k300_L2', None),
     ('c4_d9', None), ('shared_n96_L2', None), ('c3', 'coop'), ('shared_n96_L2', 'coop16cols'), ('shared_n96_L2', 'coop2cols'), ('c4_d9', 'coop2cols'),
 ]
 
@@ -406,6 +408,9 @@ def test_second_order_update_sweep(name, kernel, monkeypatch):
         # problem stays well conditioned)
         norms *= 0.02
         sigma_vals *= 1e-3
+    if name.startswith('c5_k'):  # (hundreds of objectives add up: same reason)
+        norms *= 8.0 / spec.K
+        sigma_vals *= 8.0 / spec.K
     ref_chi = ko.backward_sweep(prob, chi_T, gp)
     chi = eng.backward(chi_T, pulses)
     ref_opt, ref_psi, ref_ga, ref_store = ko.forward_update_sweep(
@@ -863,14 +868,18 @@ def test_edge_cases(monkeypatch):
 
     rng = np.random.default_rng(5)
     # non-uniform dt, control absent from one objective, more objectives than CUs: 300 -> two 256-thread
-    # workgroups per CU (register tiles), 600 -> the register-tile kernel with one launch per interval, or
-    # (KH_NO_STEPWISE=1) the generic kernels' persistent loop over objectives
+    # workgroups per CU (register tiles), 600 -> the streaming register-tile kernel (kh_tile64s.h), or (KH_NO_STREAM=1) the
+    # register-tile kernel with one launch per interval, or (KH_NO_STEPWISE=1) the generic kernels' persistent loop
     # (the plain sweeps of such engines run kh_q2_sweep_store, objectives in turns; the second K = 300 case keeps the
     # update sweep's own family for them: KH_Q2_STORE=0)
-    for K, kernel, q2_store in ((300, 'tile64/256', True), (300, 'tile64/256', False), (600, 'tile64/512 per interval', True),
-                                (600, 'generic', True)):
+    for K, kernel, q2_store in ((300, 'tile64/256', True), (300, 'tile64/256', False), (600, 'tile64/stream', True),
+                                (600, 'tile64/512 per interval', True), (600, 'generic', True)):
         if kernel == 'generic':
             monkeypatch.setenv('KH_NO_STEPWISE', '1')
+        if kernel == 'tile64/512 per interval':
+            monkeypatch.setenv('KH_NO_STREAM', '1')
+        else:
+            monkeypatch.delenv('KH_NO_STREAM', raising=False)
         if q2_store:
             monkeypatch.delenv('KH_Q2_STORE', raising=False)
         else:
@@ -1108,7 +1117,7 @@ def test_two_ranks_sharded_on_one_gpu(case):
     for _, pulses, tau, used_p2p, kernel in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
-        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/512 per interval',
+        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/stream',
                           'n80': 'tile128/512', 'sparse': 'ell/csr'}.get(case, 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
     # the path this test is here for: the sums crossed the ranks inside the persistent kernels, through the
