@@ -1615,7 +1615,7 @@ def test_bench_self_launches_two_ranks(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # (--K 128: the two ranks' workgroups must be resident on the ONE GPU at the same time -- 2 x 128 fill it)
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--no-cpu-baseline', '--nt', '401', '--K', '128']
+           '--no-cpu-baseline', '--nt', '201', '--K', '128']
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
@@ -1650,7 +1650,7 @@ def test_bench_gpus_8_dry_run_on_one_gpu(tmp_path):
     env.pop('KH_DIST_BACKEND', None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
-           '--no-cpu-baseline', '--nt', '201', '--K', '32', '--no-config4']
+           '--no-cpu-baseline', '--nt', '101', '--K', '32', '--no-config4']
     t0 = time.time()
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     wall = time.time() - t0
