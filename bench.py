@@ -491,7 +491,9 @@ def main():
             out = {
                 'metric': 'state*timestep propagations/s (Krotov iterations/s in iterations_per_sec), ' +
                           ('16-objective N=400 Liouvillian (variant)' if args.workload == 'c4' else
-                           '256-objective N=64 ensemble'),
+                           '256-objective N=64 ensemble' +
+                           (' per GPU (weak scaling: %d objectives in total)' % K_total
+                            if world > 1 and scaling == 'weak' else '')),
                 'value': props / elapsed,
                 'unit': 'props/s',
                 'iterations_per_sec': args.steps / elapsed,
