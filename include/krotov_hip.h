@@ -315,6 +315,14 @@ int kh_ell_layout(int32_t N, int32_t n_ops, const kh_csr *ops_host, int32_t *E, 
  * tests/test_hip_parity.py::test_update_sweep_next_to_a_busy_stream. */
 int kh_debug_occupy(kh_engine *engine, int32_t workgroups, double milliseconds, void *stream);
 
+/* Test hook (no counterpart in the reference): the sweep-kernel template instantiations of the library, one name per
+ * line ("kh_q2_forward_update<false, true, true>").  which = 1: every instantiation some dispatch can select (host
+ * only, no GPU needed); which = 0: those this process has launched so far.  Writes at most cap - 1 characters and a
+ * terminating 0 into buf (may be NULL); returns the buffer size the whole list needs.  With the environment variable
+ * KH_LAUNCH_LOG=<file> every process also appends an instantiation's name to that file at its first launch:
+ * tests/test_zz_kernel_coverage.py fails when an instantiation was never launched by an oracle-comparing test. */
+int kh_debug_launched(int32_t which, char *buf, int32_t cap);
+
 #ifdef __cplusplus
 }
 #endif

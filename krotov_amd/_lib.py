@@ -87,6 +87,7 @@ SYMBOLS = {
     'kh_check': (ctypes.c_int, [_P]),
     'kh_last_stats': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double)]),
     'kh_debug_occupy': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_double, _P]),
+    'kh_debug_launched': (ctypes.c_int, [ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]),
     'kh_series_tables': (ctypes.c_int, [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double)]),
     'kh_series_tables_defect': (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_double,
@@ -123,6 +124,17 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def kernel_instantiations(launched_only=False):
+    """Names of the sweep-kernel template instantiations some dispatch of the library can select (``kh_debug_launched``;
+    needs no GPU), or of those this process has launched so far."""
+    lib = load()
+    which = 0 if launched_only else 1
+    size = lib.kh_debug_launched(which, None, 0)
+    buf = ctypes.create_string_buffer(size)
+    lib.kh_debug_launched(which, buf, size)
+    return [line for line in buf.value.decode().split('\n') if line]
 
 
 class KrotovHipError(RuntimeError):

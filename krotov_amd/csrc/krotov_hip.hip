@@ -5,6 +5,9 @@
 // registers) and kh_generic.h (any N).  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <cxxabi.h>
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +38,7 @@
 #include "kh_mini.h"
 #include "kh_ell.h"
 #include "kh_tilen.h"
+#include "kh_ens.h"
 
 static thread_local std::string g_last_error;
 
@@ -142,6 +146,13 @@ struct kh_engine {
     bool stream = false;
     int stream_G = 0;
     double *d_step_partial = nullptr;  // [L] the interval's sums on that path
+    // ensembles (kh_ens.h): every objective's operator list is (H0, s_k H1) with one H0 and one H1 -- the single-launch
+    // update sweep then runs on the matrix cores with 2 ens_ncg objectives per workgroup, whatever `kind` says (which
+    // still serves the plain sweeps and the per-interval form)
+    bool ens = false;
+    int ens_ncg = 0, ens_G = 0;
+    const cplx *ens_H0 = nullptr, *ens_H1 = nullptr;
+    double *d_ens_scale = nullptr;     // [K]
     bool mini = false;           // kind q2, N <= 16, K <= 8: the one-wave-per-objective kernels (kh_mini.h)
     bool quad = false;           // mini with N <= 4, K <= 4: the whole problem in one wave
     double *d_q2_theta = nullptr, *d_q2_c0 = nullptr, *d_q2_rows = nullptr, *d_ratios = nullptr;  // series tables of the register-tile kernels
@@ -174,18 +185,74 @@ static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
 // partial start, which the bounded in-kernel waits turn into KH_ERR_TIMEOUT and the caller into a repeat of the
 // sweep with one launch per interval (krotov_amd/optimize.py).
 // KH_COOP_LAUNCH=0 keeps plain launches (A/B timing: a cooperative launch costs ~15-20 us of host time).
-template <class... Params, class... Args>
-static int launch_persistent(const kh_engine *e, void (*kernel)(Params...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
-                             Args... args) {
+// ---- which sweep-kernel instantiations exist and which have been launched (kh_debug_launched) ----
+// Every launch of a sweep kernel goes through launch_plain<Kernel> / launch_persistent<Kernel>; naming the kernel as a
+// template argument instantiates KhKernelTag<Kernel>, whose static member registers the instantiation when the library
+// is loaded: the registry is exactly the set of instantiations some dispatch can select.
+struct KhKernelRecord {
+    std::string name;
+    bool launched = false;
+};
+static std::vector<KhKernelRecord> &kh_kernel_registry() {
+    static std::vector<KhKernelRecord> reg;
+    return reg;
+}
+static int kh_register_kernel(const void *host_stub) {
+    // the host-side launch stub's symbol, demangled: "void __device_stub__kh_q2_forward_update<false, true, true>(KhSweepArgs, ...)"
+    std::string s = "?";
+    Dl_info info;
+    if (dladdr(host_stub, &info) != 0 && info.dli_sname != nullptr) {
+        int status = 0;
+        char *dem = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &status);
+        s = (status == 0 && dem != nullptr) ? dem : info.dli_sname;
+        free(dem);
+        if (s.compare(0, 5, "void ") == 0) s = s.substr(5);
+        const size_t stub = s.find("__device_stub__");
+        if (stub != std::string::npos) s.erase(stub, 15);
+        // cut the parameter list: the '(' that closes the name (template arguments hold no parentheses here)
+        const size_t paren = s.find('(');
+        if (paren != std::string::npos) s = s.substr(0, paren);
+    }
+    kh_kernel_registry().push_back({s, false});
+    return (int)kh_kernel_registry().size() - 1;
+}
+template <auto Kernel>
+struct KhKernelTag {
+    static inline const int index = kh_register_kernel((const void *)Kernel);
+};
+static void kh_note_launch(int index) {
+    KhKernelRecord &rec = kh_kernel_registry()[index];
+    if (rec.launched) return;
+    rec.launched = true;
+    if (const char *path = getenv("KH_LAUNCH_LOG")) {  // (tests: one line per instantiation and process, appended)
+        if (FILE *f = fopen(path, "a")) {
+            fprintf(f, "%s\n", rec.name.c_str());
+            fclose(f);
+        }
+    }
+}
+template <class... P>
+static std::tuple<P...> kh_param_tuple(void (*)(P...));
+
+template <auto Kernel, class... Args>
+static void launch_plain(dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    kh_note_launch(KhKernelTag<Kernel>::index);
+    hipLaunchKernelGGL(Kernel, grid, block, lds, st, args...);
+}
+
+template <auto Kernel, class... Args>
+static int launch_persistent(const kh_engine *e, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    kh_note_launch(KhKernelTag<Kernel>::index);
     if (!e->coop_launch || grid.x * grid.y * grid.z == 1) {
-        hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+        hipLaunchKernelGGL(Kernel, grid, block, lds, st, args...);
         return KH_OK;
     }
-    std::tuple<Params...> packed(args...);
-    void *ptrs[sizeof...(Params)];
+    decltype(kh_param_tuple(Kernel)) packed(args...);
+    constexpr size_t NP = std::tuple_size<decltype(packed)>::value;
+    void *ptrs[NP];
     int i = 0;
     std::apply([&](auto &...a) { ((ptrs[i++] = (void *)&a), ...); }, packed);
-    const hipError_t err = hipLaunchCooperativeKernel((const void *)kernel, grid, block, ptrs, (unsigned int)lds, st);
+    const hipError_t err = hipLaunchCooperativeKernel((const void *)Kernel, grid, block, ptrs, (unsigned int)lds, st);
     if (err == hipErrorCooperativeLaunchTooLarge) {
         (void)hipGetLastError();
         return kh_fail(KH_ERR_UNSUPPORTED, "the update sweep's %u workgroups cannot all be resident on this device",
@@ -209,10 +276,11 @@ static int check_residency(const kh_engine *e, const void *func, int threads, si
     return KH_OK;
 }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.5 (gfx950; tile64q2, tile64, tile64/stream, mini16, mini4, coop16/mfma, ell/csr, tile128, generic, generic/csr kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.6 (gfx950; tile64q2, tile64, tile64/stream, ens64/mfma, mini16, mini4, coop16/mfma, ell/csr, tile128, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
+    if (e->ens) return "ens64/mfma";
     switch (e->kind) {
         case KIND_TILE_RPT2: return "tile64/256";
         case KIND_TILE_RPT1: return e->stepwise_only ? (e->stream ? "tile64/stream" : "tile64/512 per interval") : "tile64/512";
@@ -290,6 +358,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_wg_partial);
     (void)hipFree(e->d_step_partial);
+    (void)hipFree(e->d_ens_scale);
     (void)hipFree(e->d_coop_vbuf);
     (void)hipFree(e->d_coop_xcc);
     (void)hipFree(e->d_coop_adj_nz);
@@ -1075,6 +1144,74 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         }
     }
 
+    // ---- ensembles (kh_ens.h): one drift, control operators equal up to a real scale, N <= 64, one control, more
+    // objectives than the register-tile kernels keep resident with their operators in registers.  KH_ENS=0: off;
+    // KH_ENS=1: for any K (testing); KH_ENS_MINK: smallest K that takes it; KH_ENS_NCG: column groups (testing)
+    {
+        const char *ens_env = getenv("KH_ENS");
+        const int ens_mode = ens_env ? atoi(ens_env) : -1;
+        int min_k = 513;
+        if (const char *d = getenv("KH_ENS_MINK")) min_k = atoi(d);
+        const bool want = ens_mode == 1 || (ens_mode != 0 && force == nullptr && e->K >= min_k);
+        if (want && csr_fw == nullptr && e->N <= KH_TILE_N && e->L == 1 && fw[1] != nullptr) {
+            int ncg = 0;
+            for (int c = 1; c <= KH_ENS_MAXCG; c *= 2)
+                if ((e->K + 2 * c - 1) / (2 * c) <= max_wgs) {
+                    ncg = c;
+                    break;
+                }
+            if (const char *d = getenv("KH_ENS_NCG")) {
+                const int c = atoi(d);
+                if ((c == 1 || c == 2 || c == 4 || c == 8) && (e->K + 2 * c - 1) / (2 * c) <= max_wgs) ncg = c;
+            }
+            if (ncg > 0) {
+                // reference element: the largest component of objective 0's control operator
+                std::vector<cplx> ref((size_t)e->N * e->N);
+                KH_HIP_E(hipMemcpy(ref.data(), fw[1], sizeof(cplx) * ref.size(), hipMemcpyDeviceToHost));
+                int ref_idx = 0, ref_comp = 0;
+                double best = 0.0;
+                for (size_t i = 0; i < ref.size(); ++i) {
+                    if (fabs(ref[i].x) > best) best = fabs(ref[i].x), ref_idx = (int)i, ref_comp = 0;
+                    if (fabs(ref[i].y) > best) best = fabs(ref[i].y), ref_idx = (int)i, ref_comp = 1;
+                }
+                if (best > 0.0) {
+                    int *d_flags = nullptr, flags[2] = {1, 1};
+                    KH_HIP_E(hipMalloc(&e->d_ens_scale, sizeof(double) * e->K));
+                    KH_HIP_E(hipMalloc(&d_flags, sizeof(flags)));
+                    hipError_t err = hipMemset(d_flags, 0, sizeof(flags));
+                    if (err == hipSuccess) {
+                        kh_ens_detect_kernel<<<e->K, 256>>>(e->d_ops_fw, e->K, e->N, ref_idx, ref_comp, e->d_ens_scale, d_flags);
+                        err = hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost);
+                    }
+                    (void)hipFree(d_flags);
+                    KH_HIP_E(err);
+                    if (flags[0] == 0 && flags[1] == 0) {
+                        e->ens = true;
+                        e->ens_ncg = ncg;
+                        e->ens_G = (e->K + 2 * ncg - 1) / (2 * ncg);
+                        e->ens_H0 = fw[0];
+                        e->ens_H1 = fw[1];
+                    }
+                }
+            }
+        }
+        if (e->ens) {  // all ens_G workgroups resident at once?  (as the q2 path asks for its instantiations)
+            const void *forms[2] = {nullptr, nullptr};
+            switch (e->ens_ncg) {
+                case 1: forms[0] = (const void *)kh_ens_forward_update<1, false>, forms[1] = (const void *)kh_ens_forward_update<1, true>; break;
+                case 2: forms[0] = (const void *)kh_ens_forward_update<2, false>, forms[1] = (const void *)kh_ens_forward_update<2, true>; break;
+                case 4: forms[0] = (const void *)kh_ens_forward_update<4, false>, forms[1] = (const void *)kh_ens_forward_update<4, true>; break;
+                default: forms[0] = (const void *)kh_ens_forward_update<8, false>, forms[1] = (const void *)kh_ens_forward_update<8, true>; break;
+            }
+            int rc = KH_OK;
+            for (const void *f : forms) {
+                if (rc == KH_OK) rc = ensure_dynamic_lds(e, f, kh_ens_lds_bytes(e->ens_ncg));
+                if (rc == KH_OK) rc = check_residency(e, f, KH_ENS_THREADS, kh_ens_lds_bytes(e->ens_ncg), e->ens_G, "kh_ens_forward_update");
+            }
+            if (rc != KH_OK) e->ens = false;
+        }
+    }
+
     // ---- workspaces
     KH_HIP_E(hipMalloc(&e->d_phi, sizeof(cplx) * (size_t)e->K * e->N));
     const int Lx = e->L > 0 ? e->L : 1;
@@ -1140,7 +1277,7 @@ static int launch_tile_store(kh_engine *e, const KhSweepArgs &p, const double *p
     constexpr size_t lds = KhTileLds<RPT, LT>::bytes(KhTileLds<RPT, LT>::STORE);  // operator tiles parked in LDS
     const int rc = ensure_dynamic_lds(e, (const void *)kh_tile_sweep_store<RPT, LT>, lds);
     if (rc != KH_OK) return rc;
-    kh_tile_sweep_store<RPT, LT><<<e->K, 512 / RPT, lds, st>>>(p, pulses, in, store, out, direction);
+    launch_plain<kh_tile_sweep_store<RPT, LT>>(dim3(e->K), dim3(512 / RPT), lds, st, p, pulses, in, store, out, direction);
     return KH_OK;
 }
 
@@ -1213,7 +1350,7 @@ static int launch_c4_store(kh_engine *e, const KhSweepArgs &p, const double *pul
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
     return launch_coop_placed(e, [&](dim3 grid) {
-        return launch_persistent(e, kh_c4_sweep_store<MAXG>, grid, dim3(KH_C4_THREADS), lds, st, p, c4_args(e, direction < 0),
+        return launch_persistent<kh_c4_sweep_store<MAXG>>(e, grid, dim3(KH_C4_THREADS), lds, st, p, c4_args(e, direction < 0),
                                  exchange_args(e, true), pulses, in, store, out, direction);
     });
 }
@@ -1232,9 +1369,9 @@ static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *p
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
     return launch_coop_placed(e, [&](dim3 grid) {
         if (sq)
-            return launch_persistent(e, kh_coop_sweep_store<MAXKS, COLS, true>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
+            return launch_persistent<kh_coop_sweep_store<MAXKS, COLS, true>>(e, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
                                      coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
-        return launch_persistent(e, kh_coop_sweep_store<MAXKS, COLS, false>, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
+        return launch_persistent<kh_coop_sweep_store<MAXKS, COLS, false>>(e, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
                                  coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
     });
 }
@@ -1278,14 +1415,14 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
         const size_t lds = kh_coop_lds_bytes(e->coop_ks, COLS);
         const KhCoopArgs ca = coop_args(e, false);
         if (adj && ex.world == 1)
-            return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, false, true, true, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
-        if (adj) return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, false, true, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+            return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, true, true, false>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        if (adj) return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, true, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         if (u.sigma != nullptr && sq)
-            return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, true, false, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+            return launch_persistent<kh_coop_forward_update<MAXKS, COLS, true, false, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         if (u.sigma != nullptr)
-            return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, true, false, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
-        if (sq) return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, false, false, true>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
-        return launch_persistent(e, kh_coop_forward_update<MAXKS, COLS, false, false, false>, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+            return launch_persistent<kh_coop_forward_update<MAXKS, COLS, true, false, false>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        if (sq) return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, false, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, false, false>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
     });
 }
 
@@ -1296,21 +1433,21 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
     int rc = KH_OK;
     if (e->kind_store == KIND_TILE_Q2 && e->quad) {
-        kh_quad_sweep_store<<<1, 64, 0, st>>>(p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
+        launch_plain<kh_quad_sweep_store>(dim3(1), dim3(64), 0, st, p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
     } else if (e->kind_store == KIND_TILE_Q2 && e->mini) {
-        kh_mini_sweep_store<<<e->K, 64, 0, st>>>(p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
+        launch_plain<kh_mini_sweep_store>(dim3(e->K), dim3(64), 0, st, p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
 #ifdef KH_WITH_Q4
     } else if (e->kind_store == KIND_TILE_Q2 && e->use_q4) {
         rc = ensure_dynamic_lds(e, (const void *)kh_q4_sweep_store, kh_q4_lds_bytes());
         if (rc == KH_OK)
-            kh_q4_sweep_store<<<e->K, KH_Q4_THREADS, kh_q4_lds_bytes(), st>>>(
+            launch_plain<kh_q4_sweep_store>(dim3(e->K), dim3(KH_Q4_THREADS), kh_q4_lds_bytes(), st, 
                 p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
 #endif
     } else if (e->kind_store == KIND_TILEN) {
         const cplx *const *tabs = backward ? e->d_tn_bw : e->d_tn_fw;
         const int grid = e->K < e->num_cus ? e->K : e->num_cus;
         const size_t lds = kh_tn_lds_bytes();
-#define KH_TN_STORE(EP, HR) kh_tn_sweep_store<EP, HR><<<grid, KH_TN_THREADS, lds, st>>>(p, tabs, pulses, in, store, out, direction)
+#define KH_TN_STORE(EP, HR) launch_plain<kh_tn_sweep_store<EP, HR>>(dim3(grid), dim3(KH_TN_THREADS), lds, st, p, tabs, pulses, in, store, out, direction)
         if (e->N <= 80) {
             if (e->tn_h1reg) KH_TN_STORE(20, true); else KH_TN_STORE(20, false);
         } else if (e->N <= 96) {
@@ -1326,7 +1463,7 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         const int grid = e->K < 4 * e->num_cus ? e->K : 4 * e->num_cus;
         const size_t lds = kh_ell_lds_bytes();
 #define KH_ELL_STORE(T, R, EM) \
-    kh_ell_sweep_store<T, R, EM><<<grid, T, lds, st>>>(p, ells, e->d_ell_off, e->d_ell_vals, pulses, in, store, out, direction)
+    launch_plain<kh_ell_sweep_store<T, R, EM>>(dim3(grid), dim3(T), lds, st, p, ells, e->d_ell_off, e->d_ell_vals, pulses, in, store, out, direction)
         // one row per lane where the rows' entries fit the register budget of that many waves (512 threads: 256 VGPRs,
         // 768: 168, 1024: 128), else two rows per lane of a 512-thread workgroup
         if (e->N <= 512) {
@@ -1345,7 +1482,7 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         }
 #undef KH_ELL_STORE
     } else if (e->kind_store == KIND_TILE_Q2) {
-        kh_q2_sweep_store<<<e->K, KH_Q2_THREADS, kh_q2_lds_bytes(), st>>>(
+        launch_plain<kh_q2_sweep_store>(dim3(e->K), dim3(KH_Q2_THREADS), kh_q2_lds_bytes(), st, 
             p, backward ? e->d_sq_bw : e->d_sq_fw, pulses, in, store, out, direction);
     } else if (e->kind_store == KIND_TILE_RPT2) {
         rc = dispatch_tile_store<2>(e, p, pulses, in, store, out, direction, st);
@@ -1381,7 +1518,7 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
     } else {
         const size_t lds = kh_gen_lds_bytes(e->N);
         rc = ensure_dynamic_lds(e, (const void *)kh_gen_sweep_store, lds);
-        if (rc == KH_OK) kh_gen_sweep_store<<<e->K, KH_GEN_THREADS, lds, st>>>(p, pulses, in, store, out, direction);
+        if (rc == KH_OK) launch_plain<kh_gen_sweep_store>(dim3(e->K), dim3(KH_GEN_THREADS), lds, st, p, pulses, in, store, out, direction);
     }
     if (rc != KH_OK) return rc;
     KH_HIP(hipGetLastError());
@@ -1416,9 +1553,9 @@ static int launch_tile_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     if (rc != KH_OK) return rc;
     if (!u.internal_exchange) {  // one launch per interval (sharded sweep): nothing waits inside the kernel
         if (u.sigma != nullptr)
-            kh_tile_forward_update<RPT, LT, true><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
+            launch_plain<kh_tile_forward_update<RPT, LT, true>>(dim3(e->K), dim3(512 / RPT), lds, st, p, u, ex);
         else
-            kh_tile_forward_update<RPT, LT, false><<<e->K, 512 / RPT, lds, st>>>(p, u, ex);
+            launch_plain<kh_tile_forward_update<RPT, LT, false>>(dim3(e->K), dim3(512 / RPT), lds, st, p, u, ex);
         return KH_OK;
     }
     KhExchange exl = ex;
@@ -1432,12 +1569,12 @@ static int launch_tile_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
         const int rcs = ensure_dynamic_lds(e, fs, lds);
         if (rcs != KH_OK) return rcs;
         if (u.sigma != nullptr)
-            return launch_persistent(e, kh_tile_forward_update<RPT, LT, true, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
-        return launch_persistent(e, kh_tile_forward_update<RPT, LT, false, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+            return launch_persistent<kh_tile_forward_update<RPT, LT, true, true>>(e, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+        return launch_persistent<kh_tile_forward_update<RPT, LT, false, true>>(e, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
     }
     if (u.sigma != nullptr)
-        return launch_persistent(e, kh_tile_forward_update<RPT, LT, true>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
-    return launch_persistent(e, kh_tile_forward_update<RPT, LT, false>, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+        return launch_persistent<kh_tile_forward_update<RPT, LT, true>>(e, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
+    return launch_persistent<kh_tile_forward_update<RPT, LT, false>>(e, dim3(e->K), dim3(512 / RPT), lds, st, p, u, exl);
 }
 
 static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
@@ -1469,15 +1606,35 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     // plain tile kernel (2 tiles) there -- measured 39 vs ~20 us per interval.
     const bool stepwise = !u.internal_exchange;
     int rc = KH_OK;
-    if (e->stream && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
+    if (e->ens && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
+        KhExchange exe = ex;
+        exe.G = e->ens_G;
+        KhEnsArgs en;
+        en.H0 = e->ens_H0;
+        en.H1 = e->ens_H1;
+        en.scale = e->d_ens_scale;
+        const dim3 g(e->ens_G), b(KH_ENS_THREADS);
+        const size_t lds = kh_ens_lds_bytes(e->ens_ncg);
+        const bool so = u.sigma != nullptr;
+#define KH_ENS_UPDATE(NCG)                                                                          \
+    (so ? launch_persistent<kh_ens_forward_update<NCG, true>>(e, g, b, lds, st, p, en, u, exe)      \
+        : launch_persistent<kh_ens_forward_update<NCG, false>>(e, g, b, lds, st, p, en, u, exe))
+        switch (e->ens_ncg) {
+            case 1: rc = KH_ENS_UPDATE(1); break;
+            case 2: rc = KH_ENS_UPDATE(2); break;
+            case 4: rc = KH_ENS_UPDATE(4); break;
+            default: rc = KH_ENS_UPDATE(8); break;
+        }
+#undef KH_ENS_UPDATE
+    } else if (e->stream && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
         KhExchange exs = ex;
         exs.G = e->stream_G;
         exs.world = 1;
         const dim3 g(e->stream_G), b(512);
         const bool so = u.sigma != nullptr;
 #define KH_STREAM_UPDATE_N(LT, N64)                                                                                \
-    (so ? launch_persistent(e, kh_stream_forward_update<LT, true, N64>, g, b, 0, st, p, u, exs)                   \
-        : launch_persistent(e, kh_stream_forward_update<LT, false, N64>, g, b, 0, st, p, u, exs))
+    (so ? launch_persistent<kh_stream_forward_update<LT, true, N64>>(e, g, b, 0, st, p, u, exs)                   \
+        : launch_persistent<kh_stream_forward_update<LT, false, N64>>(e, g, b, 0, st, p, u, exs))
 #define KH_STREAM_UPDATE(LT) (e->N == KH_TILE_N ? KH_STREAM_UPDATE_N(LT, true) : KH_STREAM_UPDATE_N(LT, false))
         switch (e->L) {
             case 1: rc = KH_STREAM_UPDATE(1); break;
@@ -1490,33 +1647,33 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
 #undef KH_STREAM_UPDATE_N
     } else if (e->kind == KIND_TILE_Q2 && e->quad && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
         if (u.sigma != nullptr)
-            kh_quad_forward_update<true><<<1, 64, 0, st>>>(p, e->d_sq_fw, u, ex);
+            launch_plain<kh_quad_forward_update<true>>(dim3(1), dim3(64), 0, st, p, e->d_sq_fw, u, ex);
         else
-            kh_quad_forward_update<false><<<1, 64, 0, st>>>(p, e->d_sq_fw, u, ex);
+            launch_plain<kh_quad_forward_update<false>>(dim3(1), dim3(64), 0, st, p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_TILE_Q2 && e->mini && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
         if (u.sigma != nullptr)
-            kh_mini_forward_update<true><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
+            launch_plain<kh_mini_forward_update<true>>(dim3(1), dim3(64 * e->K), 0, st, p, e->d_sq_fw, u, ex);
         else
-            kh_mini_forward_update<false><<<1, 64 * e->K, 0, st>>>(p, e->d_sq_fw, u, ex);
+            launch_plain<kh_mini_forward_update<false>>(dim3(1), dim3(64 * e->K), 0, st, p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_TILE_Q2 && !stepwise) {
         const dim3 g(e->K), b(KH_Q2_THREADS);
         // (KH_Q2_SINGLE=0: the instantiations with the cross-GPU stage on one GPU too -- A/B switch)
         const bool single = ex.world == 1 && e->q2_single;
         if (u.sigma != nullptr && single)
-            rc = launch_persistent(e, kh_q2_forward_update<true, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+            rc = launch_persistent<kh_q2_forward_update<true, false, true>>(e, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else if (u.sigma != nullptr)
-            rc = launch_persistent(e, kh_q2_forward_update<true, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+            rc = launch_persistent<kh_q2_forward_update<true, false>>(e, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else if (u.adj_sign != 0.0) {
             KhExchange exa = ex;
             exa.first_poll_delay = e->adj_poll_delay;
             if (single)  // (the default form on one GPU: an instantiation without the cross-GPU stage)
-                rc = launch_persistent(e, kh_q2_forward_update<false, true, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
+                rc = launch_persistent<kh_q2_forward_update<false, true, true>>(e, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
             else
-                rc = launch_persistent(e, kh_q2_forward_update<false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
+                rc = launch_persistent<kh_q2_forward_update<false, true>>(e, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, exa);
         } else if (single)
-            rc = launch_persistent(e, kh_q2_forward_update<false, false, true>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+            rc = launch_persistent<kh_q2_forward_update<false, false, true>>(e, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
         else
-            rc = launch_persistent(e, kh_q2_forward_update<false, false>, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
+            rc = launch_persistent<kh_q2_forward_update<false, false>>(e, g, b, kh_q2_lds_bytes(), st, p, e->d_sq_fw, u, ex);
     } else if (e->kind == KIND_COOP && !stepwise) {
         if (e->coop_cols == 2)
             rc = e->coop_ks <= 8 ? launch_coop_update<8, 2>(e, p, u, ex, st) : launch_coop_update<16, 2>(e, p, u, ex, st);
@@ -1529,8 +1686,8 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         const size_t lds = kh_tn_lds_bytes();
         const bool so = u.sigma != nullptr;
 #define KH_TN_UPDATE(EP, HR)                                                                                                  \
-    (so ? launch_persistent(e, kh_tn_forward_update<EP, true, HR>, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex) \
-        : launch_persistent(e, kh_tn_forward_update<EP, false, HR>, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex))
+    (so ? launch_persistent<kh_tn_forward_update<EP, true, HR>>(e, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex) \
+        : launch_persistent<kh_tn_forward_update<EP, false, HR>>(e, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex))
         if (e->N <= 80)
             rc = e->tn_h1reg ? KH_TN_UPDATE(20, true) : KH_TN_UPDATE(20, false);
         else if (e->N <= 96)
@@ -1543,9 +1700,9 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         const size_t lds = kh_ell_lds_bytes();
         const bool so = u.sigma != nullptr;
 #define KH_ELL_UPDATE(T, R, EM)                                                                                                  \
-    (so ? launch_persistent(e, kh_ell_forward_update<T, R, EM, true>, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,           \
+    (so ? launch_persistent<kh_ell_forward_update<T, R, EM, true>>(e, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,           \
                             (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex)                                       \
-        : launch_persistent(e, kh_ell_forward_update<T, R, EM, false>, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,          \
+        : launch_persistent<kh_ell_forward_update<T, R, EM, false>>(e, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,          \
                             (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex))
         if (e->N <= 512)
             rc = e->ell_E <= 8 ? KH_ELL_UPDATE(512, 1, 8) : e->ell_E <= 16 ? KH_ELL_UPDATE(512, 1, 16)
@@ -1570,9 +1727,9 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         const size_t lds = kh_gen_lds_bytes(e->N);
         rc = ensure_dynamic_lds(e, (const void *)kh_gen_forward_update, lds);
         if (rc == KH_OK && !u.internal_exchange)
-            kh_gen_forward_update<<<e->grid_update, KH_GEN_THREADS, lds, st>>>(p, u, ex);
+            launch_plain<kh_gen_forward_update>(dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, p, u, ex);
         else if (rc == KH_OK)
-            rc = launch_persistent(e, kh_gen_forward_update, dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, p, u, ex);
+            rc = launch_persistent<kh_gen_forward_update>(e, dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, p, u, ex);
     }
     if (rc != KH_OK) return rc;
     KH_HIP(hipGetLastError());
@@ -1618,7 +1775,7 @@ extern "C" int kh_forward_update(kh_engine *e, const kh_cdouble *chi_store_dev, 
     if (e->L < 1) return kh_fail(KH_ERR_INVALID, "no controls to update");
     if (opt_dev == guess_dev) return kh_fail(KH_ERR_INVALID, "opt_dev must not alias guess_dev");
     hipStream_t st = (hipStream_t)stream;
-    if (e->stepwise_only && !e->stream) {
+    if (e->stepwise_only && !e->stream && !e->ens) {
         // one launch per interval; on one GPU the "all-reduced" sums are the local ones (kh_reduce_partials has
         // summed the workgroups' pieces in a fixed order)
         KH_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(double) * 4, st));
@@ -1779,7 +1936,7 @@ extern "C" int kh_p2p_create_window(kh_engine *e, int32_t world, int32_t rank, u
     if (world < 1 || rank < 0 || rank >= world) return kh_fail(KH_ERR_INVALID, "bad world/rank %d/%d", rank, world);
     const int Lx = e->L > 0 ? e->L : 1;
     if (world * Lx * 2 > 64) return kh_fail(KH_ERR_UNSUPPORTED, "world * L = %d exceeds the 32 exchange lanes", world * Lx);
-    if (e->stepwise_only)  // (the caller falls back to kh_update_step + an all-reduce per interval)
+    if (e->stepwise_only && !e->ens)  // (the caller falls back to kh_update_step + an all-reduce per interval)
         return kh_fail(KH_ERR_UNSUPPORTED, "%d objectives per GPU are not co-resident: no in-kernel exchange", e->K);
     if (e->p2p_window != nullptr) return kh_fail(KH_ERR_INVALID, "window already created");
     e->p2p_world = world;
@@ -1950,6 +2107,18 @@ extern "C" int kh_debug_occupy(kh_engine *e, int32_t workgroups, double millisec
     kh_occupy_kernel<<<workgroups, 512, lds, (hipStream_t)stream>>>((long long)(milliseconds * 1e5), (int *)e->d_abort + 0);
     KH_HIP(hipGetLastError());
     return KH_OK;
+}
+
+extern "C" int kh_debug_launched(int32_t which, char *buf, int32_t cap) {
+    std::string out;
+    for (const KhKernelRecord &rec : kh_kernel_registry())
+        if (which != 0 || rec.launched) out += rec.name + "\n";
+    if (buf != nullptr && cap > 0) {
+        const size_t n = out.size() < (size_t)cap - 1 ? out.size() : (size_t)cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (int)out.size() + 1;
 }
 
 extern "C" int kh_last_stats(kh_engine *e, double stats[4]) {

@@ -44,7 +44,14 @@ SMALL = {
     # more objectives than can be co-resident (one control: > 2 per CU; several controls: > 1 per CU): the update
     # sweep runs the streaming register-tile kernel (kh_tile64s.h: every workgroup walks through several objectives
     # per interval; 600 = 512 + 88: some workgroups own one objective, some two; 1100 with three controls: five and four)
+    'c5_k600_distinct': lambda: configs.config_c5(K=600, N=8, nt=16, distinct=True),
+    # ... the same at N = 64 (the instantiations with the immediate-offset tile loader: what K = 1024 x N = 64 runs)
+    'c5_k520_n64_distinct': lambda: configs.config_c5(K=520, N=64, nt=6, distinct=True),
+    'c5_k264_n64_L2': lambda: configs.config_c5(K=264, N=64, nt=6, L=2, distinct=True),
+    # an ensemble proper (one drift, control operators mu_k H1: ensemble_objectives, objectives.py:1054-1094) with more
+    # objectives than CUs: the matrix-core ensemble kernel (kh_ens.h), four objectives per workgroup
     'c5_k600': lambda: configs.config_c5(K=600, N=8, nt=16),
+    'c5_k520_n64': lambda: configs.config_c5(K=520, N=64, nt=6),
     'c5_k300_L2': lambda: configs.config_c5(K=300, N=12, nt=16, L=2, distinct=True),
     'c5_k1100_L3': lambda: configs.config_c5(K=1100, N=6, nt=9, L=3),
     # objectives sharing one operator list, N > 64: the cooperative matrix-core kernels
@@ -96,12 +103,14 @@ def test_sweeps_match_oracle(name):
     assert np.abs(psi2.cpu().numpy() - ref_psi).max() < tol
     assert np.abs(ga2.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
     assert np.abs((opt2 - opt).cpu().numpy()).max() < 1e-12 * scale
-    assert eng.kernel.startswith(('tile64', 'mini')) == (spec.N <= 64)
+    assert eng.kernel.startswith(('tile64', 'mini', 'ens64')) == (spec.N <= 64)
     small = spec.N <= 16 and spec.K <= 8 and spec.L == 1
     quad = small and spec.N <= 4 and spec.K <= 4
     assert (eng.kernel == 'mini4/wave') == quad and (eng.kernel == 'mini16/wave') == (small and not quad)
     assert (eng.kernel == 'tile64/256') == (name == 'c5_k300')
-    assert (eng.kernel == 'tile64/stream') == (name in ('c5_k600', 'c5_k300_L2', 'c5_k1100_L3'))
+    assert (eng.kernel == 'tile64/stream') == (name in ('c5_k600_distinct', 'c5_k300_L2', 'c5_k1100_L3',
+                                                         'c5_k520_n64_distinct', 'c5_k264_n64_L2'))
+    assert (eng.kernel == 'ens64/mfma') == (name in ('c5_k600', 'c5_k520_n64'))
     assert (eng.kernel == 'coop16/mfma') == (name.startswith('c4_d') and spec.N > 64 or name.startswith('shared'))
     assert (eng.kernel == 'tile128/512') == (name in ('c5_n80', 'c5_n100', 'c5_n128'))
     eng.close()
@@ -367,10 +376,109 @@ def test_objective_propagate_on_device():
     assert np.abs(dev_l.expect[0] - host_e.expect[0]).max() < 1e-11
 
 
+ENS_CASES = {
+    # name: (spec, KH_ENS_NCG, second order)
+    'k40_n64_cg1': (lambda: configs.config_c5(K=40, N=64, nt=9), '1', False),
+    'k37_n33_cg2': (lambda: configs.config_c5(K=37, N=33, nt=9), '2', False),   # ragged: the last workgroup owns one objective
+    'k70_n64_cg4': (lambda: configs.config_c5(K=70, N=64, nt=7), '4', False),
+    'k100_n16_cg8': (lambda: configs.config_c5(K=100, N=16, nt=7), '8', False),
+    'k40_n64_cg1_so': (lambda: configs.config_c5(K=40, N=64, nt=9), '1', True),
+    'k37_n33_cg2_so': (lambda: configs.config_c5(K=37, N=33, nt=9), '2', True),
+    'k70_n64_cg4_so': (lambda: configs.config_c5(K=70, N=64, nt=7), '4', True),
+    'k100_n16_cg8_so': (lambda: configs.config_c5(K=100, N=16, nt=7), '8', True),
+    # Liouville space (mu = i dL/d eps, factor 1, non-Hermitian generator): three objectives under one operator list
+    'c2l_cg1': (lambda: configs.config_c2_liouville(nt=60), '1', False),
+    'c2l_cg2_so': (lambda: configs.config_c2_liouville(nt=60), '2', True),
+    # norms large enough for several sub-steps per interval
+    'k12_n20_substeps': (lambda: _c5_large_drift(), '2', False),
+}
+
+
+def _c5_large_drift():
+    spec = configs.config_c5(K=12, N=20, nt=9)
+    big = 6.0 * spec.H0[0]  # ||H0|| dt = 2.4: three sub-steps per interval
+    spec.H0 = [big] * spec.K
+    return spec
+
+
+@pytest.mark.parametrize('name', sorted(ENS_CASES))
+def test_ensemble_kernel_vs_oracle(name, monkeypatch):
+    """kh_ens_forward_update<NCG, SO> (objectives sharing a drift and a control operator up to a real scale: the update
+    sweep on the matrix cores, 2 NCG objectives per workgroup; optimize.py:444-508) vs the oracle, every column-group
+    count, first and second order, Hilbert and Liouville space, ragged last workgroup, sub-stepped intervals; and the
+    family the engine would have taken without it gives the same pulses."""
+    import torch
+
+    make, ncg, so = ENS_CASES[name]
+    spec = make()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    monkeypatch.setenv('KH_ENS', '1')
+    monkeypatch.setenv('KH_ENS_NCG', ncg)
+    eng = _engine(spec)
+    assert eng.kernel == 'ens64/mfma'
+    pulses = np.array(gp)
+    rng = np.random.default_rng(11)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = (0.2 + rng.random(spec.K)) * min(1.0, 8.0 / spec.K)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    chi = eng.backward(chi_T, pulses)
+    kw = {}
+    if so:
+        older = [p * (1.0 + 0.2 * rng.standard_normal(p.shape)) for p in gp]
+        _, prev = ko.forward_propagation(prob, older, store=True)
+        sigma_vals = -(1.0 + rng.random(len(spec.tlist) - 1)) * min(1.0, 8.0 / spec.K)
+        kw = dict(sigma_vals=sigma_vals, fw_prev=prev, store=True)
+        store = torch.full((spec.K, len(spec.tlist), spec.N), float('nan'), dtype=torch.complex128, device=eng.device)
+        eng.set_second_order(prev, store, sigma_vals)
+    ref = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam, **kw)
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    scale = max(1.0, np.abs(np.array(ref[0])).max())
+    assert np.abs(opt.cpu().numpy() - np.array(ref[0])).max() < 1e-12 * scale
+    assert np.abs(psi_T.cpu().numpy() - ref[1]).max() < 1e-12
+    assert np.abs(g_a.cpu().numpy() - ref[2]).max() < 1e-12 * max(1.0, np.abs(ref[2]).max())
+    if so:
+        assert np.abs(store.cpu().numpy() - ref[3]).max() < 1e-12
+    if name.endswith('substeps'):
+        assert eng.stats()['matvecs'] > 2 * 14 * spec.K * (len(spec.tlist) - 1)  # several sub-steps per interval
+    eng.close()
+    # the same sweep without the ensemble kernel
+    monkeypatch.setenv('KH_ENS', '0')
+    eng0 = _engine(spec)
+    assert eng0.kernel != 'ens64/mfma'
+    if so:
+        store0 = torch.empty_like(store)
+        eng0.set_second_order(prev, store0, sigma_vals)
+    opt0 = eng0.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))[0]
+    eng0.check()
+    assert np.abs((opt0 - opt).cpu().numpy()).max() < 1e-12 * scale
+    eng0.close()
+
+
+def test_ensemble_detection(monkeypatch):
+    """The ensemble kernel is taken only for operator lists (H0, s_k H1): a perturbed control operator or a second
+    drift leaves the engine with the streaming kernel, a drift that is an equal COPY still counts as shared."""
+    spec = configs.config_c5(K=520, N=8, nt=5)
+    assert _engine(spec).kernel == 'ens64/mfma'
+    spec.H0 = [h.copy() for h in spec.H0]  # equal content, distinct arrays
+    assert _engine(spec).kernel == 'ens64/mfma'
+    bad = configs.config_c5(K=520, N=8, nt=5)
+    bad.Hc[77] = [bad.Hc[77][0].copy()]
+    bad.Hc[77][0][3, 4] *= 1.0 + 1e-12
+    assert _engine(bad).kernel == 'tile64/stream'
+    bad = configs.config_c5(K=520, N=8, nt=5)
+    bad.H0[519] = bad.H0[519] + 1e-9 * np.eye(8)
+    assert _engine(bad).kernel == 'tile64/stream'
+    monkeypatch.setenv('KH_ENS', '0')
+    assert _engine(spec).kernel == 'tile64/stream'
+
+
 SECOND_ORDER_CASES = [
     ('c3', None), ('c5_n16', None), ('c3', 'mini'), ('c5_n64', None), ('c5_n64', 'tile512'), ('c5_n64', 'generic'), ('c5_n33', 'tile256'),
     ('c5_n64_L2', None), ('c5_n12_L3', None), ('c5_n80', None), ('c5_n80', 'generic'), ('c5_n100', None), ('c4_d9', 'tilen'), ('c2l', None),
-    ('lindblad', 'sparse'), ('c5_n12_L3', 'sparse'), ('c5_k600', None), ('c5_k300_L2', None),
+    ('lindblad', 'sparse'), ('c5_n12_L3', 'sparse'), ('c5_k600', None), ('c5_k300_L2', None), ('c5_k600_distinct', None),
+    ('c5_k264_n64_L2', None),
     ('c4_d9', None), ('shared_n96_L2', None), ('c3', 'coop'), ('shared_n96_L2', 'coop16cols'), ('shared_n96_L2', 'coop2cols'), ('c4_d9', 'coop2cols'),
 ]
 
