@@ -178,6 +178,16 @@ int kh_forward_update(kh_engine *engine, const kh_cdouble *chi_store_dev,
                       const double *lambda_dev, double *opt_dev,
                       kh_cdouble *psi_T_dev, double *g_a_dev, void *stream);
 
+/* The single-launch update sweep on at most `max_workgroups` workgroups (0: back to the engine's own choice).  What a
+ * caller does after kh_check returned KH_ERR_TIMEOUT -- co-tenants held compute units, the sweep's workgroups were not
+ * all resident at once -- before it falls back to one launch per interval: the register-tile families (N <= 64, 1..4
+ * controls) then run kh_stream_forward_update (every workgroup walks through several objectives per interval, about
+ * 2x the time at half the workgroups instead of 10x), ensembles run the matrix-core kernel with more objectives per
+ * workgroup.  KH_ERR_UNSUPPORTED for the other families, for sharded engines and below the smallest grid the kernels
+ * take (16 objectives per workgroup).  *chosen (may be NULL): the grid the next sweep will use (with 0: the engine's own).  No counterpart in the
+ * reference (its objectives are separate processes: parallelization.py:233-311). */
+int kh_set_update_workgroups(kh_engine *engine, int32_t max_workgroups, int32_t *chosen);
+
 /* Second-order Krotov update (optimize.py:434-443, 468-469, 492-500): the
  * following update sweeps add 0.5 sigma_n <phi_k(t_n) - fw_prev[k][n] | mu |
  * phi_k(t_n)> to every summand of the pulse update and store the propagated
@@ -250,6 +260,17 @@ int kh_p2p_open_peers(kh_engine *engine, const unsigned char *all_handles);
 int kh_p2p_selftest(kh_engine *engine, int32_t rounds, void *stream);
 int kh_p2p_disable(kh_engine *engine);
 
+/* Diagnostics of the cross-GPU exchange (no counterpart in the reference), for the first run on a real multi-GPU node:
+ *   out[0]  us per interval workgroup 0 of this rank waited for its own GPU's workgroups in the last sharded
+ *           single-launch update sweep (in-GPU gather),
+ *   out[1]  us per interval between publishing this GPU's sum into the peers' windows and holding every rank's sum
+ *           (the cross-GPU hop: xGMI stores + the slowest rank's lag),
+ *   out[2]  us per round of the last kh_p2p_selftest (publish -> all ranks' values read back, first round excluded),
+ *   out[3]  ranks.
+ * Kernels that run their own cross-GPU stage (one-wave, N <= 128 register-generator and sparse families) report 0 in
+ * out[0], out[1]. */
+int kh_p2p_stats(kh_engine *engine, double out[4]);
+
 /* tau_k = <target_k | psi_k(T)> (optimize.py:316-322, 502-508;
  * second_order.py:69-83).  targets_dev, psi_T_dev [K][N]; tau_dev [K]. */
 int kh_tau(kh_engine *engine, const kh_cdouble *targets_dev,
@@ -312,12 +333,13 @@ int kh_ell_layout(int32_t N, int32_t n_ops, const kh_csr *ops_host, int32_t *E, 
 /* Test hook (no counterpart in the reference): keep `workgroups` CUs busy for `milliseconds` on `stream` with a
  * kernel that does nothing but hold a CU's LDS -- the situation the single-launch update sweep must survive
  * (another stream of the process holding compute units while its workgroups need to be resident all at once).
- * tests/test_hip_parity.py::test_update_sweep_next_to_a_busy_stream. */
+ * tests/test_hip_parity.py::test_update_sweep_next_to_a_busy_stream.  The kernel leaves all-ones bit patterns (NaN as
+ * doubles) in the 128 KiB of LDS it held: test_kernels_do_not_read_uninitialised_lds runs the sweeps right behind it. */
 int kh_debug_occupy(kh_engine *engine, int32_t workgroups, double milliseconds, void *stream);
 
 /* Test hook (no counterpart in the reference): the sweep-kernel template instantiations of the library, one name per
  * line ("kh_q2_forward_update<false, true, true>").  which = 1: every instantiation some dispatch can select (host
- * only, no GPU needed); which = 0: those this process has launched so far.  Writes at most cap - 1 characters and a
+ * only, no GPU needed); which = 0: those this process has launched so far; which = 2: forget that list (returns 0).  Writes at most cap - 1 characters and a
  * terminating 0 into buf (may be NULL); returns the buffer size the whole list needs.  With the environment variable
  * KH_LAUNCH_LOG=<file> every process also appends an instantiation's name to that file at its first launch:
  * tests/test_zz_kernel_coverage.py fails when an instantiation was never launched by an oracle-comparing test. */

@@ -87,6 +87,8 @@ SYMBOLS = {
     'kh_check': (ctypes.c_int, [_P]),
     'kh_last_stats': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double)]),
     'kh_debug_occupy': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_double, _P]),
+    'kh_p2p_stats': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double)]),
+    'kh_set_update_workgroups': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     'kh_debug_launched': (ctypes.c_int, [ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]),
     'kh_series_tables': (ctypes.c_int, [ctypes.c_int32, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double)]),
@@ -124,6 +126,12 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def forget_launched_kernels():
+    """Empty the list ``kernel_instantiations(launched_only=True)`` reports (tests that check which instantiation a
+    case dispatches to)."""
+    load().kh_debug_launched(2, None, 0)
 
 
 def kernel_instantiations(launched_only=False):

@@ -371,6 +371,9 @@ struct KhExchange {
     int world, rank;
     unsigned int epoch_base;
     int fail_at;  // test hook (KH_P2P_FAIL_AT): this rank withholds its GPU's sum at that interval; < 0: never
+    // diagnostics of a sharded sweep (kh_p2p_stats): workgroup 0 adds the 100 MHz ticks it spent in the in-GPU gather to
+    // [0] and those between publishing its GPU's sum and holding all ranks' sums to [1], per interval; NULL: off
+    unsigned long long *wait_ticks;
 };
 
 // Called by (at least) the first 2*L lanes of one wave: one 8-byte store each.
@@ -599,11 +602,21 @@ __device__ __forceinline__ bool kh_exchange_collect(const KhExchange &ex, int n,
         return true;
     }
     const int parity = n & 1;
+    const bool timed = P2P && ex.world > 1 && wg == 0 && ex.wait_ticks != nullptr;  // (uniform; scalar clock reads)
+    long long t0 = 0;
+    if (timed) t0 = wall_clock64();
     if (!kh_gather<MAXL, CH>(ex, parity, L, (unsigned)(n + 1), lane, out)) return false;
     if (P2P && ex.world > 1) {
+        long long t1 = 0;
+        if (timed) t1 = wall_clock64();
         const unsigned int epoch = ex.epoch_base + (unsigned)(n + 1);
         if (wg == 0 && n != ex.fail_at) kh_p2p_publish(ex, parity, L, lane, out, epoch);
         if (!kh_p2p_gather<MAXL>(ex, parity, L, epoch, lane, out)) return false;
+        if (timed && lane == 0) {
+            const long long t2 = wall_clock64();
+            atomicAdd(ex.wait_ticks, (unsigned long long)(t1 - t0));
+            atomicAdd(ex.wait_ticks + 1, (unsigned long long)(t2 - t1));
+        }
     }
     return true;
 }

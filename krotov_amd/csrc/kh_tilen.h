@@ -168,6 +168,9 @@ kh_tn_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ tabs, const dou
     const int tid = threadIdx.x, row = tid >> 2, cg = tid & 3, N = p.N, L = p.L, nt = p.nt;
     const bool active = row < N, writer = active && cg == 0;
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.q2_theta[tid];
+    // columns N .. 127 of the term vectors meet zero matrix elements in kh_tn_row: they must be finite (0 * NaN would
+    // poison every row), and dynamic LDS holds whatever the previous kernel left there
+    if (tid >= N && tid < KH_TN_NMAX) s.buf[0][tid] = s.buf[1][tid] = c_make(0.0, 0.0);
     double matvecs = 0.0;
     int m_cur = -1;
     for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
@@ -238,6 +241,9 @@ kh_tn_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
     const double chi_norm = u.chi_norms[k];
     if (tid <= KH_MAX_DEGREE) s.deg[tid] = p.q2_theta[tid];
     if (tid < KH_MAX_L) s.g_a[tid] = 0.0;
+    // columns N .. 127 of the term vectors meet zero matrix elements in kh_tn_row: they must be finite (0 * NaN would
+    // poison every row), and dynamic LDS holds whatever the previous kernel left there
+    if (tid >= N && tid < KH_TN_NMAX) s.buf[0][tid] = s.buf[1][tid] = c_make(0.0, 0.0);
     cplx a[EPL], h1[H1REG ? EPL : 1];
     if constexpr (H1REG) kh_tn_load<EPL>(tab_k[1], tid, h1);
     cplx state = active ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);

@@ -110,6 +110,7 @@ struct kh_engine {
     cplx *d_phi = nullptr;            // [K][N]
     kh_u64 *d_slots = nullptr;        // [2][G][L][2]
     unsigned int *d_abort = nullptr;
+    unsigned long long *d_wait_ticks = nullptr;  // [4] kh_p2p_stats: in-GPU gather, cross-GPU wait (last sharded sweep); self-test ticks, rounds
     double *d_stats = nullptr;        // [4] (+ 64 trace stamps behind them in a KH_TIMING build)
     double *d_wg_partial = nullptr;   // [G][L]
     const double *guess_dev = nullptr;  // remembered by kh_update_begin
@@ -145,6 +146,8 @@ struct kh_engine {
     // walking through its objectives in every interval (one GPU; KH_NO_STREAM=1: the launch per interval, A/B)
     bool stream = false;
     int stream_G = 0;
+    int last_update_grid = 0;  // workgroups of the last single-launch update sweep where the ensemble / streaming kernels ran it
+    int reduced_G = 0;  // kh_set_update_workgroups: the single-launch update sweep on at most this many workgroups (0: off)
     double *d_step_partial = nullptr;  // [L] the interval's sums on that path
     // ensembles (kh_ens.h): every objective's operator list is (H0, s_k H1) with one H0 and one H1 -- the single-launch
     // update sweep then runs on the matrix cores with 2 ens_ncg objectives per workgroup, whatever `kind` says (which
@@ -163,6 +166,7 @@ struct kh_engine {
     bool coop_launch = true;     // KH_COOP_LAUNCH=0: plain launches instead of cooperative ones (A/B timing)
     bool q2_single = true;       // KH_Q2_SINGLE=0: the instantiations with the cross-GPU stage on one GPU too (A/B)
     bool tile_single = true;     // KH_TILE_SINGLE=0: the same for the one-term-per-phase kernels
+    bool coop_single = true;     // KH_COOP_SINGLE=0: the same for the cooperative kernels' adjoint-side form
     // fault injection for the sharded protocol (tests): rank KH_P2P_FAIL_RANK withholds its GPU's sum at interval
     // KH_P2P_FAIL_AT of its KH_P2P_FAIL_SWEEP-th update sweep through the peer windows (1-based; default 1)
     int p2p_fail_at = -1, p2p_fail_rank = 0, p2p_fail_sweep = 1, p2p_sweeps = 0;
@@ -192,6 +196,7 @@ static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
 struct KhKernelRecord {
     std::string name;
     bool launched = false;
+    bool logged = false;  // written to KH_LAUNCH_LOG by this process
 };
 static std::vector<KhKernelRecord> &kh_kernel_registry() {
     static std::vector<KhKernelRecord> reg;
@@ -213,7 +218,7 @@ static int kh_register_kernel(const void *host_stub) {
         const size_t paren = s.find('(');
         if (paren != std::string::npos) s = s.substr(0, paren);
     }
-    kh_kernel_registry().push_back({s, false});
+    kh_kernel_registry().push_back({s, false, false});
     return (int)kh_kernel_registry().size() - 1;
 }
 template <auto Kernel>
@@ -222,12 +227,16 @@ struct KhKernelTag {
 };
 static void kh_note_launch(int index) {
     KhKernelRecord &rec = kh_kernel_registry()[index];
-    if (rec.launched) return;
     rec.launched = true;
-    if (const char *path = getenv("KH_LAUNCH_LOG")) {  // (tests: one line per instantiation and process, appended)
+    if (rec.logged) return;
+    // (tests: one line per instantiation and process, appended; the variable is read at every launch so that a test
+    // session can switch the log on for its oracle-comparing tests only -- tests/conftest.py)
+    if (const char *path = getenv("KH_LAUNCH_LOG")) {
+        if (path[0] == 0) return;
         if (FILE *f = fopen(path, "a")) {
             fprintf(f, "%s\n", rec.name.c_str());
             fclose(f);
+            rec.logged = true;
         }
     }
 }
@@ -355,6 +364,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_phi);
     (void)hipFree(e->d_slots);
     (void)hipFree(e->d_abort);
+    (void)hipFree(e->d_wait_ticks);
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_wg_partial);
     (void)hipFree(e->d_step_partial);
@@ -753,6 +763,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     if (const char *d = getenv("KH_COOP_LAUNCH")) e->coop_launch = atoi(d) != 0;
     if (const char *d = getenv("KH_Q2_SINGLE")) e->q2_single = atoi(d) != 0;
     if (const char *d = getenv("KH_TILE_SINGLE")) e->tile_single = atoi(d) != 0;
+    if (const char *d = getenv("KH_COOP_SINGLE")) e->coop_single = atoi(d) != 0;
     if (const char *d = getenv("KH_P2P_FAIL_AT")) e->p2p_fail_at = atoi(d);
     if (const char *d = getenv("KH_P2P_FAIL_RANK")) e->p2p_fail_rank = atoi(d);
     if (const char *d = getenv("KH_P2P_FAIL_SWEEP")) e->p2p_fail_sweep = atoi(d);
@@ -1221,6 +1232,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     KH_HIP_E(hipMalloc(&e->d_slots, e->slots_bytes));
     KH_HIP_E(hipMalloc(&e->d_abort, 2 * sizeof(unsigned int)));  // [0] abort flag, [1] (KH_TIMING) polling rounds
     KH_HIP_E(hipMemset(e->d_abort, 0, 2 * sizeof(unsigned int)));
+    KH_HIP_E(hipMalloc(&e->d_wait_ticks, 4 * sizeof(unsigned long long)));
+    KH_HIP_E(hipMemset(e->d_wait_ticks, 0, 4 * sizeof(unsigned long long)));
     KH_HIP_E(hipMalloc(&e->d_stats, sizeof(double) * 68));
     KH_HIP_E(hipMemset(e->d_stats, 0, sizeof(double) * 68));
     KH_HIP_E(hipMalloc(&e->d_wg_partial, sizeof(double) * (size_t)e->grid_update * Lx));
@@ -1394,7 +1407,7 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     const bool sq = e->d_coop_sq_fw != nullptr;
     const void *func = u.sigma != nullptr ? (sq ? (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, true>
                                                 : (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, false>)
-                       : adj              ? (ex.world == 1 ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true, false>
+                       : adj              ? (ex.world == 1 && e->coop_single ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true, false>
                                                             : (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true>)
                        : sq               ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, false, true>
                                           : (const void *)kh_coop_forward_update<MAXKS, COLS, false, false, false>;
@@ -1414,7 +1427,7 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     return launch_coop_placed(e, [&](dim3 grid) {
         const size_t lds = kh_coop_lds_bytes(e->coop_ks, COLS);
         const KhCoopArgs ca = coop_args(e, false);
-        if (adj && ex.world == 1)
+        if (adj && ex.world == 1 && e->coop_single)
             return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, true, true, false>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         if (adj) return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, true, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         if (u.sigma != nullptr && sq)
@@ -1594,6 +1607,7 @@ static KhExchange exchange_args(const kh_engine *e, bool internal_exchange) {
     ex.epoch_base = e->p2p_epoch_base;
     ex.first_poll_delay = e->poll_delay;
     ex.fail_at = (ex.world > 1 && e->p2p_rank == e->p2p_fail_rank && e->p2p_sweeps + 1 == e->p2p_fail_sweep) ? e->p2p_fail_at : -1;
+    ex.wait_ticks = ex.world > 1 ? e->d_wait_ticks : nullptr;
     return ex;
 }
 
@@ -1601,36 +1615,48 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     const KhSweepArgs p = sweep_args(e, false);
     const KhExchange ex = exchange_args(e, u.internal_exchange != 0);
     if (u.internal_exchange) KH_HIP(hipMemsetAsync(e->d_slots, 0, e->slots_bytes, st));
+    if (u.internal_exchange && ex.world > 1) KH_HIP(hipMemsetAsync(e->d_wait_ticks, 0, 2 * sizeof(unsigned long long), st));
     // One launch per interval (sharded sweep): every launch re-stages its operator
     // tiles, so the q2 kernels (5 tiles, 320 KiB per objective) lose to the
     // plain tile kernel (2 tiles) there -- measured 39 vs ~20 us per interval.
     const bool stepwise = !u.internal_exchange;
     int rc = KH_OK;
-    if (e->ens && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
+    const bool whole = !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1;
+    e->last_update_grid = 0;
+    if (e->ens && whole) {
+        int ncg = e->ens_ncg, G = e->ens_G;
+        if (e->reduced_G > 0)  // fewer, wider workgroups (kh_set_update_workgroups)
+            while (G > e->reduced_G && ncg < KH_ENS_MAXCG) ncg *= 2, G = (e->K + 2 * ncg - 1) / (2 * ncg);
         KhExchange exe = ex;
-        exe.G = e->ens_G;
+        exe.G = G;
         KhEnsArgs en;
         en.H0 = e->ens_H0;
         en.H1 = e->ens_H1;
         en.scale = e->d_ens_scale;
-        const dim3 g(e->ens_G), b(KH_ENS_THREADS);
-        const size_t lds = kh_ens_lds_bytes(e->ens_ncg);
+        const dim3 g(G), b(KH_ENS_THREADS);
+        e->last_update_grid = G;
+        const size_t lds = kh_ens_lds_bytes(ncg);
         const bool so = u.sigma != nullptr;
 #define KH_ENS_UPDATE(NCG)                                                                          \
     (so ? launch_persistent<kh_ens_forward_update<NCG, true>>(e, g, b, lds, st, p, en, u, exe)      \
         : launch_persistent<kh_ens_forward_update<NCG, false>>(e, g, b, lds, st, p, en, u, exe))
-        switch (e->ens_ncg) {
+        switch (ncg) {
             case 1: rc = KH_ENS_UPDATE(1); break;
             case 2: rc = KH_ENS_UPDATE(2); break;
             case 4: rc = KH_ENS_UPDATE(4); break;
             default: rc = KH_ENS_UPDATE(8); break;
         }
 #undef KH_ENS_UPDATE
-    } else if (e->stream && !stepwise && u.n_begin == 0 && u.n_end == e->nt - 1) {
+    } else if ((e->stream || (e->reduced_G > 0 && e->reduced_G < e->grid_update && ex.world == 1)) && whole) {
+        // more objectives than co-resident workgroups -- or (kh_set_update_workgroups) fewer workgroups than the
+        // register-tile family of this engine would use: G workgroups walk through K / G objectives each
+        int G = e->stream ? e->stream_G : e->grid_update;
+        if (e->reduced_G > 0 && e->reduced_G < G) G = e->reduced_G;
         KhExchange exs = ex;
-        exs.G = e->stream_G;
+        exs.G = G;
         exs.world = 1;
-        const dim3 g(e->stream_G), b(512);
+        const dim3 g(G), b(512);
+        e->last_update_grid = G;
         const bool so = u.sigma != nullptr;
 #define KH_STREAM_UPDATE_N(LT, N64)                                                                                \
     (so ? launch_persistent<kh_stream_forward_update<LT, true, N64>>(e, g, b, 0, st, p, u, exs)                   \
@@ -1805,7 +1831,51 @@ extern "C" int kh_forward_update(kh_engine *e, const kh_cdouble *chi_store_dev, 
     }
     KH_HIP(hipMemcpyAsync(psi_T_dev, e->d_phi, sizeof(cplx) * (size_t)e->K * e->N, hipMemcpyDeviceToDevice, st));
     e->last_intervals = e->nt - 1;
-    e->last_wgs = e->grid_update;
+    e->last_wgs = e->last_update_grid > 0 ? e->last_update_grid : e->grid_update;
+    return KH_OK;
+}
+
+// Fewer workgroups for the single-launch update sweep: what a caller asks for after KH_ERR_TIMEOUT (co-tenants hold
+// compute units, so the sweep's workgroups were not all resident at once) before it gives up on the single launch.
+extern "C" int kh_set_update_workgroups(kh_engine *e, int32_t max_workgroups, int32_t *chosen) {
+    if (e == nullptr || max_workgroups < 0) return kh_fail(KH_ERR_INVALID, "bad argument");
+    if (chosen != nullptr) *chosen = e->ens ? e->ens_G : (e->stream ? e->stream_G : e->grid_update);
+    if (max_workgroups == 0) {
+        e->reduced_G = 0;
+        return KH_OK;
+    }
+    if (e->p2p_ready) return kh_fail(KH_ERR_UNSUPPORTED, "sharded sweeps keep their grid (all ranks must agree on the form)");
+    int G = 0;
+    if (e->ens) {
+        const int widest = (e->K + 2 * KH_ENS_MAXCG - 1) / (2 * KH_ENS_MAXCG);
+        if (max_workgroups < widest)
+            return kh_fail(KH_ERR_UNSUPPORTED, "the ensemble kernel needs at least %d workgroups for %d objectives", widest, e->K);
+        int ncg = e->ens_ncg;
+        G = e->ens_G;
+        while (G > max_workgroups && ncg < KH_ENS_MAXCG) ncg *= 2, G = (e->K + 2 * ncg - 1) / (2 * ncg);
+        const void *forms[2] = {nullptr, nullptr};
+        switch (ncg) {
+            case 1: forms[0] = (const void *)kh_ens_forward_update<1, false>, forms[1] = (const void *)kh_ens_forward_update<1, true>; break;
+            case 2: forms[0] = (const void *)kh_ens_forward_update<2, false>, forms[1] = (const void *)kh_ens_forward_update<2, true>; break;
+            case 4: forms[0] = (const void *)kh_ens_forward_update<4, false>, forms[1] = (const void *)kh_ens_forward_update<4, true>; break;
+            default: forms[0] = (const void *)kh_ens_forward_update<8, false>, forms[1] = (const void *)kh_ens_forward_update<8, true>; break;
+        }
+        for (const void *f : forms) {
+            const int rc = ensure_dynamic_lds(e, f, kh_ens_lds_bytes(ncg));
+            if (rc != KH_OK) return rc;
+        }
+    } else {
+        const bool tile_family = (e->kind == KIND_TILE_Q2 && !e->mini) || e->kind == KIND_TILE_RPT1 || e->kind == KIND_TILE_RPT2;
+        if (!tile_family || e->d_csr_fw != nullptr || e->N > KH_TILE_N || e->L < 1 || e->L > 4)
+            return kh_fail(KH_ERR_UNSUPPORTED, "only the register-tile families (N <= 64, 1..4 controls) have a form with fewer workgroups");
+        const int fewest = (e->K + KH_STREAM_MMAX - 1) / KH_STREAM_MMAX;
+        if (max_workgroups < fewest)
+            return kh_fail(KH_ERR_UNSUPPORTED, "%d objectives need at least %d workgroups (%d per workgroup)", e->K, fewest, KH_STREAM_MMAX);
+        G = e->stream ? e->stream_G : e->grid_update;
+        if (max_workgroups < G) G = max_workgroups;
+    }
+    e->reduced_G = max_workgroups;
+    if (chosen != nullptr) *chosen = G;
     return KH_OK;
 }
 
@@ -1914,7 +1984,9 @@ extern "C" int kh_update_end(kh_engine *e, kh_cdouble *psi_T_dev, void *stream) 
 __global__ void kh_p2p_selftest_kernel(KhExchange ex, int L, int rounds, unsigned int epoch0, int *result) {
     const int lane = threadIdx.x;
     int ok_all = 1;
+    long long t_first = 0;
     for (int r = 0; r < rounds; ++r) {
+        if (r == 1) t_first = wall_clock64();  // (the first round absorbs the ranks' launch skew)
         double vals[KH_MAX_L], out[KH_MAX_L];
         for (int l = 0; l < KH_MAX_L; ++l) vals[l] = (double)(ex.rank + 1) * (l + 1) + 0.25 * r;
         const unsigned int epoch = epoch0 + (unsigned)r + 1u;
@@ -1929,6 +2001,10 @@ __global__ void kh_p2p_selftest_kernel(KhExchange ex, int L, int rounds, unsigne
         }
     }
     if (lane == 0) *result = ok_all;
+    if (lane == 0 && ex.wait_ticks != nullptr && rounds > 1) {  // publish -> all ranks' values read back, per round
+        ex.wait_ticks[2] = (unsigned long long)(wall_clock64() - t_first);
+        ex.wait_ticks[3] = (unsigned long long)(rounds - 1);
+    }
 }
 
 extern "C" int kh_p2p_create_window(kh_engine *e, int32_t world, int32_t rank, unsigned char *ipc_handle_out) {
@@ -1999,6 +2075,7 @@ extern "C" int kh_p2p_selftest(kh_engine *e, int32_t rounds, void *stream) {
     ex.world = e->p2p_world;
     ex.rank = e->p2p_rank;
     ex.fail_at = -1;
+    ex.wait_ticks = e->d_wait_ticks;
     int *d_res = nullptr;
     KH_HIP(hipMalloc(&d_res, sizeof(int)));
     KH_HIP(hipMemsetAsync(d_res, 0, sizeof(int), st));
@@ -2018,6 +2095,18 @@ extern "C" int kh_p2p_selftest(kh_engine *e, int32_t rounds, void *stream) {
         return kh_fail(KH_ERR_TIMEOUT, "cross-GPU exchange self-test failed on rank %d", e->p2p_rank);
     }
     e->p2p_ready = true;
+    return KH_OK;
+}
+
+extern "C" int kh_p2p_stats(kh_engine *e, double out[4]) {
+    if (e == nullptr || out == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
+    unsigned long long t[4] = {0, 0, 0, 0};
+    KH_HIP(hipMemcpy(t, e->d_wait_ticks, sizeof(t), hipMemcpyDeviceToHost));
+    const double n = e->last_intervals > 0 ? e->last_intervals : 1.0;
+    out[0] = (double)t[0] * 0.01 / n;                       // 100 MHz ticks -> us
+    out[1] = (double)t[1] * 0.01 / n;
+    out[2] = t[3] > 0 ? (double)t[2] * 0.01 / (double)t[3] : 0.0;
+    out[3] = (double)e->p2p_world;
     return KH_OK;
 }
 
@@ -2093,6 +2182,9 @@ extern "C" int kh_series_tables_defect(double tol, double theta_cap, double defe
 __global__ void __launch_bounds__(512) kh_occupy_kernel(long long ticks, int *sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long long t0 = wall_clock64();
+    // all ones (a NaN as a double) in all of the 128 KiB: what a later kernel on this CU finds in its uninitialised LDS
+    for (int i = threadIdx.x; i < 128 * 1024 / 16; i += blockDim.x) ((uint4 *)smem)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    __syncthreads();
     smem[threadIdx.x] = (char)threadIdx.x;
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
     if (smem[(threadIdx.x + 1) & 511] == 77 && ticks < 0) *sink = 1;
@@ -2111,6 +2203,10 @@ extern "C" int kh_debug_occupy(kh_engine *e, int32_t workgroups, double millisec
 
 extern "C" int kh_debug_launched(int32_t which, char *buf, int32_t cap) {
     std::string out;
+    if (which == 2) {  // forget what this process has launched so far (not what it has logged)
+        for (KhKernelRecord &rec : kh_kernel_registry()) rec.launched = false;
+        return 0;
+    }
     for (const KhKernelRecord &rec : kh_kernel_registry())
         if (which != 0 || rec.launched) out += rec.name + "\n";
     if (buf != nullptr && cap > 0) {

@@ -294,6 +294,16 @@ class HipKrotovEngine:
         _lib.check(self._lib.kh_set_second_order(
             self._handle, fw_prev.data_ptr(), fw_store.data_ptr(), sig.data_ptr()))
 
+    def set_update_workgroups(self, max_workgroups=0):
+        """Run the following single-launch update sweeps on at most ``max_workgroups`` workgroups (0: the engine's own
+        choice again); returns the grid the next sweep will use (``kh_set_update_workgroups``).  Raises
+        ``KrotovHipError`` (``KH_ERR_UNSUPPORTED``) for kernel families without such a form."""
+        import ctypes
+
+        chosen = ctypes.c_int32(0)
+        _lib.check(self._lib.kh_set_update_workgroups(self._handle, int(max_workgroups), ctypes.byref(chosen)))
+        return int(chosen.value)
+
     def forward_update(self, chi_store, chi_norms, init, guess, shape, lambdas):
         """Forward sweep with sequential update; returns ``(opt, psi_T, g_a)``."""
         chi_store = self._c(chi_store, (self.K, self.nt, self.N))
@@ -435,30 +445,47 @@ class HipKrotovEngine:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             return bool(flag.item())
 
+        def stage(name, ok):
+            """Collective verdict of one set-up stage; on failure every rank remembers which stage failed and -- where
+            it was this rank -- the library's own words (``p2p_why``: printed by ``bench.py --gpus N``)."""
+            mine_failed = not ok
+            if all_ok(ok):
+                return True
+            self.p2p_why = "peer windows not used: %s failed%s" % (
+                name, (" on this rank (%s)" % lib.kh_last_error().decode('utf-8', 'replace')) if mine_failed else " on another rank")
+            lib.kh_p2p_disable(h)
+            return False
+
+        self.p2p_why = None
         handle = (ctypes.c_ubyte * 64)()
         ok = lib.kh_p2p_create_window(h, world, rank, handle) == 0
         mine = torch.tensor(list(bytes(handle)), dtype=torch.uint8, device=self.device)
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine, group=group)
-        if not all_ok(ok):
-            lib.kh_p2p_disable(h)
+        if not stage('kh_p2p_create_window', ok):
             return False
         blob = b''.join(bytes(g.cpu().numpy().tobytes()) for g in gathered)
         buf = (ctypes.c_ubyte * len(blob)).from_buffer_copy(blob)
         ok = lib.kh_p2p_open_peers(h, buf) == 0
-        if not all_ok(ok):
-            lib.kh_p2p_disable(h)
+        if not stage('kh_p2p_open_peers (hipIpcOpenMemHandle)', ok):
             return False
         torch.cuda.synchronize(self.device)
         dist.barrier(group=group)  # every window exists and is mapped before anyone writes
         ok = lib.kh_p2p_selftest(h, int(rounds), self._stream()) == 0
-        if not all_ok(ok):
-            lib.kh_p2p_disable(h)
+        if not stage('kh_p2p_selftest (in-kernel exchange over the windows)', ok):
             return False
         return True
 
     def disable_p2p(self):
         self._lib.kh_p2p_disable(self._handle)
+
+    def p2p_stats(self):
+        """``kh_p2p_stats``: us per interval workgroup 0 waited inside its GPU / across the GPUs in the last sharded
+        single-launch update sweep, us per round of the set-up self-test, ranks."""
+        buf = (ctypes.c_double * 4)()
+        torch.cuda.synchronize(self.device)
+        _lib.check(self._lib.kh_p2p_stats(self._handle, buf))
+        return dict(local_wait_us=buf[0], cross_gpu_wait_us=buf[1], selftest_round_us=buf[2], ranks=int(buf[3]))
 
     def tau(self, targets, psi_T):
         targets = self._c(targets, (self.K, self.N))

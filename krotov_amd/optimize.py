@@ -510,6 +510,8 @@ class _HipBackend:
         # otherwise (or after a failed sweep) one RCCL all-reduce per interval
         self._single_launch_ok = True  # (one GPU) until the single-launch update sweep has failed for good
         self._single_launch_failures = 0
+        self._update_grid = None  # workgroups of the single-launch update sweep after a retry (None: the engine's choice)
+        self._reduced_in_a_row = 0
         self.p2p = False
         if self.world > 1 and os.environ.get('KH_P2P', '1') != '0':
             self.p2p = self.engine.enable_p2p(self.group)
@@ -603,25 +605,54 @@ class _HipBackend:
         done = False
         if self.group is None:
             if self._single_launch_ok:
-                try:
-                    opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
-                    eng.check()
-                    done = True
+                # the single-launch sweep needs all its workgroups resident at once; if the GPU could not give it that
+                # (CUs held by another stream or process: its in-kernel exchange times out; or the device cannot hold
+                # the grid at all), redo it on HALF the workgroups, each walking through twice the objectives (about
+                # twice the time: kh_set_update_workgroups), halve again, ... and only then interval by interval -- one
+                # launch each, nothing waits inside a kernel, ten times the time -- like the sharded path does.
+                # Anything else than a timeout / "cannot be resident" is a real error.
+                grid = self._update_grid  # (None: the engine's own choice)
+                while not done:
+                    try:
+                        opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
+                        eng.check()
+                        done = True
+                    except _KrotovHipError as exc:
+                        if exc.code not in (_KH_ERR_TIMEOUT, _KH_ERR_UNSUPPORTED):
+                            raise
+                        try:
+                            full = eng.set_update_workgroups(0)
+                            nxt = (grid if grid is not None else full) // 2
+                            if nxt < 1:
+                                raise _KrotovHipError("no smaller grid", _KH_ERR_UNSUPPORTED)
+                            grid = eng.set_update_workgroups(nxt)
+                            logging.getLogger('krotov').warning(
+                                "single-launch update sweep failed (%s); repeating it on %d workgroups", exc, grid)
+                        except _KrotovHipError as exc2:
+                            if exc2.code != _KH_ERR_UNSUPPORTED:
+                                raise
+                            grid = None
+                            eng.set_update_workgroups(0)
+                            self._single_launch_failures += 1
+                            # a co-tenant may go away, but not after three sweeps in a row
+                            if exc.code == _KH_ERR_UNSUPPORTED or self._single_launch_failures >= 3:
+                                self._single_launch_ok = False
+                            logging.getLogger('krotov').warning(
+                                "single-launch update sweep failed (%s); repeating it with one launch per interval%s", exc,
+                                "" if self._single_launch_ok else " (and staying with that form)")
+                            break
+                if done:
                     self._single_launch_failures = 0
-                except _KrotovHipError as exc:
-                    # the single-launch sweep needs all its workgroups resident at once; if the GPU could not give it
-                    # that (CUs held by another stream or process: its in-kernel exchange times out; or the device
-                    # cannot hold the grid at all), redo the sweep interval by interval -- one launch each, nothing
-                    # waits inside a kernel -- like the sharded path does.  Anything else is a real error.
-                    if exc.code not in (_KH_ERR_TIMEOUT, _KH_ERR_UNSUPPORTED):
-                        raise
-                    self._single_launch_failures += 1
-                    # "cannot be resident" will not change; a co-tenant may go away, but not after three sweeps in a row
-                    if exc.code == _KH_ERR_UNSUPPORTED or self._single_launch_failures >= 3:
-                        self._single_launch_ok = False
-                    logging.getLogger('krotov').warning(
-                        "single-launch update sweep failed (%s); repeating it with one launch per interval%s", exc,
-                        "" if self._single_launch_ok else " (and staying with that form)")
+                    if grid is not None:
+                        # a reduced grid got through: the next sweep tries the full one again, unless that has failed
+                        # three sweeps in a row (then the grid that works is kept)
+                        self._reduced_in_a_row += 1
+                        if self._reduced_in_a_row < 3:
+                            eng.set_update_workgroups(0)
+                            grid = None
+                    else:
+                        self._reduced_in_a_row = 0
+                    self._update_grid = grid
             if not done:
                 opt, psi_T, g_a = eng.forward_update_sharded(
                     self.chi_store, norms_loc, self.init, guess, shapes, lambdas, lambda x: None, graph_chunk=0)

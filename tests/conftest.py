@@ -10,6 +10,32 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "no_oracle: a GPU test that compares with no oracle / reference data (timing, "
+                                       "plumbing): its kernel launches do not count for tests/test_zz_kernel_coverage.py")
+    # kernel-instantiation coverage (include/krotov_hip.h: kh_debug_launched): one log per session; the library appends
+    # an instantiation's name at its first launch in a process while KH_LAUNCH_LOG names the file -- which the fixture
+    # below arranges for the oracle-comparing GPU tests only (their rank sub-processes inherit the variable)
+    import tempfile
+
+    fd, path = tempfile.mkstemp(prefix='kh_launch_log_', suffix='.txt')
+    os.close(fd)
+    config._kh_launch_log = path
+    config._kh_full_run = not config.getoption('keyword') and all(os.path.isdir(a.split('::')[0]) for a in config.args)
+
+
+def pytest_unconfigure(config):
+    path = getattr(config, '_kh_launch_log', None)
+    if path and os.path.exists(path):
+        os.unlink(path)
+
+
+@pytest.fixture(autouse=True)
+def _kernel_launch_log(request, monkeypatch):
+    if 'gpu' in request.keywords and 'no_oracle' not in request.keywords:
+        monkeypatch.setenv('KH_LAUNCH_LOG', request.config._kh_launch_log)
+    else:
+        monkeypatch.delenv('KH_LAUNCH_LOG', raising=False)
+    yield
 
 
 def _gpu_available():

@@ -1112,7 +1112,11 @@ def _two_rank_spec(case):
     if case == 'c3':  # small problem: the one-wave-per-objective kernels, 2 + 2 objectives
         return configs.config_c3(nt=301)
     if case == 'k1100':  # 550 objectives per rank: not co-resident, so no in-kernel exchange -- the peer windows
-        spec = configs.config_c5(K=1100, N=6, nt=13, L=1)  # are refused and every interval is a launch + all-reduce
+        spec = configs.config_c5(K=1100, N=6, nt=13, L=1, distinct=True)  # are refused and every interval is a launch + all-reduce
+        spec.chi = 'sm'
+        return spec
+    if case == 'k1100ens':  # the same as an ensemble proper (one drift, scaled control operators): 550 objectives per rank
+        spec = configs.config_c5(K=1100, N=6, nt=13, L=1)  # on the matrix-core ensemble kernel, sums through the peer windows
         spec.chi = 'sm'
         return spec
     if case == 'c4k25':  # 13 + 12 objectives per rank: two objectives per cooperative workgroup (7 + 6 column groups)
@@ -1195,7 +1199,7 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'c4k25', 'k1100', 'n80', 'sparse'])
+@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'c4k25', 'k1100', 'k1100ens', 'n80', 'sparse'])
 def test_two_ranks_sharded_on_one_gpu(case):
     import socket
 
@@ -1221,11 +1225,11 @@ def test_two_ranks_sharded_on_one_gpu(case):
         ref = oracle_optimize(spec, 2, sigma=SigmaA(0.0, 2e-3))
     else:
         ref = oracle_optimize(spec, 2)
-    tol = 1e-12 if case in ('c5', 'c3', 'k1100', 'n80', 'sparse') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
+    tol = 1e-12 if case in ('c5', 'c3', 'k1100', 'k1100ens', 'n80', 'sparse') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
     for _, pulses, tau, used_p2p, kernel in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
-        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/stream',
+        assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/stream', 'k1100ens': 'ens64/mfma',
                           'n80': 'tile128/512', 'sparse': 'ell/csr'}.get(case, 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
     # the path this test is here for: the sums crossed the ranks inside the persistent kernels, through the
@@ -1546,6 +1550,7 @@ def test_dump_result_and_continue_on_device(tmp_path):
     assert np.array_equal(np.array(cont2.all_pulses[3:]), np.array(cont.all_pulses[3:]))
 
 
+@pytest.mark.no_oracle
 def test_two_update_sweeps_on_two_streams():
     """Two engines, each filling the GPU with one workgroup per objective, launched back to back on two streams: the
     single-launch update sweeps need all their workgroups resident at once, so the launches must not interleave
@@ -1584,6 +1589,7 @@ def test_two_update_sweeps_on_two_streams():
         eng.close()
 
 
+@pytest.mark.no_oracle
 def test_update_sweep_next_to_a_busy_stream(monkeypatch):
     """Half of the CUs are held by another stream of the process when the single-launch update sweep (one workgroup
     per CU, all of them needed at once) is launched.  Neither a plain nor a cooperative launch waits for the other
@@ -1627,15 +1633,42 @@ def test_update_sweep_next_to_a_busy_stream(monkeypatch):
         # (a scheduler that waits for the other stream, a device with spare CUs: nothing is wrong with the library, the
         # situation this test is about just cannot be provoked here)
         pytest.skip("the busy stream never made the in-kernel exchange time out on this device")
+    scale = max(1.0, float(solo[0].abs().max()))
+    # what optimize_pulses does first: the same sweep on half the workgroups, each walking through
+    # two objectives per interval, WHILE the other stream still holds its half of the CUs -- about twice the time of
+    # the undisturbed sweep, not the ten times of one launch per interval
+    def timed(fn):
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        out = fn()
+        t1.record()
+        torch.cuda.synchronize()
+        return out, t0.elapsed_time(t1)
+
+    ms_solo = min(timed(lambda: eng.forward_update(*a))[1] for _ in range(3))
+    eng.check()
+    grid = eng.set_update_workgroups(max(1, num_cus // 2))
+    assert grid == max(1, min(spec.K, num_cus // 2))
+    with torch.cuda.stream(side):
+        _lib.check(eng._lib.kh_debug_occupy(eng._handle, max(1, num_cus // 2), 60.0, eng._stream()))
+    halved, ms_halved = timed(lambda: eng.forward_update(*a))
+    eng.check()
+    assert eng.stats()['workgroups'] == grid
+    assert float((halved[0] - solo[0]).abs().max()) < 1e-12 * scale
+    assert float((halved[1] - solo[1]).abs().max()) < 1e-12
+    print("update sweep: %.2f ms undisturbed, %.2f ms on %d workgroups next to the busy stream" % (ms_solo, ms_halved, grid))
+    assert ms_halved <= 3.0 * ms_solo
+    assert eng.set_update_workgroups(0) == spec.K
+    # ... and the last resort: one launch per interval
     again = eng.forward_update_sharded(*a, lambda x: None, graph_chunk=0)
     eng.check()
-    scale = max(1.0, float(solo[0].abs().max()))
     assert float((again[0] - solo[0]).abs().max()) < 1e-12 * scale
     assert float((again[1] - solo[1]).abs().max()) < 1e-12
     eng.close()
 
 
-def test_optimize_pulses_survives_a_busy_stream(monkeypatch):
+@pytest.mark.no_oracle
+def test_optimize_pulses_survives_a_busy_stream(monkeypatch, caplog):
     """The same disturbance under ``optimize_pulses``: the iteration whose update sweep times out is redone interval
     by interval and the run ends with the pulses of an undisturbed one."""
     import torch
@@ -1658,10 +1691,94 @@ def test_optimize_pulses_survives_a_busy_stream(monkeypatch):
                 _lib.check(eng._lib.kh_debug_occupy(eng._handle, 128, 60.0, eng._stream()))
         return None
 
+    import logging
+
+    caplog.set_level(logging.WARNING, logger='krotov')
     busy = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, info_hook=disturb, **kw)
     torch.cuda.synchronize()
     assert np.abs(np.array(busy.all_pulses) - np.array(calm.all_pulses)).max() < 1e-12
     assert np.abs(np.array(busy.tau_vals) - np.array(calm.tau_vals)).max() < 1e-12
+    # the disturbed sweep was redone on half the workgroups (not interval by interval)
+    text = caplog.text
+    if 'single-launch update sweep failed' in text:
+        assert 'repeating it on 128 workgroups' in text and 'one launch per interval' not in text, text
+
+
+@pytest.mark.parametrize('name', ['c5_n100', 'c5_n80', 'c4_d9', 'c5_n33', 'c5_n12_L3', 'c5_k600'])
+def test_kernels_do_not_read_uninitialised_lds(name, monkeypatch):
+    """Dynamic LDS holds what the previous kernel on the CU left there.  ``kh_debug_occupy`` leaves all-ones (NaN)
+    in 128 KiB of every CU; the sweeps launched right behind it must still be the oracle's (the term vectors
+    of kh_tilen.h beyond row N met zero matrix elements, and 0 * NaN poisons every row)."""
+    import torch
+
+    from krotov_amd import _lib
+
+    if name == 'c4_d9':
+        monkeypatch.setenv('KH_KERNEL', 'tilen')
+    spec = SMALL[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.5 / spec.K)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    eng = _engine(spec)
+    num_cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+
+    def poison():
+        _lib.check(eng._lib.kh_debug_occupy(eng._handle, 2 * num_cus, 0.05, eng._stream()))
+
+    poison()
+    chi = eng.backward(chi_T, pulses)
+    poison()
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    tol = 1e-11 if spec.is_super else 1e-12
+    assert np.abs(chi.cpu().numpy() - ref_chi).max() < tol
+    assert np.abs(opt.cpu().numpy() - np.array(ref[0])).max() < tol * max(1.0, np.abs(np.array(ref[0])).max())
+    assert np.abs(psi_T.cpu().numpy() - ref[1]).max() < tol
+    eng.close()
+
+
+@pytest.mark.parametrize('name,grid,want', [('c5_n64', 3, 3), ('c5_n64_L2', 1, 1), ('c5_n33', 2, 2), ('c5_k300', 100, 100),
+                                            ('c5_k520_n64', 40, 33), ('c5_k600', 75, 75), ('c5_n12_L3', 2, 2)])
+def test_update_sweep_on_fewer_workgroups(name, grid, want):
+    """``kh_set_update_workgroups`` (what follows a KH_ERR_TIMEOUT): the register-tile families run their single-launch
+    update sweep as kh_stream_forward_update on the given number of workgroups, ensembles as kh_ens_forward_update with
+    more objectives per workgroup -- against the oracle; families without such a form say KH_ERR_UNSUPPORTED."""
+    from krotov_amd import _lib
+
+    spec = SMALL[name]()
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.5 / spec.K)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    eng = _engine(spec)
+    full = eng.set_update_workgroups(0)
+    assert eng.set_update_workgroups(grid) == want and want < full
+    chi = eng.backward(chi_T, pulses)
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    assert np.abs(opt.cpu().numpy() - np.array(ref[0])).max() < 1e-12 * max(1.0, np.abs(np.array(ref[0])).max())
+    assert np.abs(psi_T.cpu().numpy() - ref[1]).max() < 1e-12
+    assert np.abs(g_a.cpu().numpy() - ref[2]).max() < 1e-12 * max(1.0, np.abs(ref[2]).max())
+    assert eng.stats()['workgroups'] == want
+    too_few = (spec.K + 15) // 16 - 1  # (the kernels take at most 16 objectives per workgroup)
+    if too_few >= 1:
+        with pytest.raises(_lib.KrotovHipError) as info:
+            eng.set_update_workgroups(too_few)
+        assert info.value.code == _lib.KH_ERR_UNSUPPORTED
+    assert eng.set_update_workgroups(0) == full
+    eng.close()
+    other = _engine(SMALL['c4_d9']())  # cooperative kernels: no form with fewer workgroups
+    with pytest.raises(_lib.KrotovHipError) as info:
+        other.set_update_workgroups(2)
+    assert info.value.code == _lib.KH_ERR_UNSUPPORTED
+    other.close()
 
 
 MM_CASES = {
@@ -1708,6 +1825,7 @@ def test_update_kernel_series_regimes(name):
     assert np.abs(out[2] - ref_ga).max() < 1e-12 * max(1.0, np.abs(ref_ga).max())
 
 
+@pytest.mark.no_oracle
 def test_bench_self_launches_two_ranks(tmp_path):
     """``python bench.py --gpus 2`` with no launcher and no WORLD_SIZE in the environment -- the form the driver's
     scaling run uses -- must start its ranks itself, print ONE JSON line from rank 0 and exit 0.  Here both ranks
@@ -1740,6 +1858,7 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert rec['value'] > 0 and rec['roofline']['frac'] > 0
 
 
+@pytest.mark.no_oracle
 def test_bench_gpus_8_dry_run_on_one_gpu(tmp_path):
     """``python bench.py --gpus 8`` -- the driver's SCALE command at its largest N -- as a dry run: 8 ranks sharing the one
     GPU, 32 objectives each (config 5's 8-GPU partition: 256 workgroups in total, all co-resident), a shortened grid.
