@@ -467,10 +467,49 @@ def main():
             # more objectives than the GPU keeps co-resident: the streaming update kernel (kh_tile64s.h); the plain sweeps
             # take the objectives in turns
             'tile64/stream': ('kh_stream_forward_update', 'kh_q2_sweep_store' if args.L == 1 else 'kh_tile_sweep_store'),
+            # an ensemble proper (one drift, scaled control operators) beyond the co-resident limit: the update sweep on the
+            # matrix cores, several objectives per workgroup (kh_ens.h); plain sweeps as above
+            'ens64/mfma': ('kh_ens_forward_update', 'kh_q2_sweep_store'),
         }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
         if group is not None and not getattr(eng, '_p2p_used', False) and eng.kernel != 'generic':
             # per-interval launches (RCCL path) run the two-tile kernel, see krotov_hip.hip:launch_update
             kernel_names = ('kh_tile_forward_update', kernel_names[1])
+
+        diag = None
+        if world > 1:
+            # what every rank actually did (the first run on a real multi-GPU node must explain itself):
+            # the transport, why if it is not the peer windows, the set-up self-test's round trip, and where workgroup 0
+            # waited per interval -- inside its GPU or for the other GPUs (kh_p2p_stats)
+            used = getattr(eng, '_p2p_used', False)
+            fell = getattr(eng, '_p2p_fell_back', False)
+            try:
+                ps = eng.p2p_stats()
+            except Exception as exc:
+                ps = {'error': repr(exc)[:120]}
+            mine = {
+                'rank': rank, 'device': torch.cuda.current_device(), 'gpu': torch.cuda.get_device_name(),
+                'transport': ('per-interval all-reduce after a fallback' if fell else
+                              'peer windows' if used else 'all-reduce per interval'),
+                'why': getattr(eng, 'p2p_why', None),
+                'objectives': eng.K, 'kernel': eng.kernel,
+                'update_sweep_ms': float(np.mean(times['update'][-args.steps:])) if times.get('update') else None,
+                'backward_sweep_ms': float(np.mean(times['backward'][-args.steps:])) if times.get('backward') else None,
+                'p2p': ps,
+            }
+            if os.environ.get('KH_P2P', '1') == '0' or fell or not used:
+                # the transport of this measurement is one all-reduce of the L sums per interval: what one costs by itself
+                x = torch.zeros(args.L, dtype=torch.float64, device='cuda')
+                for _ in range(20):
+                    torch.distributed.all_reduce(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    torch.distributed.all_reduce(x)
+                torch.cuda.synchronize()
+                mine['allreduce_us'] = (time.perf_counter() - t0) / 200 * 1e6
+            gathered = [None] * world
+            torch.distributed.all_gather_object(gathered, mine)
+            diag = gathered
 
         if rank == 0:
             K_loc = eng.K
@@ -487,7 +526,7 @@ def main():
             # flops the dominant kernel really executed (its own count of matrix-vector products; the update sweep's is the
             # one kh_last_stats holds after an iteration): the A^2 chain and the shorter series issue fewer than credited
             executed = stats['matvecs'] * 8.0 * args.N * args.N if dominant == 'update' else None
-            mfma_kernel = eng.kernel == 'coop16/mfma'
+            mfma_kernel = eng.kernel == 'coop16/mfma' or (eng.kernel == 'ens64/mfma' and dominant == 'update')
             out = {
                 'metric': 'state*timestep propagations/s (Krotov iterations/s in iterations_per_sec), ' +
                           ('16-objective N=400 Liouvillian (variant)' if args.workload == 'c4' else
@@ -568,6 +607,20 @@ def main():
                 },
                 'final_J_T_re': float(1 - np.mean(np.array(res.tau_vals[-1]).real)),
             }
+            if diag is not None:
+                out['ranks'] = diag
+                if args.workload == 'c5' and args.N == 64 and args.L == 1 and args.nt > 1000:
+                    # DESIGN.md 4 / docs/HISTORY.md 4, written down before any second GPU was available: the first SCALE
+                    # record confirms or refutes it by itself
+                    out['predicted'] = {
+                        'source': 'DESIGN.md 4 (docs/HISTORY.md 4): one GPU 4.8-4.9 us per interval of the update sweep; '
+                                  'peer windows +1.0 us (cross-GPU stage, measured with ranks sharing one GPU) '
+                                  '+0.5-1.0 us (xGMI store -> poll, assumed); all-reduce per interval 19 us step + 10-20 us collective',
+                        'update_us_per_interval': [6.4, 6.9] if getattr(eng, '_p2p_used', False) else [30.0, 40.0],
+                        'ms_per_step': [38.0, 40.0] if getattr(eng, '_p2p_used', False) else [130.0, 170.0],
+                        'measured_update_us_per_interval': t_up * 1e6 / (args.nt - 1),
+                        'measured_ms_per_step': ms_per_step,
+                    }
             return out
         return None
 
@@ -591,6 +644,9 @@ def main():
                 'roofline': {k: line['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'executed_frac')},
                 'kernels': {k: line['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')
                             if k in line['kernels']}}
+            for k in ('ranks', 'predicted'):
+                if k in line:
+                    rec[k] = line[k]
             return rec
         except Exception as exc:  # (the headline line must not depend on a side measurement)
             if world > 1:
@@ -624,6 +680,7 @@ def main():
             if rank == 0:
                 out[name] = {'error': why or 'no result within %d s' % seconds}
                 out['degraded'] = True
+                out['degraded_why'] = {k: v['error'] for k, v in out.items() if isinstance(v, dict) and 'error' in v}
                 print(json.dumps(out), flush=True)
             os._exit(0)
 
@@ -645,6 +702,9 @@ def main():
             out[other] = {k: second[k] for k in ('value', 'unit', 'iterations_per_sec', 'ms_per_step', 'scaling')}
             out[other]['objectives'] = second['config']['objectives']
             out[other]['kernels'] = {k: second['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')}
+            for k in ('ranks', 'predicted'):
+                if k in second:
+                    out[other][k] = second[k]
     rccl = None
     if (world > 1 or args.force_dist) and args.workload == 'c5' and not args.no_rccl_leg:
         # the north star's transport: one RCCL all-reduce of the L update sums per time interval (kh_update_begin /
@@ -691,8 +751,10 @@ def main():
             except Exception as exc:  # (the headline line must not depend on a side measurement)
                 out['sparse'] = {'error': repr(exc)[:200]}
     if rank == 0:
-        if any(isinstance(v, dict) and 'error' in v for v in out.values()):
+        failed = {k: v['error'] for k, v in out.items() if isinstance(v, dict) and 'error' in v}
+        if failed:
             out['degraded'] = True  # a side measurement was replaced by its error (the headline itself is complete)
+            out['degraded_why'] = failed
         print(json.dumps(out), flush=True)
     if group is not None:
         torch.distributed.barrier()

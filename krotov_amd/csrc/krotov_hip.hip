@@ -815,7 +815,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         e->kind = KIND_TILE_RPT1;
         if (e->L == 1) e->kind = KIND_TILE_Q2;  // two Taylor terms per phase (kh_tile64q2.h)
         if (force && strcmp(force, "tile512") == 0) e->kind = KIND_TILE_RPT1;
-        if (force && strcmp(force, "tile256") == 0 && e->L <= 2) e->kind = KIND_TILE_RPT2;
+        if (force && strcmp(force, "tile256") == 0 && e->L == 1) e->kind = KIND_TILE_RPT2;  // (two controls: 204 spilled values, never a default choice -- no such instantiation any more)
         e->grid_update = e->K;
         // small problems: one wave per objective, the objectives of the GPU in one workgroup (kh_mini.h);
         // KH_KERNEL=q2 keeps the workgroup-per-objective kernels, KH_KERNEL=mini is accepted for symmetry
@@ -938,7 +938,10 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     if ((e->kind_store == KIND_TILE_RPT2 || e->kind_store == KIND_TILE_RPT1) && e->L == 1 && force == nullptr &&
         !(getenv("KH_Q2_STORE") && atoi(getenv("KH_Q2_STORE")) == 0))
         e->kind_store = KIND_TILE_Q2;
-    const bool coop_sq = e->kind == KIND_COOP && e->L == 1 && !(getenv("KH_COOP_NOSQ") && atoi(getenv("KH_COOP_NOSQ")));
+    // (not for 16 operator slots per lane x 16 objectives per workgroup -- N > 256 with more objectives than 4 per
+    // workgroup keep co-resident --: the A^2 chain's second fragment does not fit the registers there, launch_coop_store)
+    const bool coop_sq = e->kind == KIND_COOP && e->L == 1 && !(getenv("KH_COOP_NOSQ") && atoi(getenv("KH_COOP_NOSQ"))) &&
+                         !(e->coop_cols == 16 && e->coop_ks > 8);
     if (e->kind == KIND_TILE_Q2 || e->kind_store == KIND_TILE_Q2 || coop_sq) {
         // stage P0 = H0 H0, P1 = H0 H1 + H1 H0, P2 = H1 H1 once per distinct operator (pair)
         const unsigned pgrid = (unsigned)(((size_t)e->N * e->N + 255) / 256 < 16 ? 16 : ((size_t)e->N * e->N + 255) / 256);
@@ -1299,7 +1302,7 @@ static int dispatch_tile_store(kh_engine *e, const KhSweepArgs &p, const double 
                                cplx *store, cplx *out, int direction, hipStream_t st) {
     switch (e->L) {
         case 1: return launch_tile_store<RPT, 1>(e, p, pulses, in, store, out, direction, st);
-        case 2: return launch_tile_store<RPT, 2>(e, p, pulses, in, store, out, direction, st);
+        case 2: return launch_tile_store<1, 2>(e, p, pulses, in, store, out, direction, st);
         case 3: return launch_tile_store<1, 3>(e, p, pulses, in, store, out, direction, st);
         case 4: return launch_tile_store<1, 4>(e, p, pulses, in, store, out, direction, st);
         default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");
@@ -1373,17 +1376,23 @@ static int launch_c4_store(kh_engine *e, const KhSweepArgs &p, const double *pul
 template <int MAXKS, int COLS>
 static int launch_coop_store(kh_engine *e, const KhSweepArgs &p, const double *pulses, const cplx *in, cplx *store,
                              cplx *out, int direction, hipStream_t st) {
-    const bool sq = (direction < 0 ? e->d_coop_sq_bw : e->d_coop_sq_fw) != nullptr;
-    int rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS, true>, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
+    // (16 operator slots per lane x 16 objectives per workgroup: the A^2 chain's second resident fragment does not fit
+    // the register file -- 245 .. 343 spilled values --, the engine does not stage the A^2 tables for that shape)
+    constexpr bool SQ_FORMS = !(MAXKS == 16 && COLS == 16);
+    const bool sq = SQ_FORMS && (direction < 0 ? e->d_coop_sq_bw : e->d_coop_sq_fw) != nullptr;
+    int rc = KH_OK;
+    if constexpr (SQ_FORMS)
+        rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS, true>, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
     if (rc == KH_OK)
         rc = ensure_dynamic_lds(e, (const void *)kh_coop_sweep_store<MAXKS, COLS, false>, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     KH_HIP(hipMemsetAsync(e->d_coop_vbuf, 0, e->coop_vbuf_bytes, st));
     KH_HIP(hipMemsetAsync(e->d_coop_xcc, 0, sizeof(unsigned int) * (size_t)e->coop_G * e->coop_Y, st));
     return launch_coop_placed(e, [&](dim3 grid) {
-        if (sq)
-            return launch_persistent<kh_coop_sweep_store<MAXKS, COLS, true>>(e, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
-                                     coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
+        if constexpr (SQ_FORMS)
+            if (sq)
+                return launch_persistent<kh_coop_sweep_store<MAXKS, COLS, true>>(e, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
+                                         coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
         return launch_persistent<kh_coop_sweep_store<MAXKS, COLS, false>>(e, grid, dim3(KH_COOP_THREADS), kh_coop_lds_bytes(e->coop_ks, COLS), st, p,
                                  coop_args(e, direction < 0), exchange_args(e, true), pulses, in, store, out, direction);
     });
@@ -1403,14 +1412,20 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
             e->coop_adj = false;
         }
     }
-    const bool adj = e->coop_adj && u.sigma == nullptr && e->L == 1 && e->d_coop_sq_fw != nullptr;
-    const bool sq = e->d_coop_sq_fw != nullptr;
-    const void *func = u.sigma != nullptr ? (sq ? (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, true>
-                                                : (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, false>)
-                       : adj              ? (ex.world == 1 && e->coop_single ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true, false>
-                                                            : (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true>)
-                       : sq               ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, false, true>
+    constexpr bool SQ_FORMS = !(MAXKS == 16 && COLS == 16);  // (see launch_coop_store)
+    const bool sq = SQ_FORMS && e->d_coop_sq_fw != nullptr;
+    const bool adj = e->coop_adj && u.sigma == nullptr && e->L == 1 && sq;
+    const void *func = u.sigma != nullptr ? (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, false>
                                           : (const void *)kh_coop_forward_update<MAXKS, COLS, false, false, false>;
+    if constexpr (SQ_FORMS) {
+        if (u.sigma != nullptr && sq)
+            func = (const void *)kh_coop_forward_update<MAXKS, COLS, true, false, true>;
+        else if (adj)
+            func = ex.world == 1 && e->coop_single ? (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true, false>
+                                                   : (const void *)kh_coop_forward_update<MAXKS, COLS, false, true, true>;
+        else if (u.sigma == nullptr && sq)
+            func = (const void *)kh_coop_forward_update<MAXKS, COLS, false, false, true>;
+    }
     const int rc = ensure_dynamic_lds(e, func, kh_coop_lds_bytes(COLS <= 4 ? 16 : 15, COLS));
     if (rc != KH_OK) return rc;
     if (adj) {
@@ -1427,14 +1442,17 @@ static int launch_coop_update(kh_engine *e, const KhSweepArgs &p, const KhUpdate
     return launch_coop_placed(e, [&](dim3 grid) {
         const size_t lds = kh_coop_lds_bytes(e->coop_ks, COLS);
         const KhCoopArgs ca = coop_args(e, false);
-        if (adj && ex.world == 1 && e->coop_single)
-            return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, true, true, false>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
-        if (adj) return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, true, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
-        if (u.sigma != nullptr && sq)
-            return launch_persistent<kh_coop_forward_update<MAXKS, COLS, true, false, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        if constexpr (SQ_FORMS) {
+            if (adj && ex.world == 1 && e->coop_single)
+                return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, true, true, false>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+            if (adj) return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, true, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+            if (u.sigma != nullptr && sq)
+                return launch_persistent<kh_coop_forward_update<MAXKS, COLS, true, false, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+            if (u.sigma == nullptr && sq)
+                return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, false, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
+        }
         if (u.sigma != nullptr)
             return launch_persistent<kh_coop_forward_update<MAXKS, COLS, true, false, false>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
-        if (sq) return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, false, true>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
         return launch_persistent<kh_coop_forward_update<MAXKS, COLS, false, false, false>>(e, grid, dim3(KH_COOP_THREADS), lds, st, p, ca, u, ex);
     });
 }
@@ -1744,7 +1762,7 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
         switch (e->L) {
             case 1: rc = rpt2 ? launch_tile_update<2, 1>(e, p, u, ex, st) : launch_tile_update<1, 1>(e, p, u, ex, st); break;
-            case 2: rc = rpt2 ? launch_tile_update<2, 2>(e, p, u, ex, st) : launch_tile_update<1, 2>(e, p, u, ex, st); break;
+            case 2: rc = launch_tile_update<1, 2>(e, p, u, ex, st); break;
             case 3: rc = launch_tile_update<1, 3>(e, p, u, ex, st); break;
             case 4: rc = launch_tile_update<1, 4>(e, p, u, ex, st); break;
             default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");

@@ -513,6 +513,7 @@ class _HipBackend:
         self._update_grid = None  # workgroups of the single-launch update sweep after a retry (None: the engine's choice)
         self._reduced_in_a_row = 0
         self.p2p = False
+        self.engine.p2p_why = "KH_P2P=0" if self.world > 1 else None
         if self.world > 1 and os.environ.get('KH_P2P', '1') != '0':
             self.p2p = self.engine.enable_p2p(self.group)
             logging.getLogger('krotov').info(
@@ -672,6 +673,7 @@ class _HipBackend:
                 eng.check()
             except Exception as exc:  # exchange timeout: every rank falls back together
                 logging.getLogger('krotov').warning("cross-GPU exchange failed (%s)", exc)
+                eng.p2p_why = "peer windows dropped after a failed sweep on this rank: %s" % exc
                 failed = 1
             flag = t.tensor([failed], dtype=t.int32, device=eng.device)
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, group=self.group)
@@ -682,6 +684,8 @@ class _HipBackend:
                 self.p2p = False
                 eng.disable_p2p()
                 eng._p2p_fell_back = True  # (stays with the per-interval transport from here on)
+                if not failed:
+                    eng.p2p_why = "peer windows dropped: the sweep failed on another rank"
         if not done:
             def all_reduce(x):
                 self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM, group=self.group)

@@ -1856,6 +1856,24 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert 'error' not in rec['config4'], rec['config4']
     assert rec['config4']['kernel'].startswith('coop') and rec['config4']['value'] > 0
     assert rec['value'] > 0 and rec['roofline']['frac'] > 0
+    _check_rank_diagnostics(rec, 2)
+
+
+def _check_rank_diagnostics(rec, world):
+    """the line of a sharded run explains itself -- per rank the transport really used (and why, if
+    not the peer windows), the set-up self-test's round trip, the per-interval wait inside the GPU and across the
+    GPUs; the all-reduce's own cost in the 'rccl' leg; the prediction of DESIGN.md 4 next to the measurement."""
+    for part in (rec, rec['strong']):
+        ranks = part['ranks']
+        assert [r['rank'] for r in ranks] == list(range(world))
+        for r in ranks:
+            assert r['transport'] == 'peer windows' and r['why'] is None, r
+            assert 0.0 < r['p2p']['selftest_round_us'] < 1000.0 and r['p2p']['ranks'] == world, r
+            assert r['p2p']['local_wait_us'] > 0.0 and r['p2p']['cross_gpu_wait_us'] > 0.0, r
+            assert r['update_sweep_ms'] > 0 and r['kernel'] == 'tile64q2/512'
+    for r in rec['rccl']['ranks']:
+        assert r['transport'] == 'all-reduce per interval' and r['why'] == 'KH_P2P=0' and r['allreduce_us'] > 0.0, r
+    assert not rec.get('degraded', False) and 'degraded_why' not in rec
 
 
 @pytest.mark.no_oracle
@@ -1893,5 +1911,6 @@ def test_bench_gpus_8_dry_run_on_one_gpu(tmp_path):
     assert not rec.get('degraded', False)
     assert rec['roofline']['bound'] == 'fp64-valu' and rec['roofline']['executed_frac'] > 0
     assert wall < 900, wall
+    _check_rank_diagnostics(rec, 8)
     print("bench.py --gpus 8 dry run: %.0f s wall; weak %.1f ms, strong %.1f ms, rccl %.1f ms per iteration" % (
         wall, rec['ms_per_step'], rec['strong']['ms_per_step'], rec['rccl']['ms_per_step']))

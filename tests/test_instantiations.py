@@ -67,11 +67,7 @@ case('q2_fwd_side_p2p_form', lambda: configs.config_c5(K=8, N=64, nt=21), ['kh_q
      env={'KH_Q2_SINGLE': '0', 'KH_NO_ADJ': '1'})
 
 # ---- one-term-per-phase kernels (kh_tile64.h): <rows per thread, controls, second order, single GPU>
-_L2 = lambda: configs.config_c5(K=4, N=64, nt=21, L=2, distinct=True)  # noqa: E731
 _L4 = lambda: configs.config_c5(K=4, N=64, nt=21, L=4, distinct=True)  # noqa: E731
-case('tile256_L2_so', _L2, ['kh_tile_forward_update<2, 2, true, true>'], env={'KH_KERNEL': 'tile256'}, so=True)
-case('tile256_L2_p2p_form', _L2, ['kh_tile_forward_update<2, 2, false, false>'], env={'KH_KERNEL': 'tile256', 'KH_TILE_SINGLE': '0'})
-case('tile256_L2_so_p2p_form', _L2, ['kh_tile_forward_update<2, 2, true, false>'], env={'KH_KERNEL': 'tile256', 'KH_TILE_SINGLE': '0'}, so=True)
 case('tile512_L4_so', _L4, ['kh_tile_forward_update<1, 4, true, true>'], so=True)
 case('tile512_L4_so_p2p_form', _L4, ['kh_tile_forward_update<1, 4, true, false>'], env={'KH_TILE_SINGLE': '0'}, so=True)
 
@@ -84,10 +80,16 @@ for _ks, _N in ((8, 96), (16, 272)):
         _n = 'coop%d_c%d_' % (_ks, _cols)
         _one = lambda K=_K, N=_N: _shared(K, N, 1)  # noqa: E731
         _two = lambda K=_K, N=_N: _shared(K, N, 2)  # noqa: E731
-        case(_n + 'adj', _one, [_t + 'false, true, true, false>', 'kh_coop_sweep_store<%d, %d, true>' % (_ks, _cols)], env=_e)
-        case(_n + 'adj_p2p_form', _one, [_t + 'false, true, true, true>'], env=dict(_e, KH_COOP_SINGLE='0'))
-        case(_n + 'so', _one, [_t + 'true, false, true, true>'], env=_e, so=True)
-        case(_n + 'no_adj', _one, [_t + 'false, false, true, true>'], env=dict(_e, KH_COOP_NO_ADJ='1'))
+        if (_ks, _cols) == (16, 16):
+            # the A^2 chain is not staged for this shape (its second resident fragment does not fit the registers): one
+            # control runs the forms two controls run
+            case(_n + 'L1', _one, [_t + 'false, false, false, true>', 'kh_coop_sweep_store<16, 16, false>'], env=_e)
+            case(_n + 'L1_so', _one, [_t + 'true, false, false, true>'], env=_e, so=True)
+        else:
+            case(_n + 'adj', _one, [_t + 'false, true, true, false>', 'kh_coop_sweep_store<%d, %d, true>' % (_ks, _cols)], env=_e)
+            case(_n + 'adj_p2p_form', _one, [_t + 'false, true, true, true>'], env=dict(_e, KH_COOP_SINGLE='0'))
+            case(_n + 'so', _one, [_t + 'true, false, true, true>'], env=_e, so=True)
+            case(_n + 'no_adj', _one, [_t + 'false, false, true, true>'], env=dict(_e, KH_COOP_NO_ADJ='1'))
         case(_n + 'L2', _two, [_t + 'false, false, false, true>', 'kh_coop_sweep_store<%d, %d, false>' % (_ks, _cols)], env=_e)
         case(_n + 'L2_so', _two, [_t + 'true, false, false, true>'], env=_e, so=True)
 
