@@ -323,10 +323,13 @@ int kh_series_tables_defect(double tol, double theta_cap, double defect, double 
 /* The padded row form the sparse kernels keep in registers (host only, no GPU needed; for inspection and tests): the
  * union of the patterns of an operator list (drift + controls; data == NULL: absent; HOST arrays here), entries some
  * control touches in the first Ec slots of every row, every row padded to E entries (multiples of four).
- *   off  [E][1024]          byte offset (16 x column) of every entry's vector element; padding: the row itself
- *   vals [n_ops][E][1024]   values of every operator on the union pattern (0 where it has no entry)
- * off / vals may be NULL (sizes only); E_cap: rows the caller's arrays can hold.  KH_ERR_UNSUPPORTED when N > 1024 or a
- * row is wider than 32 entries (16 for N > 512): such engines run the generic CSR kernels. */
+ *   off  [E][S]          byte offset (16 x column) of every entry's vector element; padding: the row itself
+ *   vals [n_ops][E][S]   values of every operator on the union pattern (0 where it has no entry)
+ * with S = kh_ell_rows_of(N) padded rows: the threads x rows per lane of the kernel instantiation that serves N (512,
+ * 768, 1024, 1536 or 2048; 0: N > 2048).  off / vals may be NULL (sizes only); E_cap: entry slots the caller's arrays can
+ * hold.  KH_ERR_UNSUPPORTED when N > 2048 or a row is wider than 32 entries (16 for N > 512, 8 for N > 1024): such
+ * engines run the generic CSR kernels. */
+int32_t kh_ell_rows_of(int32_t N);
 int kh_ell_layout(int32_t N, int32_t n_ops, const kh_csr *ops_host, int32_t *E, int32_t *Ec, int32_t *off,
                   kh_cdouble *vals, int32_t E_cap);
 

@@ -94,6 +94,7 @@ SYMBOLS = {
                                         ctypes.POINTER(ctypes.c_double)]),
     'kh_series_tables_defect': (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    'kh_ell_rows_of': (ctypes.c_int32, [ctypes.c_int32]),
     'kh_ell_layout': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _P, ctypes.POINTER(ctypes.c_int32),
                                      ctypes.POINTER(ctypes.c_int32), _P, _P, ctypes.c_int32]),
 }

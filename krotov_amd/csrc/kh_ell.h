@@ -21,18 +21,25 @@
 #include "kh_generic.h"
 
 #define KH_ELL_THREADS 512  // (default workgroup; the kernels are templates on the thread count: 512, 768, 1024)
-#define KH_ELL_NMAX 1024  // rows: one per lane up to 512, two per lane (tid, tid + 512) up to 1024
+#define KH_ELL_NMAX 2048  // rows: one per lane up to 512 / 768 / 1024, else 2, 3 or 4 per lane (tid + 512 i) up to 2048
 #define KH_ELL_EMAX 32    // widest padded row with one row per lane; with two rows per lane: KH_ELL_EMAX2
 #define KH_ELL_EMAX2 16
+#define KH_ELL_EMAX4 8    // ... with three or four rows per lane (1024 < N <= 2048)
+// rows of the padded pools (= threads x rows per lane of the instantiation that serves N): 512, 768, 1024, 1536, 2048
+__host__ __device__ inline int kh_ell_rows(int N) {
+    return N <= 512 ? 512 : N <= 768 ? 768 : N <= 1024 ? 1024 : N <= 1536 ? 1536 : 2048;
+}
+__host__ __device__ inline int kh_ell_emax(int N) { return N <= 512 ? KH_ELL_EMAX : N <= 1024 ? KH_ELL_EMAX2 : KH_ELL_EMAX4; }
 #define KH_ELL_THETA_CAP 6.0  // largest ||A dt|| of one sub-step with the Chebyshev-form series (krotov_hip.hip)
 
 // One distinct operator list, one direction: where its arrays start in the engine's two pools (kernel arguments, so the
 // loads are global loads; pointers inside a structure read from memory would make them FLAT ones)
 struct KhEll {
-    long long off_at;   // int pool:  [E][1024] byte offset (column * 16) of every entry's vector element; padding: own row
-    long long vals_at;  // cplx pool: [1 + L][E][1024] values of the drift and of every control operator on the union
+    long long off_at;   // int pool:  [E][rows] byte offset (column * 16) of every entry's vector element; padding: own row
+    long long vals_at;  // cplx pool: [1 + L][E][rows] values of the drift and of every control operator on the union
                         //            pattern (0: absent)
     int E, Ec;          // entries per (padded) row; the first Ec of every row are the ones some control operator touches
+    int rows, pad_;     // kh_ell_rows(N): the pools' row count
 };
 
 #define KH_ELL_XB_BYTES (KH_ELL_NMAX * (int)sizeof(cplx))  // second vector buffer at a compile-time offset
@@ -85,8 +92,8 @@ __device__ __forceinline__ void kh_ell_load(const KhEll &el, const int *__restri
             if (e0 < el.E) {  // (E is a multiple of four: build_ell_host)
 #pragma unroll
                 for (int e = e0; e < e0 + 4; ++e) {
-                    const int *po = offs + (el.off_at + (long long)e * KH_ELL_NMAX);
-                    const cplx *pv = vals + (el.vals_at + (long long)e * KH_ELL_NMAX);
+                    const int *po = offs + (el.off_at + (long long)e * el.rows);
+                    const cplx *pv = vals + (el.vals_at + (long long)e * el.rows);
                     off[i][e] = po[row];
                     a[i][e] = pv[row];
                 }
@@ -100,7 +107,7 @@ __device__ __forceinline__ void kh_ell_load(const KhEll &el, const int *__restri
 template <int T, int RPL, int EMAX>
 __device__ __forceinline__ void kh_ell_rebuild(const KhEll &el, const cplx *__restrict__ vals, int tid, int L,
                                                const double *eps, cplx (&a)[RPL][EMAX]) {
-    const long long plane = (long long)el.E * KH_ELL_NMAX;
+    const long long plane = (long long)el.E * el.rows;
     // (kh_launder: the addresses below are loop-invariant per entry; visible to the optimiser they are hoisted out of the
     // interval loop and kept in two VGPRs per entry and operator -- registers the matrix needs)
     const int tid_l = kh_launder(tid);
@@ -111,12 +118,12 @@ __device__ __forceinline__ void kh_ell_rebuild(const KhEll &el, const cplx *__re
         for (int e0 = 0; e0 < EMAX; e0 += 4) {
             if (e0 < el.Ec) {
 #pragma unroll
-                for (int e = e0; e < e0 + 4; ++e) a[i][e] = (vals + (el.vals_at + (long long)e * KH_ELL_NMAX))[row];
+                for (int e = e0; e < e0 + 4; ++e) a[i][e] = (vals + (el.vals_at + (long long)e * el.rows))[row];
                 for (int l = 0; l < L; ++l) {
                     const double w = eps[l];
 #pragma unroll
                     for (int e = e0; e < e0 + 4; ++e) {
-                        const cplx v = (vals + (el.vals_at + (1 + l) * plane + (long long)e * KH_ELL_NMAX))[row];
+                        const cplx v = (vals + (el.vals_at + (1 + l) * plane + (long long)e * el.rows))[row];
                         a[i][e].x = fma(w, v.x, a[i][e].x);
                         a[i][e].y = fma(w, v.y, a[i][e].y);
                     }
@@ -147,7 +154,7 @@ __device__ __forceinline__ cplx kh_ell_row(const cplx (&a)[EMAX], const int (&of
 template <int EMAX>
 __device__ __forceinline__ cplx kh_ell_control_row(const KhEll &el, const cplx *__restrict__ vals, int l, unsigned row,
                                                    const int (&off)[EMAX], const char *x) {
-    const long long base = el.vals_at + (long long)(1 + l) * el.E * KH_ELL_NMAX;
+    const long long base = el.vals_at + (long long)(1 + l) * el.E * el.rows;
     row = (unsigned)kh_launder((int)row);
     cplx s = c_make(0.0, 0.0);
 #pragma unroll
@@ -156,7 +163,7 @@ __device__ __forceinline__ cplx kh_ell_control_row(const KhEll &el, const cplx *
             cplx w[4], v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                w[q] = (vals + (base + (long long)(e0 + q) * KH_ELL_NMAX))[row];
+                w[q] = (vals + (base + (long long)(e0 + q) * el.rows))[row];
                 v[q] = *(const cplx *)(x + off[e0 + q]);
             }
 #pragma unroll

@@ -252,7 +252,26 @@ static void launch_plain(dim3 grid, dim3 block, size_t lds, hipStream_t st, Args
 template <auto Kernel, class... Args>
 static int launch_persistent(const kh_engine *e, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
     kh_note_launch(KhKernelTag<Kernel>::index);
-    if (!e->coop_launch || grid.x * grid.y * grid.z == 1) {
+    if (grid.x * grid.y * grid.z == 1) {
+        hipLaunchKernelGGL(Kernel, grid, block, lds, st, args...);
+        return KH_OK;
+    }
+    if (!e->coop_launch) {
+        // a plain launch has the same residency but nobody checks the grid against it (the cooperative launch below
+        // does): ask the occupancy of THIS instantiation as built -- registers, scratch, LDS -- once per shape, so that
+        // a grid that cannot be co-resident is refused here (KH_ERR_UNSUPPORTED: the caller takes a smaller grid or one
+        // launch per interval) instead of ending in a timeout
+        static std::map<std::tuple<const void *, unsigned, size_t, int>, int> per_cu_of;
+        const auto key = std::make_tuple((const void *)Kernel, block.x, lds, e->device);
+        auto it = per_cu_of.find(key);
+        if (it == per_cu_of.end()) {
+            int per_cu = 0;
+            KH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)Kernel, (int)block.x, lds));
+            it = per_cu_of.emplace(key, per_cu).first;
+        }
+        if ((long long)it->second * e->num_cus < (long long)grid.x * grid.y * grid.z)
+            return kh_fail(KH_ERR_UNSUPPORTED, "the update sweep's %u workgroups cannot all be resident on this device (%d per CU)",
+                           grid.x * grid.y * grid.z, it->second);
         hipLaunchKernelGGL(Kernel, grid, block, lds, st, args...);
         return KH_OK;
     }
@@ -468,7 +487,7 @@ static double csr_part_fro2(const HostCsr &a, const HostCsr &adj, double sign) {
 
 // One operator list (drift + L controls, canonical host copies; NULL: absent) in the padded row form of kh_ell.h:
 // the union of the patterns, entries some control touches first.  Returns false when a row is wider than the kernels'
-// register budget (KH_ELL_EMAX entries with one row per lane, KH_ELL_EMAX2 with two).
+// register budget (kh_ell_emax(N): 32 entries with one row per lane, 16 with two, 8 with three or four).
 static bool build_ell_host(const std::vector<const HostCsr *> &ops, int N, std::vector<int> &off, std::vector<cplx> &vals,
                            int &E, int &Ec) {
     const int Lp1 = (int)ops.size();
@@ -492,7 +511,7 @@ static bool build_ell_host(const std::vector<const HostCsr *> &ops, int N, std::
         E = std::max(E, (int)rows[r].size());
         Ec = std::max(Ec, nc);
     }
-    const int emax = N <= KH_ELL_THREADS ? KH_ELL_EMAX : KH_ELL_EMAX2;
+    const int emax = kh_ell_emax(N), S = kh_ell_rows(N);
     if (E > emax) return false;
     // every row: its control-touched entries in slots [0, Ec), the others behind them from slot Ec on (so that a rebuild
     // of slots [0, Ec) never touches a drift-only entry); padding: value 0, the lane's own row
@@ -506,10 +525,10 @@ static bool build_ell_host(const std::vector<const HostCsr *> &ops, int N, std::
     E = (std::max(width, 1) + 3) / 4 * 4;    // the kernels work on groups of four entries
     const int Ec_true = Ec;
     Ec = (Ec + 3) / 4 * 4;                   // (slots [Ec_true, Ec): drift-only entries or padding -- rebuilt to themselves)
-    off.assign((size_t)E * KH_ELL_NMAX, 0);
-    vals.assign((size_t)Lp1 * E * KH_ELL_NMAX, make_double2(0.0, 0.0));
-    for (int t = 0; t < KH_ELL_NMAX; ++t)
-        for (int e = 0; e < E; ++e) off[(size_t)e * KH_ELL_NMAX + t] = (t < N ? t : 0) * (int)sizeof(cplx);
+    off.assign((size_t)E * S, 0);
+    vals.assign((size_t)Lp1 * E * S, make_double2(0.0, 0.0));
+    for (int t = 0; t < S; ++t)
+        for (int e = 0; e < E; ++e) off[(size_t)e * S + t] = (t < N ? t : 0) * (int)sizeof(cplx);
     auto value_at = [](const HostCsr *m, int r, int c, cplx &v) {
         if (m == nullptr) return false;
         const auto lo = m->indices.begin() + m->indptr[r], hi = m->indices.begin() + m->indptr[r + 1];
@@ -522,10 +541,10 @@ static bool build_ell_host(const std::vector<const HostCsr *> &ops, int N, std::
         int slot_c = 0, slot_d = Ec_true;
         for (const auto &cv : rows[r]) {
             const int slot = cv.second ? slot_c++ : slot_d++;
-            off[(size_t)slot * KH_ELL_NMAX + r] = cv.first * (int)sizeof(cplx);
+            off[(size_t)slot * S + r] = cv.first * (int)sizeof(cplx);
             for (int o = 0; o < Lp1; ++o) {
                 cplx v;
-                if (value_at(ops[o], r, cv.first, v)) vals[((size_t)o * E + slot) * KH_ELL_NMAX + r] = v;
+                if (value_at(ops[o], r, cv.first, v)) vals[((size_t)o * E + slot) * S + r] = v;
             }
         }
     }
@@ -721,6 +740,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                         vals_pool.insert(vals_pool.end(), vals.begin(), vals.end());
                         pair[dir].E = E;
                         pair[dir].Ec = Ec;
+                        pair[dir].rows = kh_ell_rows(e->N);
+                        pair[dir].pad_ = 0;
                         e->ell_E = std::max(e->ell_E, E);
                     }
                     if (!ell_ok) break;
@@ -920,9 +941,13 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         // for the cooperative kernels (theta <= 4: round-off ~ e^theta eps per step, far inside the parity budget)
         if (!(pr->theta_max > 0.0)) {
             // (the long sub-steps only with the Chebyshev form's coefficients; Taylor's at theta <= 4 as before)
-            const bool cheb = e->real_spectrum || (e->imag_defect >= 0.0 && e->imag_defect <= 0.05);
-            e->theta_max = cheb && !(getenv("KH_NEAR_IMAG") && atoi(getenv("KH_NEAR_IMAG")) == 0) ? KH_ELL_THETA_CAP : 4.0;
-            if (const char *d = getenv("KH_ELL_CAP")) e->theta_max = atof(d) > 0.0 ? atof(d) : e->theta_max;
+            const bool cheb = (e->real_spectrum || (e->imag_defect >= 0.0 && e->imag_defect <= 0.05)) &&
+                              !(getenv("KH_NEAR_IMAG") && atoi(getenv("KH_NEAR_IMAG")) == 0);
+            e->theta_max = cheb ? KH_ELL_THETA_CAP : 4.0;
+            // KH_ELL_CAP (scripts/exp_ell_cap.py): another cap for the Chebyshev-form tables only, never beyond the one
+            // they were validated for -- plain Taylor keeps theta <= 4 (its round-off grows like e^theta)
+            if (const char *d = getenv("KH_ELL_CAP"))
+                if (cheb && atof(d) > 0.0) e->theta_max = atof(d) < KH_ELL_THETA_CAP ? atof(d) : KH_ELL_THETA_CAP;
         }
     }
     // The plain sweeps have no cross-objective coupling, so the register-tile kernel serves them for any
@@ -1099,7 +1124,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             // 6e-14 and the pulses within 7e-15 of the same run with theta <= 1 per sub-step, for caps 4, 5, 6 and 8
             // alike; KH_ELL_CAP: A/B switch
             double cap = KH_ELL_THETA_CAP;
-            if (const char *d = getenv("KH_ELL_CAP")) cap = atof(d) > 0.0 ? atof(d) : cap;
+            if (const char *d = getenv("KH_ELL_CAP")) cap = atof(d) > 0.0 && atof(d) < cap ? atof(d) : cap;  // (as theta_max above)
             kh_build_real_spectrum_rows(e->tol, tab.data(), c0.data(), rows.data(), ratios.data(), cap,
                                         e->real_spectrum ? 0.0 : e->imag_defect);
         } else if (e->real_spectrum) {
@@ -1493,8 +1518,14 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         const KhEll *ells = backward ? e->d_ell_bw : e->d_ell_fw;
         const int grid = e->K < 4 * e->num_cus ? e->K : 4 * e->num_cus;
         const size_t lds = kh_ell_lds_bytes();
-#define KH_ELL_STORE(T, R, EM) \
-    launch_plain<kh_ell_sweep_store<T, R, EM>>(dim3(grid), dim3(T), lds, st, p, ells, e->d_ell_off, e->d_ell_vals, pulses, in, store, out, direction)
+        // (two vector buffers of KH_ELL_NMAX elements: more than the 64 KiB a kernel gets without asking)
+#define KH_ELL_STORE(T, R, EM)                                                                                        \
+    do {                                                                                                              \
+        rc = ensure_dynamic_lds(e, (const void *)kh_ell_sweep_store<T, R, EM>, lds);                                  \
+        if (rc == KH_OK)                                                                                              \
+            launch_plain<kh_ell_sweep_store<T, R, EM>>(dim3(grid), dim3(T), lds, st, p, ells, e->d_ell_off, e->d_ell_vals, \
+                                                       pulses, in, store, out, direction);                           \
+    } while (0)
         // one row per lane where the rows' entries fit the register budget of that many waves (512 threads: 256 VGPRs,
         // 768: 168, 1024: 128), else two rows per lane of a 512-thread workgroup
         if (e->N <= 512) {
@@ -1505,6 +1536,9 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         } else if (e->N <= 768 && e->ell_E <= 16) {
             if (e->ell_E <= 8) KH_ELL_STORE(768, 1, 8);
             else KH_ELL_STORE(768, 1, 16);
+        } else if (e->N > 1024) {  // (<= 8 entries per row: build_ell_host)
+            if (e->N <= 1536) KH_ELL_STORE(512, 3, 8);
+            else KH_ELL_STORE(512, 4, 8);
         } else if (e->ell_E <= 8) {
             KH_ELL_STORE(1024, 1, 8);
         } else {
@@ -1743,21 +1777,25 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         const dim3 g(e->K);
         const size_t lds = kh_ell_lds_bytes();
         const bool so = u.sigma != nullptr;
-#define KH_ELL_UPDATE(T, R, EM)                                                                                                  \
-    (so ? launch_persistent<kh_ell_forward_update<T, R, EM, true>>(e, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,           \
-                            (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex)                                       \
-        : launch_persistent<kh_ell_forward_update<T, R, EM, false>>(e, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,          \
-                            (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex))
+#define KH_ELL_UPDATE_SO(T, R, EM, SO)                                                                                            \
+    (ensure_dynamic_lds(e, (const void *)kh_ell_forward_update<T, R, EM, SO>, lds) != KH_OK                                        \
+         ? KH_ERR_HIP                                                                                                              \
+         : launch_persistent<kh_ell_forward_update<T, R, EM, SO>>(e, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,            \
+                                                                  (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex))
+#define KH_ELL_UPDATE(T, R, EM) (so ? KH_ELL_UPDATE_SO(T, R, EM, true) : KH_ELL_UPDATE_SO(T, R, EM, false))
         if (e->N <= 512)
             rc = e->ell_E <= 8 ? KH_ELL_UPDATE(512, 1, 8) : e->ell_E <= 16 ? KH_ELL_UPDATE(512, 1, 16)
                  : e->ell_E <= 24 ? KH_ELL_UPDATE(512, 1, 24) : KH_ELL_UPDATE(512, 1, 32);
         else if (e->N <= 768 && e->ell_E <= 16)
             rc = e->ell_E <= 8 ? KH_ELL_UPDATE(768, 1, 8) : KH_ELL_UPDATE(768, 1, 16);
+        else if (e->N > 1024)
+            rc = e->N <= 1536 ? KH_ELL_UPDATE(512, 3, 8) : KH_ELL_UPDATE(512, 4, 8);
         else if (e->ell_E <= 8)
             rc = KH_ELL_UPDATE(1024, 1, 8);
         else
             rc = e->ell_E <= 12 ? KH_ELL_UPDATE(512, 2, 12) : KH_ELL_UPDATE(512, 2, 16);
 #undef KH_ELL_UPDATE
+#undef KH_ELL_UPDATE_SO
     } else if (e->kind != KIND_GENERIC && e->kind != KIND_COOP && e->kind != KIND_ELL && e->kind != KIND_TILEN) {
         const bool rpt2 = e->kind == KIND_TILE_RPT2;
         switch (e->L) {
@@ -2265,6 +2303,8 @@ extern "C" int kh_last_stats(kh_engine *e, double stats[4]) {
     return KH_OK;
 }
 
+extern "C" int32_t kh_ell_rows_of(int32_t N) { return N >= 1 && N <= KH_ELL_NMAX ? kh_ell_rows(N) : 0; }
+
 extern "C" int kh_ell_layout(int32_t N, int32_t n_ops, const kh_csr *ops_host, int32_t *E_out, int32_t *Ec_out, int32_t *off_out,
                              kh_cdouble *vals_out, int32_t E_cap) {
     if (ops_host == nullptr || E_out == nullptr || Ec_out == nullptr || n_ops < 1 || N < 1)
@@ -2282,8 +2322,7 @@ extern "C" int kh_ell_layout(int32_t N, int32_t n_ops, const kh_csr *ops_host, i
     std::vector<cplx> vals;
     int E = 0, Ec = 0;
     if (!build_ell_host(ptrs, N, off, vals, E, Ec))
-        return kh_fail(KH_ERR_UNSUPPORTED, "rows wider than the kernels' register budget (%d entries; %d for N > %d)", KH_ELL_EMAX,
-                       KH_ELL_EMAX2, KH_ELL_THREADS);
+        return kh_fail(KH_ERR_UNSUPPORTED, "rows wider than the kernels' register budget (%d entries for N = %d)", kh_ell_emax(N), N);
     *E_out = E;
     *Ec_out = Ec;
     if (off_out != nullptr || vals_out != nullptr) {

@@ -212,7 +212,7 @@ def test_series_tables_defect_bound_at_the_corner_of_the_numerical_range():
 
 
 def _ell_layout(ops, N):
-    """kh_ell_layout on scipy.sparse operators (None: absent) -> (E, Ec, off [E][1024], vals [n][E][1024])."""
+    """kh_ell_layout on scipy.sparse operators (None: absent) -> (E, Ec, off [E][S], vals [n][E][S]), S = kh_ell_rows_of(N)."""
     import ctypes
 
     import numpy as np
@@ -233,8 +233,10 @@ def _ell_layout(ops, N):
     rc = lib.kh_ell_layout(N, len(ops), arr, ctypes.byref(E), ctypes.byref(Ec), None, None, 0)
     if rc != 0:
         return rc, None, None, None
-    off = np.zeros((E.value, 1024), dtype=np.int32)
-    vals = np.zeros((len(ops), E.value, 1024), dtype=np.complex128)
+    S = lib.kh_ell_rows_of(N)
+    assert S >= N and S in (512, 768, 1024, 1536, 2048)
+    off = np.zeros((E.value, S), dtype=np.int32)
+    vals = np.zeros((len(ops), E.value, S), dtype=np.complex128)
     assert lib.kh_ell_layout(N, len(ops), arr, ctypes.byref(E), ctypes.byref(Ec), off.ctypes.data, vals.ctypes.data, E.value) == 0
     return E.value, Ec.value, off, vals
 
@@ -244,7 +246,7 @@ def test_sparse_row_form_reproduces_the_operators():
     a drift and two controls with different patterns (one absent in a second list), unsorted column indices and
     duplicate entries: sum_e vals[o][e][r] x[off[e][r] / 16] must be (A_o x)[r] for every operator, the entries the
     controls touch sit in the first Ec slots of EVERY row, E and Ec are multiples of four, rows are padded with their own
-    row and value zero; too wide rows and N > 1024 are refused (those engines run the generic CSR kernels)."""
+    row and value zero; too wide rows and N > 2048 are refused (those engines run the generic CSR kernels)."""
     import numpy as np
     import scipy.sparse as sp
 
@@ -291,4 +293,12 @@ def test_sparse_row_form_reproduces_the_operators():
     assert b'wider' in _lib.load().kh_last_error()
     wide16 = sp.csr_matrix(sp.random(600, 600, density=0.04, random_state=np.random.RandomState(1), format='csr') + sp.eye(600))
     assert _ell_layout([wide16.astype(complex)], 600)[0] == _lib.KH_ERR_UNSUPPORTED  # > 16 entries per row, N > 512
-    assert _ell_layout([sp.eye(1025, format='csr', dtype=complex)], 1025)[0] == _lib.KH_ERR_UNSUPPORTED
+    # 1024 < N <= 2048: three / four rows per lane, at most 8 entries per row
+    E, Ec, off, vals = _ell_layout([sp.eye(1025, format='csr', dtype=complex)], 1025)
+    assert (E, off.shape) == (4, (4, 1536))
+    E, Ec, off, vals = _ell_layout([sp.diags([1.0, 2.0, 3.0], [-1, 0, 40], shape=(1600, 1600), format='csr', dtype=complex)], 1600)
+    assert (E, off.shape) == (4, (4, 2048)) and np.abs(vals[0, :, :1600].sum(axis=0) - (np.r_[0, np.ones(1599)] + 2 + np.r_[3 * np.ones(1560), np.zeros(40)])).max() == 0
+    wide9 = sp.diags([1.0] * 9, list(range(9)), shape=(1100, 1100), format='csr', dtype=complex)
+    assert _ell_layout([wide9], 1100)[0] == _lib.KH_ERR_UNSUPPORTED  # > 8 entries per row, N > 1024
+    assert _ell_layout([sp.eye(2049, format='csr', dtype=complex)], 2049)[0] == _lib.KH_ERR_UNSUPPORTED
+    assert _lib.load().kh_ell_rows_of(2049) == 0

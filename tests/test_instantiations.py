@@ -50,6 +50,12 @@ case('ell_n600_e11_so', lambda: _banded(600, 11, nt=4, K=1), ['kh_ell_forward_up
 case('ell_n625_so', lambda: configs.config_sparse_lindblad(d=25, nt=5, K=2), ['kh_ell_forward_update<768, 1, 8, true>'], sparse=True, so=True)
 case('ell_n900_so', lambda: configs.config_sparse_lindblad(d=30, nt=4, K=1), ['kh_ell_forward_update<1024, 1, 8, true>'], sparse=True, so=True)
 
+# 1024 < N <= 2048 with at most 8 entries per row: three / four rows per lane (a d = 40 Lindbladian: N = 1600)
+case('ell_n1089', lambda: configs.config_sparse_lindblad(d=33, nt=3, K=1), ['kh_ell_sweep_store<512, 3, 8>', 'kh_ell_forward_update<512, 3, 8, false>'], sparse=True)
+case('ell_n1089_so', lambda: configs.config_sparse_lindblad(d=33, nt=3, K=1), ['kh_ell_forward_update<512, 3, 8, true>'], sparse=True, so=True)
+case('ell_n1600', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=2), ['kh_ell_sweep_store<512, 4, 8>', 'kh_ell_forward_update<512, 4, 8, false>'], sparse=True)
+case('ell_n1600_so', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=1), ['kh_ell_forward_update<512, 4, 8, true>'], sparse=True, so=True)
+
 # ---- streaming register-tile kernel (kh_tile64s.h): <controls, second order, N == 64>
 case('stream_L1_n64_so', lambda: configs.config_c5(K=520, N=64, nt=4, distinct=True), ['kh_stream_forward_update<1, true, true>'], so=True)
 case('stream_L3_n64', lambda: configs.config_c5(K=260, N=64, nt=4, L=3, distinct=True), ['kh_stream_forward_update<3, false, true>'])
