@@ -120,6 +120,35 @@ def pmc_traffic(kernel, K_loc, args):
             '(%s), not measured in this run' % (rec.get('source', 'profiles/pmc_latest.json'), rec.get('build')))
 
 
+def pmc_traffic_leg(case, kernel, intervals):
+    """The same for a side measurement: (HBM bytes per launch, source) of `kernel` (name without template arguments) from
+    the committed PMC passes of the case `case` (profiles/pmc_tile_latest.json: scripts/collect_tile_pmc.sh +
+    summarize_profiles.py; 'config4': profiles/pmc_config4_latest.json), under the same rules as the headline's -- one
+    convention for the counters, keyed on the build -- and scaled from the profiled run's intervals per launch to this
+    leg's (every kernel here streams per interval; the operators read once per sweep are < 2 % of that)."""
+    name = 'pmc_config4_latest.json' if case == 'config4' else 'pmc_tile_latest.json'
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
+    except Exception:
+        return None, 'no profiles/%s' % name
+    if rec.get('_build') != build_id():
+        return None, 'profiles/%s is from another build of the kernels (%s; this one: %s): not used' % (name, rec.get('_build'), build_id())
+    kerns = rec if case == 'config4' else rec.get(case)
+    if not kerns:
+        return None, 'profiles/%s has no case %s' % (name, case)
+    cfg = kerns.get('_config', {})
+    ran = cfg.get('intervals_per_launch') or (cfg.get('nt', 0) - 1)
+    best = None
+    for kname, c in kerns.items():
+        if kname.split('<')[0] == kernel and 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+            b = (2.0 * c['FETCH_SIZE']['avg_per_launch'] + c['WRITE_SIZE']['avg_per_launch']) * 1024.0
+            best = b if best is None else max(best, b)
+    if best is None or ran <= 0:
+        return None, 'profiles/%s, case %s: no FETCH_SIZE / WRITE_SIZE record of %s' % (name, case, kernel)
+    return best * intervals / ran, ('profiles/%s case %s (%s): rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE) on THIS build, %d '
+                                    'intervals per launch there, scaled to %d' % (name, case, cfg.get('command', 'bench.py --workload c4'), ran, intervals))
+
+
 def cpu_baseline(args):
     """Oracle in reference-structured mode on a bounded sample of the workload."""
     from krotov_amd import configs
@@ -265,8 +294,21 @@ def sparse_leg(steps=3, warmup=1):
     t_up = float(np.mean(times['update'][-steps:])) * 1e-3
     t_bw = float(np.mean(times['backward'][-steps:])) * 1e-3
     terms_per_step = stats['matvecs'] / (K * (nt - 1))  # (incl. the L control products of the update sums)
-    lds_peak = K * 128.0 * 2.4  # GB/s: the K CUs this job occupies
+    # LDS read rate of one CU per MI355X_MICROARCH.md ("64 dwords (256 B) wide per clock") x 2.4 GHz, over the K CUs this
+    # job can occupy; next to it the whole chip's (256 CUs) and the gather rate measured with the kernels' own access
+    # pattern (scripts/ubench_gather.hip -> profiles/<round>/ubench_gather.txt, committed)
+    lds_peak_cu = 256.0 * 2.4  # GB/s
+    lds_peak = K * lds_peak_cu
     credited_bytes = K * (nt - 1) * TAYLOR_DEGREE * nnz_union * 16.0
+    measured_gather = None
+    try:
+        import glob
+
+        for line in open(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'ubench_gather.txt')))[-1]):
+            if line.startswith('band') and 'E= 8 gather+fma' in line and '256 workgroups' in line:
+                measured_gather = float(line.split('workgroups')[1].split('GB/s')[0])
+    except Exception:
+        pass
     rec = {
         'workload': "reference notebook 06 (3states): K=3 density matrices, N=625 sparse Liouvillian (%d entries on the union "
                     "pattern, %.1f per row), L=2, %d time steps, chis_re with weights; propagator=DensityMatrixODEPropagator"
@@ -280,9 +322,15 @@ def sparse_leg(steps=3, warmup=1):
         'roofline': {'bound': 'lds-gather', 'kernel': 'kh_ell_forward_update',
                      'achieved': credited_bytes / t_up / 1e9, 'peak': lds_peak, 'unit': 'GB/s',
                      'frac': credited_bytes / t_up / 1e9 / lds_peak,
+                     'chip_peak': 256 * lds_peak_cu, 'chip_frac': credited_bytes / t_up / 1e9 / (256 * lds_peak_cu),
+                     'measured_gather_peak_per_cu': measured_gather,
+                     'frac_of_measured_gather': None if not measured_gather else credited_bytes / t_up / 1e9 / (K * measured_gather),
                      'note': 'credited: 14 terms x nnz x 16 B of LDS gather per propagation (SURVEY.md 8d: m = 14), over the '
-                             'LDS bandwidth of the K = 3 CUs the job can use (128 B/clk x 2.4 GHz each); the chain of terms '
-                             'is serial and one objective cannot be spread over CUs without a cross-CU exchange per term'},
+                             'LDS read rate of the K = 3 CUs the job can use (256 B/clk x 2.4 GHz each, MI355X_MICROARCH.md); '
+                             'chip_frac: over all 256 CUs -- 253 idle by construction, the chain of terms is serial and one '
+                             'objective cannot be spread over CUs without a cross-CU exchange per term; '
+                             'measured_gather_peak_per_cu: scripts/ubench_gather.hip, the kernels\' access pattern with '
+                             'nothing but the gathers and their FMAs'},
         'reference_recorded': 'the reference ran this optimisation at 23 s per iteration (12 h 53 min for 2000, notebook cell 55)',
     }
     # the 16-density-matrix ladder of scripts/perf_sparse.py (N = 625, 5.8 entries per row, 500 intervals), engine level
@@ -301,6 +349,39 @@ def sparse_leg(steps=3, warmup=1):
                             'us_per_propagation': (min(t2['backward']) + min(t2['update'])) * 1e3 / (16 * 500 * 2),
                             'round_3': '202 / 221 ms per sweep, 25 us per propagation (generic CSR kernels)'}
     e2.close()
+    tr, src = pmc_traffic_leg('sparse', 'kh_ell_forward_update', 500)
+    rec['ladder_16x625']['traffic_update_sweep'] = tr
+    rec['ladder_16x625']['traffic_source'] = src
+    # beyond 1024 rows: a d = 40 ladder (N = 1600, 5.9 entries per row), four rows per lane of 512 threads -- and the
+    # generic CSR kernels the same problem ran on before
+    spec = configs.config_sparse_lindblad(d=40, nt=101, K=3)
+    tl = spec.tlist
+    pulses = np.array([[spec.controls[0](t + 0.5 * (tl[1] - tl[0]), None) for t in tl[:-1]]])
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    lad = {}
+    for label, env in (('ell', None), ('generic', 'generic')):
+        saved = os.environ.get('KH_KERNEL')
+        if env is not None:
+            os.environ['KH_KERNEL'] = env
+        try:
+            e3 = _engine_mod.HipKrotovEngine(configs.sparse_ops(spec), np.diff(tl), is_super=True)
+        finally:
+            if env is not None:
+                if saved is None:
+                    os.environ.pop('KH_KERNEL', None)
+                else:
+                    os.environ['KH_KERNEL'] = saved
+        e3.profile = True
+        for _ in range(2):
+            chi = e3.backward(chi_T, pulses)
+            e3.forward_update(chi, np.full(3, 1.0 / 6), spec.init, pulses, np.ones((1, 100)), np.full(1, 2.0))
+        e3.check()
+        t3 = e3.kernel_times_ms()
+        lad[label] = {'kernel': e3.kernel, 'backward_sweep_ms': min(t3['backward']), 'update_sweep_ms': min(t3['update']),
+                      'us_per_propagation': (min(t3['backward']) + min(t3['update'])) * 1e3 / (3 * 100 * 2)}
+        e3.close()
+    lad['speedup'] = lad['generic']['us_per_propagation'] / lad['ell']['us_per_propagation']
+    rec['ladder_3x1600'] = lad
     return rec
 
 
@@ -624,7 +705,7 @@ def main():
             return out
         return None
 
-    def leg(scaling='strong', env=None, **overrides):
+    def leg(scaling='strong', env=None, pmc_case=None, **overrides):
         """A short extra measurement in this process with some arguments (and environment switches) changed;
         everything is put back afterwards.  Returns the reduced record that goes into the headline line."""
         saved = {k: getattr(args, k) for k in ('workload', 'K', 'N', 'nt', 'L', 'distinct', 'steps', 'warmup',
@@ -647,6 +728,9 @@ def main():
             for k in ('ranks', 'predicted'):
                 if k in line:
                     rec[k] = line[k]
+            if pmc_case is not None:
+                rec['roofline']['traffic'], rec['roofline']['traffic_source'] = pmc_traffic_leg(
+                    pmc_case, line['roofline']['kernel'], line['config']['time_steps'])
             return rec
         except Exception as exc:  # (the headline line must not depend on a side measurement)
             if world > 1:
@@ -736,15 +820,18 @@ def main():
             # three iterations after the headline measurement, in this process (a second process on the GPU while this
             # one holds its context measured 2x slower): so that the default line -- the one the driver records -- also
             # carries a number for the one workload whose propagator is a dense product.  Not part of `value`.
-            out['config4'] = leg(workload='c4', steps=3, warmup=1)
+            out['config4'] = leg(workload='c4', steps=3, warmup=1, pmc_case='config4')
         if not args.no_variants:
             # "L=1 (also report L=4)" and "a second variant with K distinct random H0_k"
-            out['L4'] = leg(L=4, steps=3, warmup=1)
+            out['L4'] = leg(L=4, steps=3, warmup=1, pmc_case='L4')
             out['distinct'] = leg(distinct=True, steps=3, warmup=1)
             # per-objective operators beyond the N <= 64 register tiles (kh_tilen.h: the generator in registers up to N = 128)
-            out['N96'] = leg(N=96, steps=3, warmup=1)
-            # an ensemble that does not fit the GPU's co-resident workgroups: the operators are streamed (kh_tile64s.h)
-            out['K1024'] = leg(K=1024, steps=2, warmup=1)
+            out['N96'] = leg(N=96, steps=3, warmup=1, pmc_case='N96')
+            # an ensemble that does not fit the GPU's co-resident workgroups: one drift and scaled control operators run
+            # the update sweep on the matrix cores, several objectives per workgroup (kh_ens.h); per-objective drifts
+            # stream their operators (kh_tile64s.h) -- SURVEY.md 8d asks for both
+            out['K1024'] = leg(K=1024, steps=2, warmup=1, pmc_case='K1024')
+            out['K1024_distinct'] = leg(K=1024, distinct=True, steps=2, warmup=1, pmc_case='K1024_distinct')
         if not args.no_sparse:
             try:
                 out['sparse'] = sparse_leg()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sparse (CSR) vs dense operators on a damped d-level ladder in Liouville space (N = d^2), engine level
-(dev tool, GPU only).  usage: python scripts/perf_sparse.py [d] [nt] [K]"""
+(dev tool, GPU only).  usage: python scripts/perf_sparse.py [d] [nt] [K] [csr]"""
 import os
 import sys
 
@@ -21,8 +21,11 @@ S, lam = np.ones((1, nt - 1)), np.full(1, 2.0)
 chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
 norms = np.full(K, 1.0 / (2 * K))
 results = {}
-for label, ops in (('csr', configs.sparse_ops(spec)),
-                   ('dense', [[spec.H0[k], spec.Hc[k][0]] for k in range(K)])):
+only_csr = len(sys.argv) > 4 and sys.argv[4] == 'csr'  # (profiling runs: no dense comparison)
+cases = [('csr', configs.sparse_ops(spec))]
+if not only_csr:
+    cases.append(('dense', [[spec.H0[k], spec.Hc[k][0]] for k in range(K)]))
+for label, ops in cases:
     eng = HipKrotovEngine(ops, np.diff(tl), is_super=True)
     eng.profile = True
     for _ in range(2):
@@ -36,4 +39,5 @@ for label, ops in (('csr', configs.sparse_ops(spec)),
         label, eng.kernel, spec.N, K, nt, nnz / spec.N, min(t['backward']), min(t['update']),
         eng.stats()['matvecs'] / (K * (nt - 1))))
     eng.close()
-print('max |pulse difference| csr vs dense: %.2e' % np.abs(results['csr'][0] - results['dense'][0]).max())
+if not only_csr:
+    print('max |pulse difference| csr vs dense: %.2e' % np.abs(results['csr'][0] - results['dense'][0]).max())

@@ -34,7 +34,14 @@ cfg = bench['config']
 sys.path.insert(0, ROOT)
 import bench as _bench  # (build_id(): kh_version + hash of the kernel sources -- the record is only used by the same build)
 
+# ONE convention for the memory-side counters, here and in bench.py (pmc_traffic / pmc_traffic_leg), DESIGN.md and commit
+# messages: the JSON files hold the RAW counter values (KB, averaged per launch); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x
+# 1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-byte requests of wide coalesced reads at 64
+# bytes), WRITE_SIZE as reported.
+CONVENTION = ('raw rocprofv3 counter values, KB per launch; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 '
+              '(FETCH_SIZE doubled per MI355X_MICROARCH.md, gfx950)')
 latest = {
+    'convention': CONVENTION,
     'source': 'profiles/%s/pmc_summary.json' % tag,
     'build': bench.get('roofline', {}).get('build') or _bench.build_id(),
     'config': {'K': cfg['objectives'], 'N': cfg['N'], 'nt': cfg['time_steps'] + 1, 'L': cfg['controls']},
@@ -86,29 +93,55 @@ if os.path.isdir(cdir):
             if kern.startswith('kh_coop'):
                 for c, v in ctrs.items():
                     c4sum.setdefault(kern, {})[c] = {'avg_per_launch': sum(v) / len(v), 'launches': len(v)}
+    c4sum['_build'] = _bench.build_id()
+    c4sum['_convention'] = CONVENTION
+    c4sum['_config'] = {'workload': 'c4', 'intervals_per_launch': 1000}
     json.dump(c4sum, open(os.path.join(dst, 'pmc_config4.json'), 'w'), indent=1, sort_keys=True)
+    shutil.copy(os.path.join(dst, 'pmc_config4.json'), os.path.join(ROOT, 'profiles', 'pmc_config4_latest.json'))
+    c4sum = {k: v for k, v in c4sum.items() if not k.startswith('_')}
     for kern, c in c4sum.items():
         print(kern, {k: '%.3g' % v['avg_per_launch'] for k, v in c.items()})
 
 # PMC passes of the kernels the headline does not launch (scripts/collect_tile_pmc.sh <tag>) -> profiles/<tag>/pmc_tile.json
 tdir = os.path.join(src, 'tile_pmc')
 if os.path.isdir(tdir):
-    tsum = {}
+    tsum = {'_build': _bench.build_id(), '_convention': CONVENTION}
     for sub in sorted(os.listdir(tdir)):
         path = os.path.join(tdir, sub, 'b_counter_collection.csv')
         if not os.path.exists(path):
             continue
         case = sub.rsplit('_', 1)[0]
+        cmd_path = os.path.join(tdir, case + '.cmd')
+        if os.path.exists(cmd_path) and case not in tsum:
+            # what was profiled (scripts/collect_tile_pmc.sh writes the command line): the workload a leg's traffic is
+            # scaled from (bench.py pmc_traffic_leg: bytes per INTERVAL x the leg's intervals)
+            words = open(cmd_path).read().split()
+            script, a = os.path.basename(words[0]), words[1:]
+            if script == 'perf_sweeps.py':
+                cfg_case = {'K': int(a[0]), 'N': int(a[1]), 'nt': int(a[2]), 'L': int(a[3]), 'distinct': 'distinct' in a[4:]}
+            else:  # perf_sparse.py d nt K
+                cfg_case = {'d': int(a[0]), 'N': int(a[0]) ** 2, 'nt': int(a[1]), 'K': int(a[2]), 'L': 1}
+            tsum.setdefault(case, {})['_config'] = dict(cfg_case, command=' '.join([script] + a))
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(path)):
             agg[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
         for kern, ctrs in agg.items():
-            if kern.startswith(('kh_tile', 'kh_q2', 'kh_ell', 'kh_gen')):
+            if kern.startswith(('kh_tile', 'kh_q2', 'kh_ell', 'kh_gen', 'kh_ens', 'kh_stream', 'kh_tn')):
                 for c, v in ctrs.items():
                     tsum.setdefault(case, {}).setdefault(kern, {})[c] = {'avg_per_launch': sum(v) / len(v), 'launches': len(v)}
     json.dump(tsum, open(os.path.join(dst, 'pmc_tile.json'), 'w'), indent=1, sort_keys=True)
+    shutil.copy(os.path.join(dst, 'pmc_tile.json'), os.path.join(ROOT, 'profiles', 'pmc_tile_latest.json'))  # (bench.py: the legs' traffic)
     for case, kerns in tsum.items():
+        if case.startswith('_'):
+            continue
         for kern, c in kerns.items():
+            if kern.startswith('_'):
+                continue
             if 'SQ_WAVE_CYCLES' in c:
                 wc = c['SQ_WAVE_CYCLES']['avg_per_launch']
                 print(case, kern, {k: round(100 * v['avg_per_launch'] / wc, 1) for k, v in c.items() if k.startswith('SQ_') and k not in ('SQ_WAVE_CYCLES',)})
+
+# other artefacts of a round's collection, copied as they are
+for name in ('ubench_gather.txt', 'config4_timing.txt', 'kernel_resources.txt', 'exp_ens.txt'):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))

@@ -19,6 +19,14 @@ def _banded(N, bands, nt, K=2):
     return make(N, bands, nt, K=K)
 
 
+def _drop_controls(spec, which):
+    """Objectives `which` lose their control operator: a zero matrix for the oracle, ``None`` (absent) for the engine."""
+    for k in which:
+        spec.Hc[k] = [np.zeros_like(spec.Hc[k][0])]
+    spec.absent_controls = set(which)
+    return spec
+
+
 def _shared(K, N, L):
     return configs.config_shared(K=K, N=N, nt=4, L=L)
 
@@ -57,14 +65,21 @@ case('ell_n1600', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=2), ['kh_
 case('ell_n1600_so', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=1), ['kh_ell_forward_update<512, 4, 8, true>'], sparse=True, so=True)
 
 # ---- streaming register-tile kernel (kh_tile64s.h): <controls, second order, N == 64>
-case('stream_L1_n64_so', lambda: configs.config_c5(K=520, N=64, nt=4, distinct=True), ['kh_stream_forward_update<1, true, true>'], so=True)
-case('stream_L3_n64', lambda: configs.config_c5(K=260, N=64, nt=4, L=3, distinct=True), ['kh_stream_forward_update<3, false, true>'])
-case('stream_L3_n64_so', lambda: configs.config_c5(K=260, N=64, nt=4, L=3, distinct=True), ['kh_stream_forward_update<3, true, true>'], so=True)
-case('stream_L3_n6_so', lambda: configs.config_c5(K=1100, N=6, nt=5, L=3), ['kh_stream_forward_update<3, true, false>'], so=True)
-case('stream_L4_n64', lambda: configs.config_c5(K=260, N=64, nt=4, L=4, distinct=True), ['kh_stream_forward_update<4, false, true>'])
-case('stream_L4_n64_so', lambda: configs.config_c5(K=260, N=64, nt=4, L=4, distinct=True), ['kh_stream_forward_update<4, true, true>'], so=True)
-case('stream_L4_n8', lambda: configs.config_c5(K=270, N=8, nt=6, L=4), ['kh_stream_forward_update<4, false, false>'])
-case('stream_L4_n8_so', lambda: configs.config_c5(K=270, N=8, nt=6, L=4), ['kh_stream_forward_update<4, true, false>'], so=True)
+_k520 = lambda: configs.config_c5(K=520, N=64, nt=6, distinct=True)  # noqa: E731  (three objectives per workgroup)
+case('stream_L1_n64_pf', _k520, ['kh_stream_forward_update<1, false, true, true>'])  # tiles prefetched through LDS (LDS-DMA)
+case('stream_L1_n64_pf_so', _k520, ['kh_stream_forward_update<1, true, true, true>'], so=True)
+case('stream_L1_n64_no_pf', _k520, ['kh_stream_forward_update<1, false, true, false>'], env={'KH_STREAM_PF': '0'})
+case('stream_L1_n64_no_pf_so', _k520, ['kh_stream_forward_update<1, true, true, false>'], env={'KH_STREAM_PF': '0'}, so=True)
+# ... with a ragged tail (the last workgroups own one objective less) and objectives without the control operator
+case('stream_L1_n64_pf_ragged', lambda: _drop_controls(configs.config_c5(K=600, N=64, nt=5, distinct=True), (0, 257, 599)),
+     ['kh_stream_forward_update<1, false, true, true>'], env={'KH_STREAM_G': '256'})  # 256 x 2 + 88: three and two per workgroup
+case('stream_L3_n64', lambda: configs.config_c5(K=260, N=64, nt=4, L=3, distinct=True), ['kh_stream_forward_update<3, false, true, false>'])
+case('stream_L3_n64_so', lambda: configs.config_c5(K=260, N=64, nt=4, L=3, distinct=True), ['kh_stream_forward_update<3, true, true, false>'], so=True)
+case('stream_L3_n6_so', lambda: configs.config_c5(K=1100, N=6, nt=5, L=3), ['kh_stream_forward_update<3, true, false, false>'], so=True)
+case('stream_L4_n64', lambda: configs.config_c5(K=260, N=64, nt=4, L=4, distinct=True), ['kh_stream_forward_update<4, false, true, false>'])
+case('stream_L4_n64_so', lambda: configs.config_c5(K=260, N=64, nt=4, L=4, distinct=True), ['kh_stream_forward_update<4, true, true, false>'], so=True)
+case('stream_L4_n8', lambda: configs.config_c5(K=270, N=8, nt=6, L=4), ['kh_stream_forward_update<4, false, false, false>'])
+case('stream_L4_n8_so', lambda: configs.config_c5(K=270, N=8, nt=6, L=4), ['kh_stream_forward_update<4, true, false, false>'], so=True)
 
 # ---- two-terms-per-phase kernels (kh_tile64q2.h): <second order, sums on the adjoint side, single GPU>; the forms with the
 # cross-GPU stage run on one GPU with KH_Q2_SINGLE=0 (and across ranks in test_two_ranks_sharded_on_one_gpu)
@@ -117,7 +132,8 @@ def test_instantiation_vs_oracle(name, monkeypatch):
     if sparse:
         ops = configs.sparse_ops(spec)
     else:
-        ops = [[spec.H0[k]] + [spec.Hc[k][l] for l in range(spec.L)] for k in range(spec.K)]
+        absent = getattr(spec, 'absent_controls', ())
+        ops = [[spec.H0[k]] + [None if k in absent else spec.Hc[k][l] for l in range(spec.L)] for k in range(spec.K)]
     eng = HipKrotovEngine(ops, np.diff(spec.tlist), is_super=spec.is_super)
     _lib.forget_launched_kernels()
     rng = np.random.default_rng(17)
