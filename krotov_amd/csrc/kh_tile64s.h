@@ -21,7 +21,6 @@
 #include "kh_tile64.h"
 
 #define KH_STREAM_MMAX 16  // objectives per workgroup (LDS: 2 KiB each)
-#define KH_STREAM_MMAX_PF 8  // ... of the instantiations that prefetch the tiles through LDS (128 KiB of staging)
 #ifndef KH_TIMING_WG
 #define KH_TIMING_WG 0
 #endif
@@ -58,30 +57,12 @@ __device__ __forceinline__ void kh_stream_load_op(const cplx *op, int N, int wav
     }
 }
 
-// LDS-DMA of 16 bytes per lane: global gsrc (per lane) -> LDS lds_dst + 16 lane (lds_dst: wave-uniform byte address).  Inline
-// assembly on purpose: a load the compiler knows to be writing LDS makes it drain vmcnt in front of every barrier, and
-// the point of the prefetch is to stay in flight across the products' barriers.  (M0 is the destination base and is
-// not preserved around a statement: written and restored inside it -- cdna_hip_programming.md, "LDS-DMA recipe".)
-__device__ __forceinline__ void kh_glds16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
-// PF (one control, N = 64): the NEXT objective's two tiles travel into an LDS staging area (2 x 64 KiB, lane-linear:
-// every wave fetches and later reads its own 16 KiB, so no barrier is involved) while the current objective's products
-// run; a tile set is then 16 conflict-free ds_read_b128 per lane instead of a ~2.3 us wait for the memory side
-// (K = 1024 distinct drifts: 9.4 of 36 us per interval were that wait, docs/HISTORY.md R5.3).
-template <int LT, bool SO, bool N64, bool PF = false>
+template <int LT, bool SO, bool N64>
 __global__ void __launch_bounds__(512, 2)
 kh_stream_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
-    static_assert(!PF || (N64 && LT == 1), "the staging area holds two 64 x 64 tiles");
     constexpr int WAVES = 8;
-    constexpr int MM = PF ? KH_STREAM_MMAX_PF : KH_STREAM_MMAX;
     typedef KhTileOps<1, LT, 0> Tiles;
-    __shared__ __attribute__((aligned(16))) cplx bufs[MM][2][KH_TILE_N];
+    __shared__ __attribute__((aligned(16))) cplx bufs[KH_STREAM_MMAX][2][KH_TILE_N];
     __shared__ __attribute__((aligned(16))) double red[WAVES][LT];
     __shared__ __attribute__((aligned(16))) double D_sh[2][LT + 1];
     __shared__ __attribute__((aligned(16))) double ok_sh[2][LT];
@@ -107,44 +88,6 @@ kh_stream_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
 #pragma unroll
         for (int o = 0; o <= LT; ++o) {
             kh_stream_load_op<N64>(ops_k[o], N, wave, lane, h.reg[o]);
-        }
-    };
-    // ---- PF: staging area [(1 + LT) * 8][512] elements behind the static LDS; element (o, j) of lane tid at ((o 8 + j) 512 + tid)
-    const cplx *stage = kh_tile_dyn_lds;
-    bool staged_ctl = true;  // (uniform) the staged objective has the control operator
-    // issue the fetch of objective k's tiles (this wave's share: 16 KiB); the staging area must have been read before
-    auto prefetch = [&](int k) {
-        if constexpr (PF) {
-            // (the pointer table through a provably uniform address: scalar loads -- a vector load here would make the
-            // compiler wait for "its" load with vmcnt(0), i.e. for the DMA issued in front of it)
-            const cplx *const *ops_k = p.ops + (size_t)__builtin_amdgcn_readfirstlane(k) * (1 + LT);
-            const cplx *ops_o[1 + LT];
-#pragma unroll
-            for (int o = 0; o <= LT; ++o) ops_o[o] = ops_k[o];
-            const int cgl = KhTileLanes::cg(lane), rowl = KhTile<1>::row_in(wave, lane, 0);
-            const unsigned base = (unsigned)(size_t)stage + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 64u * (unsigned)sizeof(cplx);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's reads of the area have returned)
-            staged_ctl = ops_o[1] != nullptr;
-#pragma unroll
-            for (int o = 0; o <= LT; ++o) {
-                const cplx *op = ops_o[o];
-                if (op == nullptr) continue;  // (uniform)
-                const cplx *src = op + (unsigned)kh_launder(rowl * KH_TILE_N + cgl);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    kh_glds16(src + 8 * j, base + (unsigned)((o * 8 + j) * 512) * (unsigned)sizeof(cplx));
-            }
-        }
-    };
-    // the staged tiles -> registers (waits for this wave's DMA)
-    auto take_tiles = [&](Tiles &h) {
-        if constexpr (PF) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int o = 0; o <= LT; ++o)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    h.reg[o][0][j] = (o == 0 || staged_ctl) ? stage[(size_t)(o * 8 + j) * 512 + tid] : c_make(0.0, 0.0);
         }
     };
     // wave-level pieces of  Im(mu <bra | H_l phi>)  of one objective -> red[wave][l]; phi in x (LDS); chi (second order:
@@ -200,7 +143,6 @@ kh_stream_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
     }
     int m_loaded = -1;
     double dt = 0.0;
-    if (PF && mw > 0 && u.n_begin < u.n_end) prefetch(w);  // the first interval's first objective
 
     // objective j of this workgroup over interval n
     auto step = [&](Tiles &hc, int n, int j) -> bool {
@@ -209,13 +151,7 @@ kh_stream_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         const long long tk0 = wall_clock64();
         long long tkg = tk0;
 #endif
-        // PF: the tiles of (n, j) are staged; the fetch of the next objective's -- (n, j + 1), or (n + 1, 0): the operators do
-        // not depend on the pulse -- is issued right in front of this objective's products (below): behind every small
-        // load of the step, whose compiler-placed vmcnt(0) would otherwise wait for the DMA too
-        if constexpr (PF)
-            take_tiles(hc);
-        else if (j > 0)
-            load_tiles(hc, k);
+        if (j > 0) load_tiles(hc, k);
         if (j == 0) {
             const int par = n & 1;
             // ---- cross-objective sum (optimize.py:470) ----
@@ -250,8 +186,8 @@ kh_stream_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
                         ok_sh[par][l] = ok ? 1.0 : 0.0;
                     }
                 }
-                if constexpr (!PF) load_tiles(hc, k);
-            } else if constexpr (!PF) {
+                load_tiles(hc, k);
+            } else {
                 load_tiles(hc, k);
             }
 #ifdef KH_TIMING
@@ -311,9 +247,6 @@ kh_stream_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         }
         cplx state[1];
         state[0] = bufs[j][cur][row];
-        if constexpr (PF) {
-            if (j + 1 < mw || n + 1 < u.n_end) prefetch(w + (j + 1 < mw ? j + 1 : 0) * G);
-        }
         // the generator takes the drift's registers: H_0 is fetched again for the next interval anyway
         hc.build(eps, hc.reg[0]);
         matvecs += kh_tile_expm_action<1>(hc.reg[0], state, bufs[j], inv_sh, cur, p.fre, p.fim, dt, nsub, m, wave, lane);

@@ -167,7 +167,6 @@ struct kh_engine {
     bool q2_single = true;       // KH_Q2_SINGLE=0: the instantiations with the cross-GPU stage on one GPU too (A/B)
     bool tile_single = true;     // KH_TILE_SINGLE=0: the same for the one-term-per-phase kernels
     bool coop_single = true;     // KH_COOP_SINGLE=0: the same for the cooperative kernels' adjoint-side form
-    bool stream_pf = true;       // KH_STREAM_PF=0: the streaming kernel without the tile prefetch through LDS (A/B)
     // fault injection for the sharded protocol (tests): rank KH_P2P_FAIL_RANK withholds its GPU's sum at interval
     // KH_P2P_FAIL_AT of its KH_P2P_FAIL_SWEEP-th update sweep through the peer windows (1-based; default 1)
     int p2p_fail_at = -1, p2p_fail_rank = 0, p2p_fail_sweep = 1, p2p_sweeps = 0;
@@ -786,7 +785,6 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     if (const char *d = getenv("KH_Q2_SINGLE")) e->q2_single = atoi(d) != 0;
     if (const char *d = getenv("KH_TILE_SINGLE")) e->tile_single = atoi(d) != 0;
     if (const char *d = getenv("KH_COOP_SINGLE")) e->coop_single = atoi(d) != 0;
-    if (const char *d = getenv("KH_STREAM_PF")) e->stream_pf = atoi(d) != 0;
     if (const char *d = getenv("KH_P2P_FAIL_AT")) e->p2p_fail_at = atoi(d);
     if (const char *d = getenv("KH_P2P_FAIL_RANK")) e->p2p_fail_rank = atoi(d);
     if (const char *d = getenv("KH_P2P_FAIL_SWEEP")) e->p2p_fail_sweep = atoi(d);
@@ -1716,17 +1714,6 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
     (so ? launch_persistent<kh_stream_forward_update<LT, true, N64>>(e, g, b, 0, st, p, u, exs)                   \
         : launch_persistent<kh_stream_forward_update<LT, false, N64>>(e, g, b, 0, st, p, u, exs))
 #define KH_STREAM_UPDATE(LT) (e->N == KH_TILE_N ? KH_STREAM_UPDATE_N(LT, true) : KH_STREAM_UPDATE_N(LT, false))
-        // one control, N = 64, at most 8 objectives per workgroup: the next objective's tiles are prefetched through an LDS
-        // staging area of 128 KiB (KH_STREAM_PF=0: off, A/B)
-        const size_t pf_lds = (size_t)2 * KH_TILE_N * KH_TILE_N * sizeof(cplx);
-        const bool pf = e->L == 1 && e->N == KH_TILE_N && (e->K + G - 1) / G <= KH_STREAM_MMAX_PF && e->stream_pf;
-        if (pf) {
-            rc = ensure_dynamic_lds(e, so ? (const void *)kh_stream_forward_update<1, true, true, true>
-                                          : (const void *)kh_stream_forward_update<1, false, true, true>, pf_lds);
-            if (rc != KH_OK) return rc;
-            rc = so ? launch_persistent<kh_stream_forward_update<1, true, true, true>>(e, g, b, pf_lds, st, p, u, exs)
-                    : launch_persistent<kh_stream_forward_update<1, false, true, true>>(e, g, b, pf_lds, st, p, u, exs);
-        } else
         switch (e->L) {
             case 1: rc = KH_STREAM_UPDATE(1); break;
             case 2: rc = KH_STREAM_UPDATE(2); break;

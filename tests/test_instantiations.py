@@ -66,20 +66,17 @@ case('ell_n1600_so', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=1), ['
 
 # ---- streaming register-tile kernel (kh_tile64s.h): <controls, second order, N == 64>
 _k520 = lambda: configs.config_c5(K=520, N=64, nt=6, distinct=True)  # noqa: E731  (three objectives per workgroup)
-case('stream_L1_n64_pf', _k520, ['kh_stream_forward_update<1, false, true, true>'])  # tiles prefetched through LDS (LDS-DMA)
-case('stream_L1_n64_pf_so', _k520, ['kh_stream_forward_update<1, true, true, true>'], so=True)
-case('stream_L1_n64_no_pf', _k520, ['kh_stream_forward_update<1, false, true, false>'], env={'KH_STREAM_PF': '0'})
-case('stream_L1_n64_no_pf_so', _k520, ['kh_stream_forward_update<1, true, true, false>'], env={'KH_STREAM_PF': '0'}, so=True)
+case('stream_L1_n64_so', _k520, ['kh_stream_forward_update<1, true, true>'], so=True)
 # ... with a ragged tail (the last workgroups own one objective less) and objectives without the control operator
-case('stream_L1_n64_pf_ragged', lambda: _drop_controls(configs.config_c5(K=600, N=64, nt=5, distinct=True), (0, 257, 599)),
-     ['kh_stream_forward_update<1, false, true, true>'], env={'KH_STREAM_G': '256'})  # 256 x 2 + 88: three and two per workgroup
-case('stream_L3_n64', lambda: configs.config_c5(K=260, N=64, nt=4, L=3, distinct=True), ['kh_stream_forward_update<3, false, true, false>'])
-case('stream_L3_n64_so', lambda: configs.config_c5(K=260, N=64, nt=4, L=3, distinct=True), ['kh_stream_forward_update<3, true, true, false>'], so=True)
-case('stream_L3_n6_so', lambda: configs.config_c5(K=1100, N=6, nt=5, L=3), ['kh_stream_forward_update<3, true, false, false>'], so=True)
-case('stream_L4_n64', lambda: configs.config_c5(K=260, N=64, nt=4, L=4, distinct=True), ['kh_stream_forward_update<4, false, true, false>'])
-case('stream_L4_n64_so', lambda: configs.config_c5(K=260, N=64, nt=4, L=4, distinct=True), ['kh_stream_forward_update<4, true, true, false>'], so=True)
-case('stream_L4_n8', lambda: configs.config_c5(K=270, N=8, nt=6, L=4), ['kh_stream_forward_update<4, false, false, false>'])
-case('stream_L4_n8_so', lambda: configs.config_c5(K=270, N=8, nt=6, L=4), ['kh_stream_forward_update<4, true, false, false>'], so=True)
+case('stream_L1_n64_ragged', lambda: _drop_controls(configs.config_c5(K=600, N=64, nt=5, distinct=True), (0, 257, 599)),
+     ['kh_stream_forward_update<1, false, true>'], env={'KH_STREAM_G': '256'})  # 256 x 2 + 88: three and two per workgroup
+case('stream_L3_n64', lambda: configs.config_c5(K=260, N=64, nt=4, L=3, distinct=True), ['kh_stream_forward_update<3, false, true>'])
+case('stream_L3_n64_so', lambda: configs.config_c5(K=260, N=64, nt=4, L=3, distinct=True), ['kh_stream_forward_update<3, true, true>'], so=True)
+case('stream_L3_n6_so', lambda: configs.config_c5(K=1100, N=6, nt=5, L=3), ['kh_stream_forward_update<3, true, false>'], so=True)
+case('stream_L4_n64', lambda: configs.config_c5(K=260, N=64, nt=4, L=4, distinct=True), ['kh_stream_forward_update<4, false, true>'])
+case('stream_L4_n64_so', lambda: configs.config_c5(K=260, N=64, nt=4, L=4, distinct=True), ['kh_stream_forward_update<4, true, true>'], so=True)
+case('stream_L4_n8', lambda: configs.config_c5(K=270, N=8, nt=6, L=4), ['kh_stream_forward_update<4, false, false>'])
+case('stream_L4_n8_so', lambda: configs.config_c5(K=270, N=8, nt=6, L=4), ['kh_stream_forward_update<4, true, false>'], so=True)
 
 # ---- two-terms-per-phase kernels (kh_tile64q2.h): <second order, sums on the adjoint side, single GPU>; the forms with the
 # cross-GPU stage run on one GPU with KH_Q2_SINGLE=0 (and across ranks in test_two_ranks_sharded_on_one_gpu)
