@@ -47,6 +47,8 @@ from .conversions import (
 )
 from ._lib import KrotovHipError as _KrotovHipError
 from ._lib import KH_ERR_TIMEOUT as _KH_ERR_TIMEOUT, KH_ERR_UNSUPPORTED as _KH_ERR_UNSUPPORTED
+
+_KH_MAX_CONTROLS = 8  # KH_MAX_L of krotov_amd/csrc/kh_common.h
 from .info_hooks import chain
 from .mu import derivative_wrt_pulse
 from .parallelization import serial_map
@@ -803,6 +805,13 @@ def optimize_pulses(
             continue_from, objectives, tlist, store_all_pulses
         )
     g_a_integrals = np.zeros(len(guess_pulses))
+    if device_path and len(guess_pulses) > _KH_MAX_CONTROLS and process_group is None:
+        # the sweep kernels are compiled for at most 8 controls (KH_MAX_L); the reference takes any number
+        # (optimize.py:33-55, conversions.py:140-254).  More than that runs the reference's own structure: the host loop
+        # around single-interval propagations (each of them on the GPU) -- correct, and slow
+        logger.warning("%d controls: the device sweeps take at most %d; running the host loop around single-step "
+                       "propagations on the GPU", len(guess_pulses), _KH_MAX_CONTROLS)
+        device_path = False
 
     if continue_from is None:
         result = Result()

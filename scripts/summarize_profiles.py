@@ -9,6 +9,27 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_counters(dirpath):
+    """{kernel name with template arguments: {counter: (average per launch, launches)}} of one rocprofv3 --pmc pass:
+    from its b_counter_collection.csv, or from the b_counter_summary.json scripts/slim_counters.py left in its place."""
+    out = collections.defaultdict(dict)
+    js = os.path.join(dirpath, 'b_counter_summary.json')
+    path = os.path.join(dirpath, 'b_counter_collection.csv')
+    if os.path.exists(js):
+        for kern, ctrs in json.load(open(js)).items():
+            for c, v in ctrs.items():
+                out[kern.split('(')[0].replace('void ', '')][c] = (v['avg_per_launch'], v['launches'])
+    elif os.path.exists(path):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(path)):
+            agg[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
+        for kern, ctrs in agg.items():
+            for c, v in ctrs.items():
+                out[kern][c] = (sum(v) / len(v), len(v))
+    return out
+
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 src = os.path.join(ROOT, 'gpurun_out', tag)
 dst = os.path.join(ROOT, 'profiles', tag)
@@ -18,17 +39,16 @@ shutil.copy(os.path.join(src, 'bench_n1.json'), os.path.join(dst, 'bench_n1.json
 bench = json.loads(open(os.path.join(src, 'bench_n1.json')).read().strip())
 summary = {}
 for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_lds'):
-    path = os.path.join(src, sub, 'b_counter_collection.csv')
-    if not os.path.exists(path):
-        continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(path)):
-        agg[r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
-    for kern, ctrs in agg.items():
+    for kern_full, ctrs in load_counters(os.path.join(src, sub)).items():
+        kern = kern_full.split('<')[0]
         if not kern.startswith('kh_'):
             continue
-        for c, v in ctrs.items():
-            summary.setdefault(kern, {})[c] = {'avg_per_launch': sum(v) / len(v), 'launches': len(v)}
+        for c, (avg, n) in ctrs.items():
+            prev = summary.setdefault(kern, {}).get(c)
+            if prev is not None:  # (several instantiations of one kernel in the run: launch-weighted)
+                avg = (prev['avg_per_launch'] * prev['launches'] + avg * n) / (prev['launches'] + n)
+                n += prev['launches']
+            summary[kern][c] = {'avg_per_launch': avg, 'launches': n}
 json.dump(summary, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
 cfg = bench['config']
 sys.path.insert(0, ROOT)
@@ -83,16 +103,13 @@ cdir = os.path.join(src, 'c4_pmc')
 if os.path.isdir(cdir):
     c4sum = {}
     for sub in sorted(os.listdir(cdir)):
-        path = os.path.join(cdir, sub, 'b_counter_collection.csv')
-        if not os.path.exists(path):
+        if not os.path.isdir(os.path.join(cdir, sub)):
             continue
-        agg = collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(path)):
-            agg[r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
-        for kern, ctrs in agg.items():
+        for kern_full, ctrs in load_counters(os.path.join(cdir, sub)).items():
+            kern = kern_full.split('<')[0]
             if kern.startswith('kh_coop'):
-                for c, v in ctrs.items():
-                    c4sum.setdefault(kern, {})[c] = {'avg_per_launch': sum(v) / len(v), 'launches': len(v)}
+                for c, (avg, n) in ctrs.items():
+                    c4sum.setdefault(kern, {})[c] = {'avg_per_launch': avg, 'launches': n}
     c4sum['_build'] = _bench.build_id()
     c4sum['_convention'] = CONVENTION
     c4sum['_config'] = {'workload': 'c4', 'intervals_per_launch': 1000}
@@ -107,8 +124,7 @@ tdir = os.path.join(src, 'tile_pmc')
 if os.path.isdir(tdir):
     tsum = {'_build': _bench.build_id(), '_convention': CONVENTION}
     for sub in sorted(os.listdir(tdir)):
-        path = os.path.join(tdir, sub, 'b_counter_collection.csv')
-        if not os.path.exists(path):
+        if not os.path.isdir(os.path.join(tdir, sub)):
             continue
         case = sub.rsplit('_', 1)[0]
         cmd_path = os.path.join(tdir, case + '.cmd')
@@ -122,13 +138,10 @@ if os.path.isdir(tdir):
             else:  # perf_sparse.py d nt K
                 cfg_case = {'d': int(a[0]), 'N': int(a[0]) ** 2, 'nt': int(a[1]), 'K': int(a[2]), 'L': 1}
             tsum.setdefault(case, {})['_config'] = dict(cfg_case, command=' '.join([script] + a))
-        agg = collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(path)):
-            agg[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
-        for kern, ctrs in agg.items():
-            if kern.startswith(('kh_tile', 'kh_q2', 'kh_ell', 'kh_gen', 'kh_ens', 'kh_stream', 'kh_tn')):
-                for c, v in ctrs.items():
-                    tsum.setdefault(case, {}).setdefault(kern, {})[c] = {'avg_per_launch': sum(v) / len(v), 'launches': len(v)}
+        for kern, ctrs in load_counters(os.path.join(tdir, sub)).items():
+            if kern.startswith(('kh_tile', 'kh_q2_sweep', 'kh_q2_forward', 'kh_ell', 'kh_gen', 'kh_ens_forward', 'kh_stream', 'kh_tn_sweep', 'kh_tn_forward')):
+                for c, (avg, n) in ctrs.items():
+                    tsum.setdefault(case, {}).setdefault(kern, {})[c] = {'avg_per_launch': avg, 'launches': n}
     json.dump(tsum, open(os.path.join(dst, 'pmc_tile.json'), 'w'), indent=1, sort_keys=True)
     shutil.copy(os.path.join(dst, 'pmc_tile.json'), os.path.join(ROOT, 'profiles', 'pmc_tile_latest.json'))  # (bench.py: the legs' traffic)
     for case, kerns in tsum.items():

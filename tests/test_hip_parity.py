@@ -766,6 +766,25 @@ def _optimize_on_device(spec, iters, **kw):
         iter_stop=iters, store_all_pulses=True, **kw)
 
 
+def test_more_controls_than_the_kernels_take(caplog):
+    """The reference takes any number of controls (optimize.py:33-55); the sweep kernels are compiled for 8.  Nine
+    controls must not raise: ``optimize_pulses`` runs the host loop around single-interval propagations on the GPU and
+    arrives at the oracle's pulses; eight controls stay on the device sweeps (generic kernels)."""
+    import logging
+
+    for L, on_device in ((9, False), (8, True)):
+        spec = configs.config_c5(K=2, N=6, nt=7, L=L, distinct=True)
+        caplog.clear()
+        caplog.set_level(logging.WARNING, logger='krotov')
+        res = _optimize_on_device(spec, 2)
+        ref = oracle_optimize(spec, 2)
+        got = np.array([np.array(p) for p in res.all_pulses])
+        assert got.shape[1] == L
+        assert np.abs(got - ref['all_pulses']).max() < 1e-12 * max(1.0, np.abs(ref['all_pulses']).max())
+        assert np.abs(np.array(res.tau_vals) - ref['tau_vals']).max() < 1e-12
+        assert ('host loop around single-step' in caplog.text) == (not on_device)
+
+
 @pytest.mark.parametrize('cols', ['2', '4', '16'])
 @pytest.mark.parametrize('name', ['ref_c2_liouville', 'ref_c3_iswap', 'ref_c4_small'])
 def test_cooperative_kernels_vs_reference_loop_goldens(name, cols, monkeypatch):
