@@ -731,6 +731,12 @@ def main():
             if pmc_case is not None:
                 rec['roofline']['traffic'], rec['roofline']['traffic_source'] = pmc_traffic_leg(
                     pmc_case, line['roofline']['kernel'], line['config']['time_steps'])
+                if rec['roofline']['traffic']:
+                    # the same kernel against the OTHER roof: counter bytes per launch over its duration (the streaming
+                    # kernel of K1024_distinct moves 136 MB per interval: this is the fraction that says how close it is)
+                    gbs = rec['roofline']['traffic'] / (line['roofline']['launch_ms'] * 1e-3) / 1e9
+                    rec['roofline']['hbm_gbs'] = gbs
+                    rec['roofline']['hbm_frac'] = gbs / HBM_PEAK_GBS
             return rec
         except Exception as exc:  # (the headline line must not depend on a side measurement)
             if world > 1:

@@ -35,17 +35,33 @@ struct KhSweepArgs {
     const double *q2_rows;    // [KH_MAX_DEGREE+1][KH_Q2_ROWS][2]   (two-terms-per-phase kernels)
     const double *ratios;     // [KH_MAX_DEGREE+1][KH_RATIO_STRIDE]  (one-term-per-phase kernels)
     double *stats;            // [0] += matvecs issued (per objective, summed)
+    // generic kernels, dense operators too large for an LDS-resident generator: one N x N scratch matrix per workgroup
+    // (gen_scratch_wgs of them) where A(eps) of the interval is formed once, or NULL: operators re-assembled per term
+    cplx *gen_scratch;
+    int gen_scratch_wgs;
 };
 
-// LDS layout (dynamic): xa[N] xb[N] acc[N] chi[N] + scratch
+// LDS layout (dynamic): xa[N] xb[N] acc[N] chi[N] + scratch [+ the interval's generator A(eps), N x N, where it fits]
 struct KhGenLds {
     cplx *xa, *xb, *acc, *chi;
     double *red;  // [KH_GEN_THREADS/64 * 2 * KH_MAX_L] reduction scratch
     double *D;    // [KH_MAX_L] cross-objective sums of the current interval
     int *ok;      // exchange status broadcast
+    double *ratio;  // [KH_RATIO_STRIDE] the series' term ratios of the current degree (a global load per term otherwise)
+    cplx *A;      // [N][N] A(eps) = H0 + sum_l eps_l H_l of the objective and interval at hand, or NULL (does not fit / CSR)
 };
 
-__device__ __forceinline__ KhGenLds kh_gen_carve(char *smem, int N) {
+// Dense operators with N <= 96: the generator of an interval is formed ONCE, in LDS (N = 96: 144 KiB), instead of being
+// re-assembled from its 1 + L operators in every term of the series -- which re-read (1 + L) N^2 16 bytes from the
+// memory side per term and objective (L = 8, N = 64, K = 256: 369 us per interval, all of it that stream).
+#define KH_GEN_LDS_A_NMAX 96
+__host__ __device__ inline bool kh_gen_lds_A(int N, bool dense) { return dense && N <= KH_GEN_LDS_A_NMAX; }
+
+__host__ __device__ inline size_t kh_gen_lds_base_bytes(int N) {
+    return ((size_t)4 * N * sizeof(cplx) + ((KH_GEN_THREADS / 64) * 2 * KH_MAX_L + KH_MAX_L + KH_RATIO_STRIDE) * sizeof(double) + 64 + 15) / 16 * 16;
+}
+
+__device__ __forceinline__ KhGenLds kh_gen_carve(char *smem, int N, bool dense) {
     KhGenLds s;
     s.xa = (cplx *)smem;
     s.xb = s.xa + N;
@@ -54,11 +70,48 @@ __device__ __forceinline__ KhGenLds kh_gen_carve(char *smem, int N) {
     s.red = (double *)(s.chi + N);
     s.D = s.red + (KH_GEN_THREADS / 64) * 2 * KH_MAX_L;
     s.ok = (int *)(s.D + KH_MAX_L);
+    s.ratio = (double *)(s.ok + 8);
+    s.A = kh_gen_lds_A(N, dense) ? (cplx *)(smem + kh_gen_lds_base_bytes(N)) : nullptr;
     return s;
 }
 
-__host__ inline size_t kh_gen_lds_bytes(int N) {
-    return (size_t)4 * N * sizeof(cplx) + ((KH_GEN_THREADS / 64) * 2 * KH_MAX_L + KH_MAX_L) * sizeof(double) + 64;
+__host__ inline size_t kh_gen_lds_bytes(int N, bool dense) {
+    return kh_gen_lds_base_bytes(N) + (kh_gen_lds_A(N, dense) ? (size_t)N * N * sizeof(cplx) : 0);
+}
+
+// A(eps) = H0 + sum_l eps_l H_l of one objective -> dst (LDS), element by element in the order kh_gen_row_dot assembles
+// it (the same fused multiply-adds: bit-identical to the streamed form).  All threads; ends with a barrier.
+__device__ __forceinline__ void kh_gen_build_generator(const cplx *const *ops_k, const double *eps, int L, int N, cplx *dst) {
+    const int nn = N * N;
+    for (int i0 = threadIdx.x; i0 < nn; i0 += 4 * KH_GEN_THREADS) {
+        cplx a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * KH_GEN_THREADS;
+            a[q] = i < nn ? ops_k[0][i] : c_make(0.0, 0.0);
+        }
+        for (int l = 0; l < L; ++l) {
+            const cplx *h = ops_k[1 + l];
+            if (h == nullptr) continue;
+            cplx v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * KH_GEN_THREADS;
+                v[q] = i < nn ? h[i] : c_make(0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q].x = fma(eps[l], v[q].x, a[q].x);
+                a[q].y = fma(eps[l], v[q].y, a[q].y);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * KH_GEN_THREADS;
+            if (i < nn) dst[i] = a[q];
+        }
+    }
+    __syncthreads();
 }
 
 // y[row] = sum_c (h0[row][c] + sum_l eps_l h_l[row][c]) * x[c] for the rows this
@@ -124,6 +177,26 @@ __device__ __forceinline__ cplx kh_gen_row_dot(const cplx *const *ops_k, const K
     return sum;
 }
 
+// Four rows of A x at once for a staged generator (row-major N x N in LDS, N <= KH_GEN_LDS_A_NMAX): rows row0 + grp +
+// 16 i, i < 4, of this 16-lane group.  One read of every vector chunk serves the four rows, and the sixteen-odd loads of a
+// trip are independent: their latencies overlap instead of adding up pass by pass (2 us -> see docs/HISTORY.md R5.10 per term).
+__device__ __forceinline__ void kh_gen_rows4_staged(const cplx *A, int N, int row_first, int c16, const cplx *x, cplx (&out)[4]) {
+    cplx sum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum[i] = c_make(0.0, 0.0);
+    for (int c = c16; c < N; c += 16) {
+        const cplx xv = x[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row_first + 16 * i;
+            const cplx a = row < N ? A[(size_t)row * N + c] : c_make(0.0, 0.0);
+            c_fma(sum[i], a, xv);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = c_make(sum16(sum[i].x), sum16(sum[i].y));
+}
+
 // acc <- exp(f * A(eps) * dt) acc, A = H0 + sum eps_l H_l, by s Taylor
 // sub-steps of degree m.  All threads of the workgroup call this.
 __device__ __forceinline__ int kh_gen_expm_action(const KhSweepArgs &p, const cplx *const *ops_k,
@@ -138,8 +211,19 @@ __device__ __forceinline__ int kh_gen_expm_action(const KhSweepArgs &p, const cp
     // thresholds and term ratios of the engine's series (kh_common.h, "Series coefficients": Taylor, or the
     // shorter real-spectrum series when every operator is Hermitian)
     kh_degree_lookup(theta, p.q2_theta, p.theta_max, p.inv_theta_max, 12, &nsub, &m);
-    const double *ratio = p.ratios + (size_t)m * KH_RATIO_STRIDE;
+    // (every thread of the workgroup passes here with the same m: the previous call's readers of s.ratio are behind a barrier)
+    if (tid <= m) s.ratio[tid] = p.ratios[(size_t)m * KH_RATIO_STRIDE + tid];
+    __syncthreads();
+    const double *ratio = s.ratio;
     const double h = dt / nsub, c0 = ratio[0];
+    // the generator of this interval, formed once (kh_gen_build_generator), or the operators streamed per term
+    // ... in LDS where it fits, else in this workgroup's scratch matrix (global memory: written and read by this
+    // workgroup only, its barrier orders both; the reads then stream ONE matrix per term instead of 1 + L)
+    cplx *gen = s.A;
+    if (gen == nullptr && csr_k == nullptr && p.gen_scratch != nullptr && (int)blockIdx.x < p.gen_scratch_wgs)
+        gen = p.gen_scratch + (size_t)blockIdx.x * N * N;
+    const bool staged = gen != nullptr && csr_k == nullptr;
+    if (staged) kh_gen_build_generator(ops_k, eps, L, N, gen);
     for (int sub = 0; sub < nsub; ++sub) {
         for (int i = tid; i < N; i += KH_GEN_THREADS) {
             const cplx v = s.acc[i];
@@ -151,6 +235,22 @@ __device__ __forceinline__ int kh_gen_expm_action(const KhSweepArgs &p, const cp
         for (int j = 1; j <= m; ++j) {
             const double hj = h * ratio[j];
             const cplx coef = c_make(p.fre * hj, p.fim * hj);
+            if (staged) {
+                for (int row0 = 0; row0 < N; row0 += 64) {
+                    cplx d[4];
+                    kh_gen_rows4_staged(gen, N, row0 + grp, c16, xin, d);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = row0 + grp + 16 * i;
+                        if (c16 == 0 && row < N) {
+                            const cplx t = c_mul(coef, d[i]);
+                            xout[row] = t;
+                            s.acc[row].x += t.x;
+                            s.acc[row].y += t.y;
+                        }
+                    }
+                }
+            } else
             for (int row0 = 0; row0 < N; row0 += 16) {
                 const int row = row0 + grp;
                 const cplx d = kh_gen_row_dot(ops_k, csr_k, eps, L, N, row, c16, xin);
@@ -179,7 +279,7 @@ __global__ void __launch_bounds__(KH_GEN_THREADS)
 kh_gen_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx *__restrict__ state_in,
                    cplx *__restrict__ store, cplx *__restrict__ state_out, int direction) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const KhGenLds s = kh_gen_carve(smem, p.N);
+    const KhGenLds s = kh_gen_carve(smem, p.N, p.csr == nullptr);
     const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
     double matvecs = 0.0;
     for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
@@ -305,7 +405,7 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         u.n_end = u.n_begin + 1;
         if (u.n_begin >= p.nt - 1) return;  // replay past the last interval: nothing to do
     }
-    const KhGenLds s = kh_gen_carve(smem, p.N);
+    const KhGenLds s = kh_gen_carve(smem, p.N, p.csr == nullptr);
     double *D_sh = s.D;  // all LDS in the dynamic region (keeps its base 16-byte aligned)
     int *ok_sh_p = s.ok;
     const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;

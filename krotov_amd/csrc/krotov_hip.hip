@@ -113,6 +113,9 @@ struct kh_engine {
     unsigned long long *d_wait_ticks = nullptr;  // [4] kh_p2p_stats: in-GPU gather, cross-GPU wait (last sharded sweep); self-test ticks, rounds
     double *d_stats = nullptr;        // [4] (+ 64 trace stamps behind them in a KH_TIMING build)
     double *d_wg_partial = nullptr;   // [G][L]
+    cplx *d_gen_scratch = nullptr;    // [gen_scratch_wgs][N][N] generic kernels: the interval's generator (ensure_gen_scratch)
+    int gen_scratch_wgs = 0;
+    bool gen_scratch_failed = false;
     const double *guess_dev = nullptr;  // remembered by kh_update_begin
     // second-order update (kh_set_second_order); all NULL = first order
     const cplx *so_fw_prev = nullptr;
@@ -347,7 +350,30 @@ static KhSweepArgs sweep_args(const kh_engine *e, bool backward) {
     p.q2_rows = e->d_q2_rows;
     p.ratios = e->d_ratios;
     p.stats = e->d_stats;
+    p.gen_scratch = e->d_gen_scratch;
+    p.gen_scratch_wgs = e->gen_scratch_wgs;
     return p;
+}
+
+// The generic kernels' scratch generators (kh_generic.h: dense operators with N > 96): one N x N matrix per workgroup,
+// allocated at the first launch that can use it; at most 4 GiB, and a failed allocation just leaves the streamed form.
+static void ensure_gen_scratch(kh_engine *e, int wgs) {
+    if (e->d_csr_fw != nullptr || kh_gen_lds_A(e->N, true) || e->gen_scratch_wgs >= wgs || e->gen_scratch_failed) return;
+    const size_t bytes = sizeof(cplx) * (size_t)wgs * e->N * e->N;
+    if (bytes > ((size_t)4 << 30)) {
+        e->gen_scratch_failed = true;
+        return;
+    }
+    if (e->d_gen_scratch != nullptr) (void)hipFree(e->d_gen_scratch);
+    e->d_gen_scratch = nullptr;
+    e->gen_scratch_wgs = 0;
+    if (hipMalloc(&e->d_gen_scratch, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        e->d_gen_scratch = nullptr;
+        e->gen_scratch_failed = true;
+        return;
+    }
+    e->gen_scratch_wgs = wgs;
 }
 
 extern "C" void kh_engine_destroy(kh_engine *e) {
@@ -384,6 +410,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_slots);
     (void)hipFree(e->d_abort);
     (void)hipFree(e->d_wait_ticks);
+    (void)hipFree(e->d_gen_scratch);
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_wg_partial);
     (void)hipFree(e->d_step_partial);
@@ -587,9 +614,9 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     hipDeviceProp_t prop;
     KH_HIP_E(hipGetDeviceProperties(&prop, e->device));
     e->num_cus = prop.multiProcessorCount;
-    if (kh_gen_lds_bytes(e->N) > (size_t)prop.sharedMemPerBlock && kh_gen_lds_bytes(e->N) > 160 * 1024) {
+    if (kh_gen_lds_bytes(e->N, csr_fw == nullptr) > (size_t)prop.sharedMemPerBlock && kh_gen_lds_bytes(e->N, csr_fw == nullptr) > 160 * 1024) {
         kh_engine_destroy(e);
-        return kh_fail(KH_ERR_UNSUPPORTED, "N=%d needs %zu bytes of LDS", pr->N, kh_gen_lds_bytes(pr->N));
+        return kh_fail(KH_ERR_UNSUPPORTED, "N=%d needs %zu bytes of LDS", pr->N, kh_gen_lds_bytes(pr->N, csr_fw == nullptr));
     }
 
     // ---- operator tables: forward pointers as given, adjoints staged once per distinct operator
@@ -1184,12 +1211,13 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     }
 
     // ---- ensembles (kh_ens.h): one drift, control operators equal up to a real scale, N <= 64, one control, more
-    // objectives than the register-tile kernels keep resident with their operators in registers.  KH_ENS=0: off;
+    // objectives than CUs (from 257 on it beats the two-workgroups-per-CU tile kernels too: 10.7 against 11.1 us per interval at
+    // K = 512).  KH_ENS=0: off;
     // KH_ENS=1: for any K (testing); KH_ENS_MINK: smallest K that takes it; KH_ENS_NCG: column groups (testing)
     {
         const char *ens_env = getenv("KH_ENS");
         const int ens_mode = ens_env ? atoi(ens_env) : -1;
-        int min_k = 513;
+        int min_k = 257;  // (one objective per CU: the two-terms-per-phase kernels, 4.8 us per interval against 10.2 here)
         if (const char *d = getenv("KH_ENS_MINK")) min_k = atoi(d);
         const bool want = ens_mode == 1 || (ens_mode != 0 && force == nullptr && e->K >= min_k);
         if (want && csr_fw == nullptr && e->N <= KH_TILE_N && e->L == 1 && fw[1] != nullptr) {
@@ -1581,9 +1609,16 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
             return sweep_store(e, backward, pulses, in, store, out, st);
         }
     } else {
-        const size_t lds = kh_gen_lds_bytes(e->N);
+        const size_t lds = kh_gen_lds_bytes(e->N, e->d_csr_fw == nullptr);
         rc = ensure_dynamic_lds(e, (const void *)kh_gen_sweep_store, lds);
-        if (rc == KH_OK) launch_plain<kh_gen_sweep_store>(dim3(e->K), dim3(KH_GEN_THREADS), lds, st, p, pulses, in, store, out, direction);
+        // (the workgroups loop over the objectives: no more of them than the device runs at once -- each may own an
+        // N x N scratch generator)
+        const int grid = e->K < 2 * e->num_cus ? e->K : 2 * e->num_cus;
+        ensure_gen_scratch(e, grid);
+        KhSweepArgs pg = p;
+        pg.gen_scratch = e->d_gen_scratch;
+        pg.gen_scratch_wgs = e->gen_scratch_wgs;
+        if (rc == KH_OK) launch_plain<kh_gen_sweep_store>(dim3(grid), dim3(KH_GEN_THREADS), lds, st, pg, pulses, in, store, out, direction);
     }
     if (rc != KH_OK) return rc;
     KH_HIP(hipGetLastError());
@@ -1806,12 +1841,16 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");
         }
     } else {
-        const size_t lds = kh_gen_lds_bytes(e->N);
+        const size_t lds = kh_gen_lds_bytes(e->N, e->d_csr_fw == nullptr);
         rc = ensure_dynamic_lds(e, (const void *)kh_gen_forward_update, lds);
+        ensure_gen_scratch(e, e->grid_update);
+        KhSweepArgs pg = p;
+        pg.gen_scratch = e->d_gen_scratch;
+        pg.gen_scratch_wgs = e->gen_scratch_wgs;
         if (rc == KH_OK && !u.internal_exchange)
-            launch_plain<kh_gen_forward_update>(dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, p, u, ex);
+            launch_plain<kh_gen_forward_update>(dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, pg, u, ex);
         else if (rc == KH_OK)
-            rc = launch_persistent<kh_gen_forward_update>(e, dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, p, u, ex);
+            rc = launch_persistent<kh_gen_forward_update>(e, dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, pg, u, ex);
     }
     if (rc != KH_OK) return rc;
     KH_HIP(hipGetLastError());

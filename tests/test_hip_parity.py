@@ -40,7 +40,8 @@ SMALL = {
     'c5_n128': lambda: configs.config_c5(K=2, N=128, nt=11, L=1),
     'c5_n33': lambda: configs.config_c5(K=5, N=33, nt=41),
     # more objectives than CUs: two 256-thread workgroups per CU
-    'c5_k300': lambda: configs.config_c5(K=300, N=16, nt=21),
+    'c5_k300': lambda: configs.config_c5(K=300, N=16, nt=21, distinct=True),
+    'c5_k300_ens': lambda: configs.config_c5(K=300, N=16, nt=21),  # one drift, scaled control operators: the ensemble kernel
     # more objectives than can be co-resident (one control: > 2 per CU; several controls: > 1 per CU): the update
     # sweep runs the streaming register-tile kernel (kh_tile64s.h: every workgroup walks through several objectives
     # per interval; 600 = 512 + 88: some workgroups own one objective, some two; 1100 with three controls: five and four)
@@ -110,7 +111,7 @@ def test_sweeps_match_oracle(name):
     assert (eng.kernel == 'tile64/256') == (name == 'c5_k300')
     assert (eng.kernel == 'tile64/stream') == (name in ('c5_k600_distinct', 'c5_k300_L2', 'c5_k1100_L3',
                                                          'c5_k520_n64_distinct', 'c5_k264_n64_L2'))
-    assert (eng.kernel == 'ens64/mfma') == (name in ('c5_k600', 'c5_k520_n64'))
+    assert (eng.kernel == 'ens64/mfma') == (name in ('c5_k600', 'c5_k520_n64', 'c5_k300_ens'))
     assert (eng.kernel == 'coop16/mfma') == (name.startswith('c4_d') and spec.N > 64 or name.startswith('shared'))
     assert (eng.kernel == 'tile128/512') == (name in ('c5_n80', 'c5_n100', 'c5_n128'))
     eng.close()
