@@ -1558,11 +1558,15 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
         // 768: 168, 1024: 128), else two rows per lane of a 512-thread workgroup
         if (e->N <= 512) {
             if (e->ell_E <= 8) KH_ELL_STORE(512, 1, 8);
+            else if (e->ell_E <= 12) KH_ELL_STORE(512, 1, 12);
             else if (e->ell_E <= 16) KH_ELL_STORE(512, 1, 16);
             else if (e->ell_E <= 24) KH_ELL_STORE(512, 1, 24);
             else KH_ELL_STORE(512, 1, 32);
         } else if (e->N <= 768 && e->ell_E <= 16) {
+            // (12: drift + two controls of a Lindbladian -- the reference's notebook 06 has 11.2 entries per row; every
+            // padded slot is a gather and four multiply-adds per term)
             if (e->ell_E <= 8) KH_ELL_STORE(768, 1, 8);
+            else if (e->ell_E <= 12) KH_ELL_STORE(768, 1, 12);
             else KH_ELL_STORE(768, 1, 16);
         } else if (e->N > 1024) {  // (<= 8 entries per row: build_ell_host)
             if (e->N <= 1536) KH_ELL_STORE(512, 3, 8);
@@ -1819,10 +1823,10 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
                                                                   (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex))
 #define KH_ELL_UPDATE(T, R, EM) (so ? KH_ELL_UPDATE_SO(T, R, EM, true) : KH_ELL_UPDATE_SO(T, R, EM, false))
         if (e->N <= 512)
-            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(512, 1, 8) : e->ell_E <= 16 ? KH_ELL_UPDATE(512, 1, 16)
-                 : e->ell_E <= 24 ? KH_ELL_UPDATE(512, 1, 24) : KH_ELL_UPDATE(512, 1, 32);
+            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(512, 1, 8) : e->ell_E <= 12 ? KH_ELL_UPDATE(512, 1, 12)
+                 : e->ell_E <= 16 ? KH_ELL_UPDATE(512, 1, 16) : e->ell_E <= 24 ? KH_ELL_UPDATE(512, 1, 24) : KH_ELL_UPDATE(512, 1, 32);
         else if (e->N <= 768 && e->ell_E <= 16)
-            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(768, 1, 8) : KH_ELL_UPDATE(768, 1, 16);
+            rc = e->ell_E <= 8 ? KH_ELL_UPDATE(768, 1, 8) : e->ell_E <= 12 ? KH_ELL_UPDATE(768, 1, 12) : KH_ELL_UPDATE(768, 1, 16);
         else if (e->N > 1024)
             rc = e->N <= 1536 ? KH_ELL_UPDATE(512, 3, 8) : KH_ELL_UPDATE(512, 4, 8);
         else if (e->ell_E <= 8)

@@ -1801,6 +1801,38 @@ def test_update_sweep_on_fewer_workgroups(name, grid, want):
     other.close()
 
 
+@pytest.mark.parametrize('name', ['c5_n100', 'c5_n80', 'c5_n64', 'c5_n64_L2'])
+def test_advanced_tiles_with_a_pulse_spanning_orders_of_magnitude(name):
+    """The register-resident kernels ADVANCE their generator from interval to interval (A += (eps - eps') H_l, restarted
+    from the drift every 64 intervals) instead of re-forming it: rounding of the advances is of the order of the LARGEST
+    pulse value seen since the restart and does not shrink when the pulse does.  A guess pulse that sweeps
+    three orders of magnitude within one restart period must still give the oracle's sweeps to the usual 1e-12
+    (measured: 1e-15 -- the advances' rounding is relative to the generator's own magnitude at that time and is
+    wiped out at every restart)."""
+    spec = SMALL[name]()
+    nt = len(spec.tlist)
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    # 30 -> 0.03 -> 30 over the grid, on top of the guess: theta per step up to ~3 (sub-steps) down to ~1e-3
+    env = 30.0 * 10.0 ** (-1.5 * (1.0 - np.cos(2.0 * np.pi * np.arange(nt - 1) / (nt - 1))))
+    gp = [env * (0.3 + np.abs(g)) for g in gp]
+    pulses = np.array(gp)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.1 / spec.K)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    eng = _engine(spec)
+    chi = eng.backward(chi_T, pulses)
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    scale = max(1.0, np.abs(np.array(ref[0])).max())
+    errs = (np.abs(chi.cpu().numpy() - ref_chi).max(), np.abs(opt.cpu().numpy() - np.array(ref[0])).max() / scale,
+            np.abs(psi_T.cpu().numpy() - ref[1]).max())
+    print("%s (%s): |d chi| %.1e  |d pulse| / scale %.1e  |d psi(T)| %.1e" % (name, eng.kernel, *errs))
+    assert max(errs) < 1e-12
+    eng.close()
+
+
 MM_CASES = {
     'c5_n64': lambda: configs.config_c5(K=8, N=64, nt=61),
     'c5_n33': lambda: configs.config_c5(K=5, N=33, nt=41),

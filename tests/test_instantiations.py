@@ -47,6 +47,9 @@ case('tn_n128_so', lambda: configs.config_c5(K=2, N=128, nt=7, L=1), ['kh_tn_for
 case('tn_n110_so', lambda: configs.config_c5(K=2, N=110, nt=7, L=1), ['kh_tn_forward_update<28, true, false>'], so=True)
 
 # ---- sparse operators in registers (kh_ell.h): <threads, rows per lane, widest row[, second order]>
+case('ell_e11', lambda: _banded(40, 11, nt=9), ['kh_ell_sweep_store<512, 1, 12>', 'kh_ell_forward_update<512, 1, 12, false>'], sparse=True)
+case('ell_e11_so', lambda: _banded(40, 11, nt=9), ['kh_ell_forward_update<512, 1, 12, true>'], sparse=True, so=True)
+case('ell_n600_e11', lambda: _banded(600, 11, nt=4, K=1), ['kh_ell_sweep_store<768, 1, 12>', 'kh_ell_forward_update<768, 1, 12, false>'], sparse=True)
 case('ell_e21', lambda: _banded(40, 21, nt=9), ['kh_ell_sweep_store<512, 1, 24>', 'kh_ell_forward_update<512, 1, 24, false>'], sparse=True)
 case('ell_e21_so', lambda: _banded(40, 21, nt=9), ['kh_ell_forward_update<512, 1, 24, true>'], sparse=True, so=True)
 case('ell_e29', lambda: _banded(48, 29, nt=9), ['kh_ell_sweep_store<512, 1, 32>', 'kh_ell_forward_update<512, 1, 32, false>'], sparse=True)
@@ -54,7 +57,9 @@ case('ell_e29_so', lambda: _banded(48, 29, nt=9), ['kh_ell_forward_update<512, 1
 case('ell_n800_e15', lambda: _banded(800, 15, nt=4, K=1), ['kh_ell_sweep_store<512, 2, 16>', 'kh_ell_forward_update<512, 2, 16, false>'], sparse=True)
 case('ell_n800_e15_so', lambda: _banded(800, 15, nt=4, K=1), ['kh_ell_forward_update<512, 2, 16, true>'], sparse=True, so=True)
 case('ell_n800_e11_so', lambda: _banded(800, 11, nt=4, K=1), ['kh_ell_forward_update<512, 2, 12, true>'], sparse=True, so=True)
-case('ell_n600_e11_so', lambda: _banded(600, 11, nt=4, K=1), ['kh_ell_forward_update<768, 1, 16, true>'], sparse=True, so=True)
+case('ell_n600_e11_so', lambda: _banded(600, 11, nt=4, K=1), ['kh_ell_forward_update<768, 1, 12, true>'], sparse=True, so=True)
+case('ell_n600_e15', lambda: _banded(600, 15, nt=4, K=1), ['kh_ell_sweep_store<768, 1, 16>', 'kh_ell_forward_update<768, 1, 16, false>'], sparse=True)
+case('ell_n600_e15_so', lambda: _banded(600, 15, nt=4, K=1), ['kh_ell_forward_update<768, 1, 16, true>'], sparse=True, so=True)
 case('ell_n625_so', lambda: configs.config_sparse_lindblad(d=25, nt=5, K=2), ['kh_ell_forward_update<768, 1, 8, true>'], sparse=True, so=True)
 case('ell_n900_so', lambda: configs.config_sparse_lindblad(d=30, nt=4, K=1), ['kh_ell_forward_update<1024, 1, 8, true>'], sparse=True, so=True)
 
