@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python $R/bench.py 2>/dev/null | tail -1 > $OUT/bench_n1.json
+T0=$(date +%s); timeout 900 python $R/bench.py 2>/dev/null | tail -1 > $OUT/bench_n1.json; echo "default bench.py run: $(( $(date +%s) - T0 )) s wall" > $OUT/bench_wall.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python $R/bench.py --no-cpu-baseline --no-config4 --no-variants --no-sparse > $OUT/stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o b -- python $R/bench.py --no-cpu-baseline --no-config4 --no-variants --no-sparse --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o b -- python $R/bench.py --no-cpu-baseline --no-config4 --no-variants --no-sparse --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1

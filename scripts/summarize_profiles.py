@@ -155,6 +155,7 @@ if os.path.isdir(tdir):
                 print(case, kern, {k: round(100 * v['avg_per_launch'] / wc, 1) for k, v in c.items() if k.startswith('SQ_') and k not in ('SQ_WAVE_CYCLES',)})
 
 # other artefacts of a round's collection, copied as they are
-for name in ('ubench_gather.txt', 'config4_timing.txt', 'kernel_resources.txt', 'exp_ens.txt'):
+for name in ('ubench_gather.txt', 'config4_timing.txt', 'kernel_resources.txt', 'exp_ens.txt', 'cliffs.txt', 'busy_stream.txt',
+             'stream_timing.txt', 'bench_wall.txt'):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
