@@ -328,7 +328,9 @@ int kh_series_tables_defect(double tol, double theta_cap, double defect, double 
  * with S = kh_ell_rows_of(N) padded rows: the threads x rows per lane of the kernel instantiation that serves N (512,
  * 768, 1024, 1536 or 2048; 0: N > 2048).  off / vals may be NULL (sizes only); E_cap: entry slots the caller's arrays can
  * hold.  KH_ERR_UNSUPPORTED when N > 2048 or a row is wider than 32 entries (16 for N > 512, 8 for N > 1024): such
- * engines run the generic CSR kernels. */
+ * engines run the STREAMED form of the same kernels (kh_engine_kernel: "ellstream/csr"; N <= 4096, rows up to 32 entries:
+ * the same arrays with S = N rounded up to 64, read from memory in every term instead of living in registers), and
+ * the generic CSR kernels beyond that (N <= 2540: their vectors must fit LDS). */
 int32_t kh_ell_rows_of(int32_t N);
 int kh_ell_layout(int32_t N, int32_t n_ops, const kh_csr *ops_host, int32_t *E, int32_t *Ec, int32_t *off,
                   kh_cdouble *vals, int32_t E_cap);

@@ -43,6 +43,16 @@ struct KhEll {
 };
 
 #define KH_ELL_XB_BYTES (KH_ELL_NMAX * (int)sizeof(cplx))  // second vector buffer at a compile-time offset
+// STREAMED form (template flag of the kernels below; krotov_hip.hip: e->ell_stream): operators whose rows do not fit
+// the registers -- N up to 4096, up to 32 entries per row -- keep NOTHING resident: a term reads the row's offsets and
+// values from the pools (lane = row, so every load is coalesced; L2 / Infinity-Cache traffic of 20 bytes per entry and
+// term), the interval's values of the control-touched slots are formed once per interval into a per-workgroup scratch
+// plane (row-private: the lane that writes an element is the one that reads it).  Eight rows per lane of 512 threads;
+// the two vector buffers take 2 x 64 KiB of LDS.  Several times faster than the generic CSR kernels (which it replaces
+// for these shapes, and which cannot hold N > 2540 in LDS at all), several times slower than the register form.
+#define KH_ELLS_NMAX 4096
+#define KH_ELLS_RPL 8
+#define KH_ELLS_XB_BYTES (KH_ELLS_NMAX * (int)sizeof(cplx))
 
 struct KhEllLds {
     double *ratio;  // [KH_RATIO_STRIDE] the series' ratios of the current degree
@@ -55,14 +65,15 @@ struct KhEllLds {
                     // run-time control number would be moved through the VGPR index register)
 };
 
-__host__ __device__ inline size_t kh_ell_lds_bytes() {
-    return (size_t)2 * KH_ELL_XB_BYTES +
+__host__ __device__ inline size_t kh_ell_lds_bytes(bool stream = false) {
+    return (size_t)2 * (stream ? KH_ELLS_XB_BYTES : KH_ELL_XB_BYTES) +
            (KH_RATIO_STRIDE + 16 * KH_MAX_L + KH_MAX_L + KH_MAX_L + 1 + KH_MAX_DEGREE + 1 + 2 * KH_MAX_L) * sizeof(double) + 64;
 }
 
+template <int XB = KH_ELL_XB_BYTES>
 __device__ __forceinline__ KhEllLds kh_ell_carve(char *smem) {
     KhEllLds s;
-    s.ratio = (double *)(smem + 2 * KH_ELL_XB_BYTES);
+    s.ratio = (double *)(smem + 2 * XB);
     s.red = s.ratio + KH_RATIO_STRIDE;
     s.D = s.red + 16 * KH_MAX_L;
     s.ok = s.D + KH_MAX_L;
@@ -174,6 +185,120 @@ __device__ __forceinline__ cplx kh_ell_control_row(const KhEll &el, const cplx *
     return s;
 }
 
+// ---- streamed form: the same three operations with the matrix in the pools ----
+// the interval's values of the control-touched slots (e < Ec) of this lane's rows -> the workgroup's scratch plane
+template <int T, int RPL>
+__device__ __forceinline__ void kh_ells_rebuild(const KhEll &el, const cplx *__restrict__ vals, cplx *__restrict__ scr, int tid,
+                                                int L, const double *eps, int N) {
+    const long long plane = (long long)el.E * el.rows;
+    for (int i = 0; i < RPL; ++i) {
+        const int row = tid + T * i;
+        if (row >= N) break;
+        for (int e0 = 0; e0 < el.Ec; e0 += 4) {
+            cplx v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (vals + (el.vals_at + (long long)(e0 + q) * el.rows))[row];
+            for (int l = 0; l < L; ++l) {
+                const double w = eps[l];
+                cplx c[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[q] = (vals + (el.vals_at + (1 + l) * plane + (long long)(e0 + q) * el.rows))[row];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q].x = fma(w, c[q].x, v[q].x);
+                    v[q].y = fma(w, c[q].y, v[q].y);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) scr[(long long)(e0 + q) * el.rows + row] = v[q];
+        }
+    }
+}
+
+// one row of A x: offsets from the pool, values from the scratch plane (slots the controls touch) or the drift's plane
+__device__ __forceinline__ cplx kh_ells_row(const KhEll &el, const int *__restrict__ offs, const cplx *__restrict__ vals,
+                                            const cplx *__restrict__ scr, int row, const char *x) {
+    cplx s = c_make(0.0, 0.0);
+    for (int e0 = 0; e0 < el.E; e0 += 4) {
+        const cplx *src = e0 < el.Ec ? scr + (long long)e0 * el.rows : vals + (el.vals_at + (long long)e0 * el.rows);
+        const int *po = offs + (el.off_at + (long long)e0 * el.rows);
+        int o[4];
+        cplx a[4], v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[q] = po[(long long)q * el.rows + row];
+            a[q] = src[(long long)q * el.rows + row];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *(const cplx *)(x + o[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c_fma(s, a[q], v[q]);
+    }
+    return s;
+}
+
+// (A_l x)_row for one control operator
+__device__ __forceinline__ cplx kh_ells_control_row(const KhEll &el, const int *__restrict__ offs, const cplx *__restrict__ vals,
+                                                    int l, int row, const char *x) {
+    const long long base = el.vals_at + (long long)(1 + l) * el.E * el.rows;
+    cplx s = c_make(0.0, 0.0);
+    for (int e0 = 0; e0 < el.Ec; e0 += 4) {
+        int o[4];
+        cplx w[4], v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[q] = (offs + (el.off_at + (long long)(e0 + q) * el.rows))[row];
+            w[q] = (vals + (base + (long long)(e0 + q) * el.rows))[row];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *(const cplx *)(x + o[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c_fma(s, w[q], v[q]);
+    }
+    return s;
+}
+
+// kh_ell_expm_action with the matrix streamed
+template <int T, int RPL>
+__device__ __forceinline__ int kh_ells_expm_action(const KhEll &el, const int *__restrict__ offs, const cplx *__restrict__ vals,
+                                                   const cplx *__restrict__ scr, cplx (&state)[RPL], char *smem,
+                                                   const double *ratio, double fre, double fim, double dt, int nsub, int m,
+                                                   int tid, int N) {
+    char *xa = smem, *xb = smem + KH_ELLS_XB_BYTES;
+    const double h = dt / nsub;
+    auto term = [&](int j, const char *xin, char *xout) {
+        const double hj = h * ratio[j];
+        const cplx coef = c_make(fre * hj, fim * hj);
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int row = tid + T * i;
+            if (row < N) {
+                const cplx t = c_mul(coef, kh_ells_row(el, offs, vals, scr, row, xin));
+                ((cplx *)xout)[row] = t;
+                state[i].x += t.x;
+                state[i].y += t.y;
+            }
+        }
+        __syncthreads();
+    };
+    for (int sub = 0; sub < nsub; ++sub) {
+        const double c0 = ratio[0];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int row = tid + T * i;
+            if (row < N) ((cplx *)xa)[row] = state[i];
+            state[i] = c_make(c0 * state[i].x, c0 * state[i].y);
+        }
+        __syncthreads();
+        for (int j = 1; j <= m; j += 2) {
+            term(j, xa, xb);
+            if (j + 1 > m) break;
+            term(j + 1, xb, xa);
+        }
+    }
+    return nsub * m;
+}
+
 // the series' ratios of degree m -> LDS (workgroup-uniform m; contains barriers)
 __device__ __forceinline__ void kh_ell_load_ratios(const KhSweepArgs &p, const KhEllLds &s, int m, int tid) {
     __syncthreads();
@@ -225,13 +350,15 @@ __device__ __forceinline__ int kh_ell_expm_action(const cplx (&a)[RPL][EMAX], co
 // ---------------------------------------------------------------------------
 // plain propagation with storage (backward sweep / iteration-0 forward sweep)
 // ---------------------------------------------------------------------------
-template <int T, int RPL, int EMAX>
+// STREAM: the streamed form (see KH_ELLS_NMAX); scratch: [gridDim.x][Ec_max * rows] elements, scratch_stride per workgroup
+template <int T, int RPL, int EMAX, bool STREAM = false>
 __global__ void __launch_bounds__(T)
 kh_ell_sweep_store(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__restrict__ offs, const cplx *__restrict__ vals,
                    const double *__restrict__ pulses, const cplx *__restrict__ state_in, cplx *__restrict__ store,
-                   cplx *__restrict__ state_out, int direction) {
+                   cplx *__restrict__ state_out, int direction, cplx *__restrict__ scratch, long long scratch_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const KhEllLds s = kh_ell_carve(smem);
+    const KhEllLds s = kh_ell_carve<STREAM ? KH_ELLS_XB_BYTES : KH_ELL_XB_BYTES>(smem);
+    cplx *scr = STREAM ? scratch + (long long)blockIdx.x * scratch_stride : nullptr;
     const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
     double matvecs = 0.0;
     int m_cur = -1;
@@ -240,9 +367,9 @@ kh_ell_sweep_store(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__r
     for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
         const KhEll el = ells[k];
         const double *norms_k = p.op_norms + (size_t)k * (1 + L);
-        cplx a[RPL][EMAX];
-        int off[RPL][EMAX];
-        kh_ell_load<T, RPL, EMAX>(el, offs, vals, tid, a, off);
+        cplx a[STREAM ? 1 : RPL][EMAX];
+        int off[STREAM ? 1 : RPL][EMAX];
+        if constexpr (!STREAM) kh_ell_load<T, RPL, EMAX>(el, offs, vals, tid, a, off);
         cplx state[RPL];
         auto put = [&](cplx *dst) {
 #pragma unroll
@@ -266,14 +393,20 @@ kh_ell_sweep_store(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__r
             }
             const double dt = p.dt[n];
             __syncthreads();  // (s.eps; also: the previous interval's last term has been read by everybody)
-            kh_ell_rebuild<T, RPL, EMAX>(el, vals, tid, L, s.eps, a);
+            if constexpr (STREAM)
+                kh_ells_rebuild<T, RPL>(el, vals, scr, tid, L, s.eps, N);
+            else
+                kh_ell_rebuild<T, RPL, EMAX>(el, vals, tid, L, s.eps, a);
             int nsub, m;
             kh_degree_cached(theta * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
             if (m != m_cur) {
                 kh_ell_load_ratios(p, s, m, tid);
                 m_cur = m;
             }
-            matvecs += kh_ell_expm_action<T, RPL, EMAX>(a, off, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
+            if constexpr (STREAM)
+                matvecs += kh_ells_expm_action<T, RPL>(el, offs, vals, scr, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
+            else
+                matvecs += kh_ell_expm_action<T, RPL, EMAX>(a, off, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
             if (store != nullptr) put(store + ((size_t)k * nt + (direction > 0 ? n + 1 : n)) * N);
         }
         if (state_out != nullptr) put(state_out + (size_t)k * N);
@@ -284,20 +417,22 @@ kh_ell_sweep_store(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__r
 // ---------------------------------------------------------------------------
 // forward sweep with sequential pulse update (optimize.py:444-508): ONE launch, grid == K, sums exchanged in-kernel
 // ---------------------------------------------------------------------------
-template <int T, int RPL, int EMAX, bool SO>
+template <int T, int RPL, int EMAX, bool SO, bool STREAM = false>
 __global__ void __launch_bounds__(T)
 kh_ell_forward_update(KhSweepArgs p, const KhEll *__restrict__ ells, const int *__restrict__ offs,
-                      const cplx *__restrict__ vals, KhUpdateArgs u, KhExchange ex) {
+                      const cplx *__restrict__ vals, KhUpdateArgs u, KhExchange ex, cplx *__restrict__ scratch,
+                      long long scratch_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const KhEllLds s = kh_ell_carve(smem);
+    const KhEllLds s = kh_ell_carve<STREAM ? KH_ELLS_XB_BYTES : KH_ELL_XB_BYTES>(smem);
+    cplx *scr = STREAM ? scratch + (long long)blockIdx.x * scratch_stride : nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, N = p.N, L = p.L, nt = p.nt;
     const int k = blockIdx.x;
     const KhEll el = ells[k];
     const double *norms_k = p.op_norms + (size_t)k * (1 + L);
     const double chi_norm = u.chi_norms[k];
-    cplx a[RPL][EMAX];
-    int off[RPL][EMAX];
-    kh_ell_load<T, RPL, EMAX>(el, offs, vals, tid, a, off);
+    cplx a[STREAM ? 1 : RPL][EMAX];
+    int off[STREAM ? 1 : RPL][EMAX];
+    if constexpr (!STREAM) kh_ell_load<T, RPL, EMAX>(el, offs, vals, tid, a, off);
     cplx state[RPL];
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
@@ -337,7 +472,11 @@ kh_ell_forward_update(KhSweepArgs p, const KhEll *__restrict__ ells, const int *
             for (int i = 0; i < RPL; ++i) {
                 const int row = tid + T * i;
                 if (row < N) {
-                    const cplx z = kh_ell_control_row<EMAX>(el, vals, l, (unsigned)row, off[i], smem);
+                    cplx z;
+                    if constexpr (STREAM)
+                        z = kh_ells_control_row(el, offs, vals, l, row, smem);
+                    else
+                        z = kh_ell_control_row<EMAX>(el, vals, l, (unsigned)row, off[i], smem);
                     cplx ov = c_make(0.0, 0.0);
                     c_fma_conj(ov, bra[i], z);
                     v += u.mu_re * ov.y + u.mu_im * ov.x;  // Im(mu <bra|A_l phi>): one real combination
@@ -422,14 +561,20 @@ kh_ell_forward_update(KhSweepArgs p, const KhEll *__restrict__ ells, const int *
         }
         __syncthreads();
         // ---- propagate over interval n with the updated pulses (optimize.py:479-491) ----
-        kh_ell_rebuild<T, RPL, EMAX>(el, vals, tid, L, s.eps, a);
+        if constexpr (STREAM)
+            kh_ells_rebuild<T, RPL>(el, vals, scr, tid, L, s.eps, N);
+        else
+            kh_ell_rebuild<T, RPL, EMAX>(el, vals, tid, L, s.eps, a);
         int nsub, m;
         kh_degree_cached(theta * dt, s.deg, p.theta_max, p.inv_theta_max, dc, &nsub, &m);
         if (m != m_cur) {
             kh_ell_load_ratios(p, s, m, tid);
             m_cur = m;
         }
-        matvecs += kh_ell_expm_action<T, RPL, EMAX>(a, off, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
+        if constexpr (STREAM)
+            matvecs += kh_ells_expm_action<T, RPL>(el, offs, vals, scr, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
+        else
+            matvecs += kh_ell_expm_action<T, RPL, EMAX>(a, off, state, smem, s.ratio, p.fre, p.fim, dt, nsub, m, tid, N);
         if constexpr (SO) {
 #pragma unroll
             for (int i = 0; i < RPL; ++i)

@@ -99,6 +99,10 @@ struct kh_engine {
     int *d_ell_off = nullptr;         // ... their column offsets and values (one pool each)
     cplx *d_ell_vals = nullptr;
     int ell_E = 0;                    // widest row over all objectives and both directions (picks the instantiation)
+    bool gen_fits = true;             // the generic kernels' LDS vectors fit (N <= 2540)
+    bool ell_stream = false;          // the streamed form of kh_ell.h (rows that do not fit the registers, N <= 4096)
+    cplx *d_ell_scratch = nullptr;    // ... its per-workgroup scratch planes [workgroups][ell_scratch_stride]
+    long long ell_scratch_stride = 0;
     const cplx **d_coop_fops_fw = nullptr, **d_coop_fops_bw = nullptr;  // [1+L] fragment-ordered operator copies
     const cplx **d_coop_sq_fw = nullptr, **d_coop_sq_bw = nullptr;      // [3] the same for P0, P1, P2 (one control)
     const cplx **d_sq_fw = nullptr;   // [K*3] P0, P1, P2 of A^2 (q2 kernels), forward operators
@@ -307,7 +311,7 @@ static int check_residency(const kh_engine *e, const void *func, int threads, si
     return KH_OK;
 }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.6 (gfx950; tile64q2, tile64, tile64/stream, ens64/mfma, mini16, mini4, coop16/mfma, ell/csr, tile128, generic, generic/csr kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.6 (gfx950; tile64q2, tile64, tile64/stream, ens64/mfma, mini16, mini4, coop16/mfma, ell/csr, ellstream/csr, tile128, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
@@ -317,7 +321,7 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
         case KIND_TILE_RPT1: return e->stepwise_only ? (e->stream ? "tile64/stream" : "tile64/512 per interval") : "tile64/512";
         case KIND_TILE_Q2: return e->mini ? (e->quad ? "mini4/wave" : "mini16/wave") : "tile64q2/512";
         case KIND_COOP: return "coop16/mfma";
-        case KIND_ELL: return "ell/csr";
+        case KIND_ELL: return e->ell_stream ? "ellstream/csr" : "ell/csr";
         case KIND_TILEN: return "tile128/512";
         default: return e->d_csr_fw != nullptr ? "generic/csr" : "generic";
     }
@@ -411,6 +415,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_abort);
     (void)hipFree(e->d_wait_ticks);
     (void)hipFree(e->d_gen_scratch);
+    (void)hipFree(e->d_ell_scratch);
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_wg_partial);
     (void)hipFree(e->d_step_partial);
@@ -516,7 +521,7 @@ static double csr_part_fro2(const HostCsr &a, const HostCsr &adj, double sign) {
 // the union of the patterns, entries some control touches first.  Returns false when a row is wider than the kernels'
 // register budget (kh_ell_emax(N): 32 entries with one row per lane, 16 with two, 8 with three or four).
 static bool build_ell_host(const std::vector<const HostCsr *> &ops, int N, std::vector<int> &off, std::vector<cplx> &vals,
-                           int &E, int &Ec) {
+                           int &E, int &Ec, bool stream = false) {
     const int Lp1 = (int)ops.size();
     std::vector<std::vector<std::pair<int, int>>> rows(N);  // (column, touched by a control)
     E = Ec = 0;
@@ -538,7 +543,8 @@ static bool build_ell_host(const std::vector<const HostCsr *> &ops, int N, std::
         E = std::max(E, (int)rows[r].size());
         Ec = std::max(Ec, nc);
     }
-    const int emax = kh_ell_emax(N), S = kh_ell_rows(N);
+    // (stream: the pools of the streamed kernels -- nothing lives in registers, so rows up to 32 entries for any N they take)
+    const int emax = stream ? KH_ELL_EMAX : kh_ell_emax(N), S = stream ? (N + 63) / 64 * 64 : kh_ell_rows(N);
     if (E > emax) return false;
     // every row: its control-touched entries in slots [0, Ec), the others behind them from slot Ec on (so that a rebuild
     // of slots [0, Ec) never touches a drift-only entry); padding: value 0, the lane's own row
@@ -614,7 +620,12 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     hipDeviceProp_t prop;
     KH_HIP_E(hipGetDeviceProperties(&prop, e->device));
     e->num_cus = prop.multiProcessorCount;
-    if (kh_gen_lds_bytes(e->N, csr_fw == nullptr) > (size_t)prop.sharedMemPerBlock && kh_gen_lds_bytes(e->N, csr_fw == nullptr) > 160 * 1024) {
+    // the generic kernels -- every engine's last resort -- keep four vectors of N elements in LDS: N <= 2540.  Sparse
+    // operators up to N = 4096 may still run the streamed padded-row kernels (decided below: gen_fits stays false then
+    // and whatever would need the generic kernels -- one launch per interval, more objectives than CUs -- is refused)
+    const bool gen_fits = !(kh_gen_lds_bytes(e->N, csr_fw == nullptr) > (size_t)prop.sharedMemPerBlock && kh_gen_lds_bytes(e->N, csr_fw == nullptr) > 160 * 1024);
+    e->gen_fits = gen_fits;
+    if (!gen_fits && !(csr_fw != nullptr && e->N <= KH_ELLS_NMAX)) {
         kh_engine_destroy(e);
         return kh_fail(KH_ERR_UNSUPPORTED, "N=%d needs %zu bytes of LDS", pr->N, kh_gen_lds_bytes(pr->N, csr_fw == nullptr));
     }
@@ -739,8 +750,16 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         }
         // the padded row form (kh_ell.h): one structure per distinct operator list and direction
         const char *force_k = getenv("KH_KERNEL");
-        if (e->N <= KH_ELL_NMAX && !(force_k && strcmp(force_k, "generic") == 0)) {
+        // ... matrix in registers where the rows fit (N <= 2048), else -- or with KH_KERNEL=ellstream -- the streamed form
+        // (N <= 4096, rows up to 32 entries): the same pools with their own row count, read per term
+        const bool want_stream = force_k && strcmp(force_k, "ellstream") == 0;
+        for (int form = want_stream ? 1 : 0; form < 2 && !ell_ok; ++form) {
+            const bool stream = form == 1;
+            if (e->N > (stream ? KH_ELLS_NMAX : KH_ELL_NMAX) || (force_k && strcmp(force_k, "generic") == 0)) continue;
+            if (stream && getenv("KH_NO_ELLSTREAM") && atoi(getenv("KH_NO_ELLSTREAM"))) continue;
             ell_ok = true;
+            e->ell_E = 0;
+            int ec_max = 0;
             std::map<std::vector<const void *>, std::pair<KhEll, KhEll>> made;
             std::vector<KhEll> ell_fw(e->K), ell_bw(e->K);
             std::vector<int> off_pool;
@@ -757,17 +776,18 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                         std::vector<int> off;
                         std::vector<cplx> vals;
                         int E = 0, Ec = 0;
-                        if (!build_ell_host(ops_h, e->N, off, vals, E, Ec)) {
+                        if (!build_ell_host(ops_h, e->N, off, vals, E, Ec, stream)) {
                             ell_ok = false;
                             break;
                         }
+                        ec_max = std::max(ec_max, Ec);
                         pair[dir].off_at = (long long)off_pool.size();
                         pair[dir].vals_at = (long long)vals_pool.size();
                         off_pool.insert(off_pool.end(), off.begin(), off.end());
                         vals_pool.insert(vals_pool.end(), vals.begin(), vals.end());
                         pair[dir].E = E;
                         pair[dir].Ec = Ec;
-                        pair[dir].rows = kh_ell_rows(e->N);
+                        pair[dir].rows = stream ? (e->N + 63) / 64 * 64 : kh_ell_rows(e->N);
                         pair[dir].pad_ = 0;
                         e->ell_E = std::max(e->ell_E, E);
                     }
@@ -786,8 +806,19 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                 KH_HIP_E(hipMalloc(&e->d_ell_bw, sizeof(KhEll) * e->K));
                 KH_HIP_E(hipMemcpy(e->d_ell_fw, ell_fw.data(), sizeof(KhEll) * e->K, hipMemcpyHostToDevice));
                 KH_HIP_E(hipMemcpy(e->d_ell_bw, ell_bw.data(), sizeof(KhEll) * e->K, hipMemcpyHostToDevice));
+                e->ell_stream = stream;
+                if (stream) {
+                    // one scratch plane per workgroup (update sweep: K of them; plain sweeps: at most one per CU)
+                    e->ell_scratch_stride = (long long)std::max(ec_max, 4) * ((e->N + 63) / 64 * 64);
+                    const int wgs = e->K < e->num_cus ? e->K : e->num_cus;  // (the update sweep takes K <= #CUs workgroups, the plain sweeps at most #CUs)
+                    KH_HIP_E(hipMalloc(&e->d_ell_scratch, sizeof(cplx) * (size_t)e->ell_scratch_stride * wgs));
+                }
             }
         }
+    }
+    if (!e->gen_fits && !ell_ok) {
+        kh_engine_destroy(e);
+        return kh_fail(KH_ERR_UNSUPPORTED, "N=%d: rows wider than 32 entries and no room for the generic kernels' vectors in LDS", pr->N);
     }
     if (pr->op_norms != nullptr) {
         KH_HIP_E(hipMemcpy(e->d_norms, pr->op_norms, sizeof(double) * nops, hipMemcpyHostToDevice));
@@ -1544,19 +1575,25 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
 #undef KH_TN_STORE
     } else if (e->kind_store == KIND_ELL) {
         const KhEll *ells = backward ? e->d_ell_bw : e->d_ell_fw;
-        const int grid = e->K < 4 * e->num_cus ? e->K : 4 * e->num_cus;
-        const size_t lds = kh_ell_lds_bytes();
+        const int grid = e->ell_stream ? (e->K < e->num_cus ? e->K : e->num_cus) : (e->K < 4 * e->num_cus ? e->K : 4 * e->num_cus);
+        const size_t lds = kh_ell_lds_bytes(e->ell_stream);
         // (two vector buffers of KH_ELL_NMAX elements: more than the 64 KiB a kernel gets without asking)
 #define KH_ELL_STORE(T, R, EM)                                                                                        \
     do {                                                                                                              \
         rc = ensure_dynamic_lds(e, (const void *)kh_ell_sweep_store<T, R, EM>, lds);                                  \
         if (rc == KH_OK)                                                                                              \
             launch_plain<kh_ell_sweep_store<T, R, EM>>(dim3(grid), dim3(T), lds, st, p, ells, e->d_ell_off, e->d_ell_vals, \
-                                                       pulses, in, store, out, direction);                           \
+                                                       pulses, in, store, out, direction, (cplx *)nullptr, 0LL);     \
     } while (0)
         // one row per lane where the rows' entries fit the register budget of that many waves (512 threads: 256 VGPRs,
         // 768: 168, 1024: 128), else two rows per lane of a 512-thread workgroup
-        if (e->N <= 512) {
+        if (e->ell_stream) {
+            rc = ensure_dynamic_lds(e, (const void *)kh_ell_sweep_store<512, KH_ELLS_RPL, 4, true>, lds);
+            if (rc == KH_OK)
+                launch_plain<kh_ell_sweep_store<512, KH_ELLS_RPL, 4, true>>(dim3(grid), dim3(512), lds, st, p, ells, e->d_ell_off,
+                                                                             e->d_ell_vals, pulses, in, store, out, direction,
+                                                                             e->d_ell_scratch, e->ell_scratch_stride);
+        } else if (e->N <= 512) {
             if (e->ell_E <= 8) KH_ELL_STORE(512, 1, 8);
             else if (e->ell_E <= 12) KH_ELL_STORE(512, 1, 12);
             else if (e->ell_E <= 16) KH_ELL_STORE(512, 1, 16);
@@ -1613,6 +1650,7 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
             return sweep_store(e, backward, pulses, in, store, out, st);
         }
     } else {
+        if (!e->gen_fits) return kh_fail(KH_ERR_UNSUPPORTED, "N=%d: the generic kernels' vectors do not fit LDS", e->N);
         const size_t lds = kh_gen_lds_bytes(e->N, e->d_csr_fw == nullptr);
         rc = ensure_dynamic_lds(e, (const void *)kh_gen_sweep_store, lds);
         // (the workgroups loop over the objectives: no more of them than the device runs at once -- each may own an
@@ -1814,15 +1852,26 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
 #undef KH_TN_UPDATE
     } else if (e->kind == KIND_ELL && !stepwise) {
         const dim3 g(e->K);
-        const size_t lds = kh_ell_lds_bytes();
+        const size_t lds = kh_ell_lds_bytes(e->ell_stream);
         const bool so = u.sigma != nullptr;
 #define KH_ELL_UPDATE_SO(T, R, EM, SO)                                                                                            \
     (ensure_dynamic_lds(e, (const void *)kh_ell_forward_update<T, R, EM, SO>, lds) != KH_OK                                        \
          ? KH_ERR_HIP                                                                                                              \
          : launch_persistent<kh_ell_forward_update<T, R, EM, SO>>(e, g, dim3(T), lds, st, p, (const KhEll *)e->d_ell_fw,            \
-                                                                  (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex))
+                                                                  (const int *)e->d_ell_off, (const cplx *)e->d_ell_vals, u, ex,    \
+                                                                  (cplx *)nullptr, 0LL))
 #define KH_ELL_UPDATE(T, R, EM) (so ? KH_ELL_UPDATE_SO(T, R, EM, true) : KH_ELL_UPDATE_SO(T, R, EM, false))
-        if (e->N <= 512)
+        if (e->ell_stream) {
+            rc = ensure_dynamic_lds(e, so ? (const void *)kh_ell_forward_update<512, KH_ELLS_RPL, 4, true, true>
+                                          : (const void *)kh_ell_forward_update<512, KH_ELLS_RPL, 4, false, true>, lds);
+            if (rc == KH_OK)
+                rc = so ? launch_persistent<kh_ell_forward_update<512, KH_ELLS_RPL, 4, true, true>>(
+                              e, g, dim3(512), lds, st, p, (const KhEll *)e->d_ell_fw, (const int *)e->d_ell_off,
+                              (const cplx *)e->d_ell_vals, u, ex, e->d_ell_scratch, e->ell_scratch_stride)
+                        : launch_persistent<kh_ell_forward_update<512, KH_ELLS_RPL, 4, false, true>>(
+                              e, g, dim3(512), lds, st, p, (const KhEll *)e->d_ell_fw, (const int *)e->d_ell_off,
+                              (const cplx *)e->d_ell_vals, u, ex, e->d_ell_scratch, e->ell_scratch_stride);
+        } else if (e->N <= 512)
             rc = e->ell_E <= 8 ? KH_ELL_UPDATE(512, 1, 8) : e->ell_E <= 12 ? KH_ELL_UPDATE(512, 1, 12)
                  : e->ell_E <= 16 ? KH_ELL_UPDATE(512, 1, 16) : e->ell_E <= 24 ? KH_ELL_UPDATE(512, 1, 24) : KH_ELL_UPDATE(512, 1, 32);
         else if (e->N <= 768 && e->ell_E <= 16)
@@ -1845,6 +1894,8 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");
         }
     } else {
+        if (!e->gen_fits)
+            return kh_fail(KH_ERR_UNSUPPORTED, "N=%d: this form of the update sweep needs the generic kernels, whose vectors do not fit LDS", e->N);
         const size_t lds = kh_gen_lds_bytes(e->N, e->d_csr_fw == nullptr);
         rc = ensure_dynamic_lds(e, (const void *)kh_gen_forward_update, lds);
         ensure_gen_scratch(e, e->grid_update);

@@ -677,6 +677,51 @@ def test_sparse_operator_sweeps(name, force_generic, monkeypatch):
     eng.close()
 
 
+def test_sparse_liouvillian_of_dimension_4096():
+    """The reference's ``DensityMatrixODEPropagator`` has no size limit (propagators.py:162-327); the register form of
+    the sparse kernels ends at N = 2048 and the generic kernels' LDS vectors at N = 2540.  A d = 64 ladder (N = 4096, 5.9
+    entries per row, two density matrices) must run -- the streamed padded-row kernels -- and give the sweeps of the
+    oracle's restated zvode step at tight tolerances (1e-12 / 1e-14: the integrator's own error is ~1e-10 here) to
+    1e-8; trace preservation to 1e-12 independently of any reference."""
+    from krotov_amd.engine import HipKrotovEngine
+
+    spec = configs.config_sparse_lindblad(d=64, nt=5, K=2)
+    ops = configs.sparse_ops(spec)
+    assert spec.N == 4096
+    eng = HipKrotovEngine(ops, np.diff(spec.tlist), is_super=True)
+    assert eng.kernel == 'ellstream/csr'
+    gp, S, lam = oracle_controls(spec)
+    pulses = np.array(gp)
+    prob = ko.OracleProblem(ops, spec.init, spec.target, spec.tlist, is_super=True,
+                            ode=dict(rtol=1e-12, atol=1e-14, nsteps=200000))
+    fw_T, states = eng.forward(pulses, spec.init, store=True)
+    ref_T, ref_states = ko.forward_propagation(prob, gp, store=True)
+    got = states.cpu().numpy()
+    assert np.abs(got - ref_states).max() < 1e-8
+    d = 64
+    tr = got.reshape(spec.K, len(spec.tlist), d, d).trace(axis1=2, axis2=3)
+    assert np.abs(tr - tr[:, :1]).max() < 1e-12
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.4)
+    # (the backward sweep propagates with the adjoint Liouvillians: the oracle's ODE step takes them as given)
+    adj = [[None if o is None else o.conj().T.tocsr() for o in row] for row in ops]
+    prob_bw = ko.OracleProblem(adj, spec.init, spec.target, spec.tlist, is_super=True, ode=prob.ode)
+    ref_chi = np.empty_like(ref_states)
+    ref_chi[:, -1] = chi_T
+    for n in range(len(spec.tlist) - 2, -1, -1):
+        for k in range(spec.K):
+            ref_chi[k, n] = ko.step_ode(prob_bw.ops[k], [p[n] for p in gp], spec.tlist[n + 1] - spec.tlist[n], ref_chi[k, n + 1], prob.ode)
+    chi = eng.backward(chi_T, pulses)
+    assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-8
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+    eng.check()
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-8 * scale
+    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-8
+    eng.close()
+
+
 def test_density_matrix_ode_propagator_drop_in():
     """optimize_pulses(propagator=DensityMatrixODEPropagator()) with scipy.sparse Liouvillians:
     sparse device path vs the oracle (and vs the dense device path)."""

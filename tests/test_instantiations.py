@@ -47,27 +47,36 @@ case('tn_n128_so', lambda: configs.config_c5(K=2, N=128, nt=7, L=1), ['kh_tn_for
 case('tn_n110_so', lambda: configs.config_c5(K=2, N=110, nt=7, L=1), ['kh_tn_forward_update<28, true, false>'], so=True)
 
 # ---- sparse operators in registers (kh_ell.h): <threads, rows per lane, widest row[, second order]>
-case('ell_e11', lambda: _banded(40, 11, nt=9), ['kh_ell_sweep_store<512, 1, 12>', 'kh_ell_forward_update<512, 1, 12, false>'], sparse=True)
-case('ell_e11_so', lambda: _banded(40, 11, nt=9), ['kh_ell_forward_update<512, 1, 12, true>'], sparse=True, so=True)
-case('ell_n600_e11', lambda: _banded(600, 11, nt=4, K=1), ['kh_ell_sweep_store<768, 1, 12>', 'kh_ell_forward_update<768, 1, 12, false>'], sparse=True)
-case('ell_e21', lambda: _banded(40, 21, nt=9), ['kh_ell_sweep_store<512, 1, 24>', 'kh_ell_forward_update<512, 1, 24, false>'], sparse=True)
-case('ell_e21_so', lambda: _banded(40, 21, nt=9), ['kh_ell_forward_update<512, 1, 24, true>'], sparse=True, so=True)
-case('ell_e29', lambda: _banded(48, 29, nt=9), ['kh_ell_sweep_store<512, 1, 32>', 'kh_ell_forward_update<512, 1, 32, false>'], sparse=True)
-case('ell_e29_so', lambda: _banded(48, 29, nt=9), ['kh_ell_forward_update<512, 1, 32, true>'], sparse=True, so=True)
-case('ell_n800_e15', lambda: _banded(800, 15, nt=4, K=1), ['kh_ell_sweep_store<512, 2, 16>', 'kh_ell_forward_update<512, 2, 16, false>'], sparse=True)
-case('ell_n800_e15_so', lambda: _banded(800, 15, nt=4, K=1), ['kh_ell_forward_update<512, 2, 16, true>'], sparse=True, so=True)
-case('ell_n800_e11_so', lambda: _banded(800, 11, nt=4, K=1), ['kh_ell_forward_update<512, 2, 12, true>'], sparse=True, so=True)
-case('ell_n600_e11_so', lambda: _banded(600, 11, nt=4, K=1), ['kh_ell_forward_update<768, 1, 12, true>'], sparse=True, so=True)
-case('ell_n600_e15', lambda: _banded(600, 15, nt=4, K=1), ['kh_ell_sweep_store<768, 1, 16>', 'kh_ell_forward_update<768, 1, 16, false>'], sparse=True)
-case('ell_n600_e15_so', lambda: _banded(600, 15, nt=4, K=1), ['kh_ell_forward_update<768, 1, 16, true>'], sparse=True, so=True)
-case('ell_n625_so', lambda: configs.config_sparse_lindblad(d=25, nt=5, K=2), ['kh_ell_forward_update<768, 1, 8, true>'], sparse=True, so=True)
-case('ell_n900_so', lambda: configs.config_sparse_lindblad(d=30, nt=4, K=1), ['kh_ell_forward_update<1024, 1, 8, true>'], sparse=True, so=True)
+case('ell_e11', lambda: _banded(40, 11, nt=9), ['kh_ell_sweep_store<512, 1, 12, false>', 'kh_ell_forward_update<512, 1, 12, false, false>'], sparse=True)
+case('ell_e11_so', lambda: _banded(40, 11, nt=9), ['kh_ell_forward_update<512, 1, 12, true, false>'], sparse=True, so=True)
+case('ell_n600_e11', lambda: _banded(600, 11, nt=4, K=1), ['kh_ell_sweep_store<768, 1, 12, false>', 'kh_ell_forward_update<768, 1, 12, false, false>'], sparse=True)
+case('ell_e21', lambda: _banded(40, 21, nt=9), ['kh_ell_sweep_store<512, 1, 24, false>', 'kh_ell_forward_update<512, 1, 24, false, false>'], sparse=True)
+case('ell_e21_so', lambda: _banded(40, 21, nt=9), ['kh_ell_forward_update<512, 1, 24, true, false>'], sparse=True, so=True)
+case('ell_e29', lambda: _banded(48, 29, nt=9), ['kh_ell_sweep_store<512, 1, 32, false>', 'kh_ell_forward_update<512, 1, 32, false, false>'], sparse=True)
+case('ell_e29_so', lambda: _banded(48, 29, nt=9), ['kh_ell_forward_update<512, 1, 32, true, false>'], sparse=True, so=True)
+case('ell_n800_e15', lambda: _banded(800, 15, nt=4, K=1), ['kh_ell_sweep_store<512, 2, 16, false>', 'kh_ell_forward_update<512, 2, 16, false, false>'], sparse=True)
+case('ell_n800_e15_so', lambda: _banded(800, 15, nt=4, K=1), ['kh_ell_forward_update<512, 2, 16, true, false>'], sparse=True, so=True)
+case('ell_n800_e11_so', lambda: _banded(800, 11, nt=4, K=1), ['kh_ell_forward_update<512, 2, 12, true, false>'], sparse=True, so=True)
+case('ell_n600_e11_so', lambda: _banded(600, 11, nt=4, K=1), ['kh_ell_forward_update<768, 1, 12, true, false>'], sparse=True, so=True)
+case('ell_n600_e15', lambda: _banded(600, 15, nt=4, K=1), ['kh_ell_sweep_store<768, 1, 16, false>', 'kh_ell_forward_update<768, 1, 16, false, false>'], sparse=True)
+case('ell_n600_e15_so', lambda: _banded(600, 15, nt=4, K=1), ['kh_ell_forward_update<768, 1, 16, true, false>'], sparse=True, so=True)
+case('ell_n625_so', lambda: configs.config_sparse_lindblad(d=25, nt=5, K=2), ['kh_ell_forward_update<768, 1, 8, true, false>'], sparse=True, so=True)
+case('ell_n900_so', lambda: configs.config_sparse_lindblad(d=30, nt=4, K=1), ['kh_ell_forward_update<1024, 1, 8, true, false>'], sparse=True, so=True)
 
 # 1024 < N <= 2048 with at most 8 entries per row: three / four rows per lane (a d = 40 Lindbladian: N = 1600)
-case('ell_n1089', lambda: configs.config_sparse_lindblad(d=33, nt=3, K=1), ['kh_ell_sweep_store<512, 3, 8>', 'kh_ell_forward_update<512, 3, 8, false>'], sparse=True)
-case('ell_n1089_so', lambda: configs.config_sparse_lindblad(d=33, nt=3, K=1), ['kh_ell_forward_update<512, 3, 8, true>'], sparse=True, so=True)
-case('ell_n1600', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=2), ['kh_ell_sweep_store<512, 4, 8>', 'kh_ell_forward_update<512, 4, 8, false>'], sparse=True)
-case('ell_n1600_so', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=1), ['kh_ell_forward_update<512, 4, 8, true>'], sparse=True, so=True)
+case('ell_n1089', lambda: configs.config_sparse_lindblad(d=33, nt=3, K=1), ['kh_ell_sweep_store<512, 3, 8, false>', 'kh_ell_forward_update<512, 3, 8, false, false>'], sparse=True)
+case('ell_n1089_so', lambda: configs.config_sparse_lindblad(d=33, nt=3, K=1), ['kh_ell_forward_update<512, 3, 8, true, false>'], sparse=True, so=True)
+case('ell_n1600', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=2), ['kh_ell_sweep_store<512, 4, 8, false>', 'kh_ell_forward_update<512, 4, 8, false, false>'], sparse=True)
+case('ell_n1600_so', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=1), ['kh_ell_forward_update<512, 4, 8, true, false>'], sparse=True, so=True)
+
+# the STREAMED form of the same kernels (nothing resident: rows that do not fit the registers, N up to 4096)
+case('ells_n600_e21', lambda: _banded(600, 21, nt=4, K=1), ['kh_ell_sweep_store<512, 8, 4, true>', 'kh_ell_forward_update<512, 8, 4, false, true>'], sparse=True)
+case('ells_n600_e21_so', lambda: _banded(600, 21, nt=4, K=1), ['kh_ell_forward_update<512, 8, 4, true, true>'], sparse=True, so=True)
+case('ells_forced_lindblad', lambda: configs.config_sparse_lindblad(d=12, nt=21, K=3), ['kh_ell_sweep_store<512, 8, 4, true>', 'kh_ell_forward_update<512, 8, 4, false, true>'],
+     env={'KH_KERNEL': 'ellstream'}, sparse=True)
+case('ells_forced_L3_so', lambda: configs.config_c5(K=5, N=12, nt=31, L=3, distinct=True), ['kh_ell_forward_update<512, 8, 4, true, true>'],
+     env={'KH_KERNEL': 'ellstream'}, sparse=True, so=True)
+case('ells_n2116', lambda: configs.config_sparse_lindblad(d=46, nt=3, K=1), ['kh_ell_sweep_store<512, 8, 4, true>', 'kh_ell_forward_update<512, 8, 4, false, true>'], sparse=True)
 
 # ---- streaming register-tile kernel (kh_tile64s.h): <controls, second order, N == 64>
 _k520 = lambda: configs.config_c5(K=520, N=64, nt=6, distinct=True)  # noqa: E731  (three objectives per workgroup)
