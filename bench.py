@@ -382,6 +382,23 @@ def sparse_leg(steps=3, warmup=1):
         e3.close()
     lad['speedup'] = lad['generic']['us_per_propagation'] / lad['ell']['us_per_propagation']
     rec['ladder_3x1600'] = lad
+    # ... and beyond what registers (N <= 2048) and the generic kernels' LDS vectors (N <= 2540) hold: d = 64, N = 4096 on the
+    # streamed form of the sparse kernels (rows read from the pools per term)
+    spec = configs.config_sparse_lindblad(d=64, nt=51, K=3)
+    tl = spec.tlist
+    pulses = np.array([[spec.controls[0](t + 0.5 * (tl[1] - tl[0]), None) for t in tl[:-1]]])
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    e4 = _engine_mod.HipKrotovEngine(configs.sparse_ops(spec), np.diff(tl), is_super=True)
+    e4.profile = True
+    for _ in range(2):
+        chi = e4.backward(chi_T, pulses)
+        e4.forward_update(chi, np.full(3, 1.0 / 6), spec.init, pulses, np.ones((1, 50)), np.full(1, 2.0))
+    e4.check()
+    t4 = e4.kernel_times_ms()
+    rec['ladder_3x4096'] = {'kernel': e4.kernel, 'backward_sweep_ms': min(t4['backward']), 'update_sweep_ms': min(t4['update']),
+                            'us_per_propagation': (min(t4['backward']) + min(t4['update'])) * 1e3 / (3 * 50 * 2),
+                            'terms_per_step': e4.stats()['matvecs'] / (3 * 50)}
+    e4.close()
     return rec
 
 
