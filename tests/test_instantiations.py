@@ -50,6 +50,7 @@ case('tn_n110_so', lambda: configs.config_c5(K=2, N=110, nt=7, L=1), ['kh_tn_for
 case('ell_e11', lambda: _banded(40, 11, nt=9), ['kh_ell_sweep_store<512, 1, 12, false>', 'kh_ell_forward_update<512, 1, 12, false, false>'], sparse=True)
 case('ell_e11_so', lambda: _banded(40, 11, nt=9), ['kh_ell_forward_update<512, 1, 12, true, false>'], sparse=True, so=True)
 case('ell_n600_e11', lambda: _banded(600, 11, nt=4, K=1), ['kh_ell_sweep_store<768, 1, 12, false>', 'kh_ell_forward_update<768, 1, 12, false, false>'], sparse=True)
+case('ell_e15_so', lambda: _banded(40, 15, nt=9), ['kh_ell_forward_update<512, 1, 16, true, false>'], sparse=True, so=True)
 case('ell_e21', lambda: _banded(40, 21, nt=9), ['kh_ell_sweep_store<512, 1, 24, false>', 'kh_ell_forward_update<512, 1, 24, false, false>'], sparse=True)
 case('ell_e21_so', lambda: _banded(40, 21, nt=9), ['kh_ell_forward_update<512, 1, 24, true, false>'], sparse=True, so=True)
 case('ell_e29', lambda: _banded(48, 29, nt=9), ['kh_ell_sweep_store<512, 1, 32, false>', 'kh_ell_forward_update<512, 1, 32, false, false>'], sparse=True)
