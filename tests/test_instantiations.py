@@ -67,7 +67,7 @@ case('ell_n900_so', lambda: configs.config_sparse_lindblad(d=30, nt=4, K=1), ['k
 # 1024 < N <= 2048 with at most 8 entries per row: three / four rows per lane (a d = 40 Lindbladian: N = 1600)
 case('ell_n1089', lambda: configs.config_sparse_lindblad(d=33, nt=3, K=1), ['kh_ell_sweep_store<512, 3, 8, false>', 'kh_ell_forward_update<512, 3, 8, false, false>'], sparse=True)
 case('ell_n1089_so', lambda: configs.config_sparse_lindblad(d=33, nt=3, K=1), ['kh_ell_forward_update<512, 3, 8, true, false>'], sparse=True, so=True)
-case('ell_n1600', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=2), ['kh_ell_sweep_store<512, 4, 8, false>', 'kh_ell_forward_update<512, 4, 8, false, false>'], sparse=True)
+case('ell_n1600', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=1), ['kh_ell_sweep_store<512, 4, 8, false>', 'kh_ell_forward_update<512, 4, 8, false, false>'], sparse=True)
 case('ell_n1600_so', lambda: configs.config_sparse_lindblad(d=40, nt=3, K=1), ['kh_ell_forward_update<512, 4, 8, true, false>'], sparse=True, so=True)
 
 # the STREAMED form of the same kernels (nothing resident: rows that do not fit the registers, N up to 4096)
@@ -77,7 +77,8 @@ case('ells_forced_lindblad', lambda: configs.config_sparse_lindblad(d=12, nt=21,
      env={'KH_KERNEL': 'ellstream'}, sparse=True)
 case('ells_forced_L3_so', lambda: configs.config_c5(K=5, N=12, nt=31, L=3, distinct=True), ['kh_ell_forward_update<512, 8, 4, true, true>'],
      env={'KH_KERNEL': 'ellstream'}, sparse=True, so=True)
-case('ells_n2116', lambda: configs.config_sparse_lindblad(d=46, nt=3, K=1), ['kh_ell_sweep_store<512, 8, 4, true>', 'kh_ell_forward_update<512, 8, 4, false, true>'], sparse=True)
+case('ells_forced_n900', lambda: configs.config_sparse_lindblad(d=30, nt=4, K=2), ['kh_ell_sweep_store<512, 8, 4, true>', 'kh_ell_forward_update<512, 8, 4, false, true>'],
+     env={'KH_KERNEL': 'ellstream'}, sparse=True)  # two rows per lane in use (N = 4096: test_sparse_liouvillian_of_dimension_4096)
 
 # ---- streaming register-tile kernel (kh_tile64s.h): <controls, second order, N == 64>
 _k520 = lambda: configs.config_c5(K=520, N=64, nt=6, distinct=True)  # noqa: E731  (three objectives per workgroup)
