@@ -866,6 +866,27 @@ def test_optimize_pulses_vs_reference_loop_goldens(name):
     assert np.abs(np.array(res.optimized_controls) - g['optimized_controls']).max() < tol * scale
 
 
+@pytest.mark.parametrize('name,ncg', [('ref_c5_n64', '1'), ('ref_c5_n64', '2'), ('ref_c5_small', '4')])
+def test_ensemble_kernel_vs_reference_loop_goldens(name, ncg, monkeypatch):
+    """The matrix-core ensemble kernel (kh_ens.h; forced onto the small robustness ensembles with KH_ENS=1) through
+    ``optimize_pulses`` vs the outputs of the reference's own loop on the same inputs (2e-12 vs
+    ``ref_c5_n64``)."""
+    import krotov_amd.engine as engine_mod
+
+    monkeypatch.setenv('KH_ENS', '1')
+    monkeypatch.setenv('KH_ENS_NCG', ncg)
+    g = golden(name)
+    spec = GOLDEN_CASES[name]()
+    res = _optimize_on_device(spec, int(g['iter_stop']))
+    assert engine_mod.LAST_ENGINE().kernel == 'ens64/mfma'
+    got = np.array([np.array(p) for p in res.all_pulses])
+    scale = max(1.0, np.abs(g['all_pulses']).max())
+    assert np.abs(got - g['all_pulses']).max() < 2e-12 * scale
+    assert np.abs(np.array(res.tau_vals) - g['tau_vals']).max() < 2e-12
+    fw_T = np.array([np.asarray(s).ravel(order='F') for s in res.states])
+    assert np.abs(fw_T - g['fw_T']).max() < 2e-12
+
+
 def test_tls_dump_18_iterations_on_device():
     """reference tests/test_result_serialization/oct_result.dump: every pulse of
     all 18 iterations (4.5k sequential steps each way per iteration) to 1e-9."""
