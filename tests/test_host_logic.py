@@ -390,3 +390,97 @@ def test_bench_starts_its_own_ranks(monkeypatch):
     tail = cmd[cmd.index(os.path.join(root, 'bench.py')) + 1:]
     assert tail == ['--gpus', '4', '--steps', '3', '--warmup', '1']
     assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
+
+
+def test_update_sweep_retry_ladder_on_the_host(monkeypatch, caplog):
+    """``_HipBackend.iterate`` after KH_ERR_TIMEOUT (the single-launch update sweep's workgroups were not all resident):
+    half the workgroups, half again, ... through ``set_update_workgroups``; only when the engine has no smaller grid one
+    launch per interval; the full grid again at the next iteration, a reduced one kept after three iterations in a row
+    that needed it.  Driven on the CPU with the oracle-backed engine double, whose single-launch sweep
+    "times out" above a scripted number of workgroups; the pulses must be the oracle's whatever path was taken."""
+    import logging
+
+    import krotov_amd
+    import krotov_amd.engine as engine_mod
+    from helpers import oracle_optimize
+    from krotov_amd import _lib, configs
+    from oracle_engine_double import OracleEngineDouble
+
+    script = {'fits': 2, 'floor': 1, 'calls': [], 'stepwise': 0}
+
+    class Flaky(OracleEngineDouble):
+        grid = None  # None: the engine's own (K workgroups)
+
+        def set_update_workgroups(self, g=0):
+            script['calls'].append(g)
+            if g == 0:
+                self.grid = None
+                return self.K
+            if g < script['floor']:
+                raise _lib.KrotovHipError("no such grid", _lib.KH_ERR_UNSUPPORTED)
+            self.grid = g
+            return g
+
+        def forward_update(self, *a):
+            if (self.grid or self.K) > script['fits']:
+                raise _lib.KrotovHipError("timed out", _lib.KH_ERR_TIMEOUT)
+            return super().forward_update(*a)
+
+        def forward_update_sharded(self, *a, **kw):
+            script['stepwise'] += 1 if kw.get('graph_chunk') == 0 else 0
+            return super().forward_update_sharded(*a, **kw)
+
+    monkeypatch.setattr(engine_mod, 'HipKrotovEngine', Flaky)
+    caplog.set_level(logging.WARNING, logger='krotov')
+    spec = configs.config_c5(K=8, N=4, nt=9, L=1, distinct=True)
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    kw = dict(propagator=krotov_amd.propagators.expm, chi_constructor=krotov_amd.functionals.chis_re, store_all_pulses=True)
+    ref = oracle_optimize(spec, 5)
+
+    # 8 workgroups never fit, 2 do: 8 -> 4 -> 2 in every iteration; after three such iterations the 2 are kept
+    res = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=5, **kw)
+    assert np.abs(np.array(res.all_pulses) - ref['all_pulses']).max() < 1e-12
+    assert script['stepwise'] == 0
+    # iterations 1..3: query the full grid (0), ask for 4, query (0), ask for 2, and reset (0) afterwards -- except after
+    # the third, where the reduced grid stays; iterations 4, 5: no call at all (the sweep runs on 2 straight away)
+    assert script['calls'] == [0, 4, 0, 2, 0] * 2 + [0, 4, 0, 2]
+    assert caplog.text.count('repeating it on 4 workgroups') == 3 and caplog.text.count('repeating it on 2 workgroups') == 3
+
+    # no grid fits and the engine refuses anything below 4: one launch per interval, for good after three sweeps
+    script.update(fits=0, floor=4, calls=[], stepwise=0)
+    caplog.clear()
+    res = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=5, **kw)
+    assert np.abs(np.array(res.all_pulses) - ref['all_pulses']).max() < 1e-12
+    assert script['stepwise'] == 5
+    assert caplog.text.count('one launch per interval') == 3 and 'staying with that form' in caplog.text
+    assert script['calls'] == [0, 4, 0, 2, 0] * 3  # (4 is tried and times out, 2 is refused: reset) -- then never again
+
+
+def test_bench_leg_traffic_is_keyed_on_the_build_and_scaled_per_interval(tmp_path, monkeypatch):
+    """bench.py's ``pmc_traffic_leg``: counters of another build of the kernels are refused, bytes = (2 x FETCH_SIZE +
+    WRITE_SIZE) x 1024 (the one convention), scaled from the profiled run's intervals to the leg's; the
+    instantiation with the largest traffic stands for a kernel name without template arguments."""
+    import json
+
+    import bench
+
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    rec = {'_build': 'B1', '_convention': 'x',
+           'K1024': {'_config': {'K': 1024, 'N': 64, 'nt': 501, 'L': 1, 'command': 'perf_sweeps.py 1024 64 501 1'},
+                     'kh_ens_forward_update<2, false>': {'FETCH_SIZE': {'avg_per_launch': 1000.0, 'launches': 3},
+                                                         'WRITE_SIZE': {'avg_per_launch': 48.0, 'launches': 3}},
+                     'kh_ens_forward_update<2, true>': {'FETCH_SIZE': {'avg_per_launch': 10.0, 'launches': 1},
+                                                        'WRITE_SIZE': {'avg_per_launch': 1.0, 'launches': 1}},
+                     'kh_q2_sweep_store': {'FETCH_SIZE': {'avg_per_launch': 7.0, 'launches': 3}}}}
+    (prof / 'pmc_tile_latest.json').write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    monkeypatch.setattr(bench, 'build_id', lambda: 'B1')
+    t, src = bench.pmc_traffic_leg('K1024', 'kh_ens_forward_update', 4000)
+    assert t == (2 * 1000.0 + 48.0) * 1024.0 * 4000 / 500 and 'scaled to 4000' in src
+    assert bench.pmc_traffic_leg('K1024', 'kh_q2_sweep_store', 4000)[0] is None  # (no WRITE_SIZE pass of that kernel)
+    assert bench.pmc_traffic_leg('L4', 'kh_tile_forward_update', 4000)[0] is None
+    monkeypatch.setattr(bench, 'build_id', lambda: 'B2')
+    t, src = bench.pmc_traffic_leg('K1024', 'kh_ens_forward_update', 4000)
+    assert t is None and 'another build' in src
+    assert bench.pmc_traffic_leg('config4', 'kh_coop_forward_update', 1000) == (None, 'no profiles/pmc_config4_latest.json')
