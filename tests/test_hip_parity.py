@@ -1743,7 +1743,9 @@ def test_update_sweep_next_to_a_busy_stream(monkeypatch):
     assert float((halved[0] - solo[0]).abs().max()) < 1e-12 * scale
     assert float((halved[1] - solo[1]).abs().max()) < 1e-12
     print("update sweep: %.2f ms undisturbed, %.2f ms on %d workgroups next to the busy stream" % (ms_solo, ms_halved, grid))
-    assert ms_halved <= 3.0 * ms_solo
+    # (measured 2.6-2.8x on three boxes, profiles/r05/busy_stream.txt; one launch per interval is ~10x: the bound leaves
+    # room for the timer's and the other stream's jitter without letting that regression through)
+    assert ms_halved <= 3.5 * ms_solo
     assert eng.set_update_workgroups(0) == spec.K
     # ... and the last resort: one launch per interval
     again = eng.forward_update_sharded(*a, lambda x: None, graph_chunk=0)
