@@ -605,9 +605,13 @@ def main():
                     torch.distributed.all_reduce(x)
                 torch.cuda.synchronize()
                 mine['allreduce_us'] = (time.perf_counter() - t0) / 200 * 1e6
-            gathered = [None] * world
-            torch.distributed.all_gather_object(gathered, mine)
-            diag = gathered
+            try:
+                gathered = [None] * world
+                torch.distributed.all_gather_object(gathered, mine)
+                diag = gathered
+            except Exception as exc:  # (diagnostics must not cost the measurement: the line then carries this rank's only)
+                mine['gather_error'] = repr(exc)[:160]
+                diag = [mine]
 
         if rank == 0:
             K_loc = eng.K
