@@ -20,7 +20,9 @@ def pytest_configure(config):
     fd, path = tempfile.mkstemp(prefix='kh_launch_log_', suffix='.txt')
     os.close(fd)
     config._kh_launch_log = path
-    config._kh_full_run = not config.getoption('keyword') and all(os.path.isdir(a.split('::')[0]) for a in config.args)
+    # (a full run in ONE process: pytest-xdist workers each see a part of the suite and keep their own log)
+    config._kh_full_run = (not config.getoption('keyword') and all(os.path.isdir(a.split('::')[0]) for a in config.args)
+                           and not hasattr(config, 'workerinput') and not getattr(config.option, 'numprocesses', None))
 
 
 def pytest_unconfigure(config):
