@@ -656,7 +656,8 @@ def main():
                                 'L=%d control, chis_re, complex128; one step = one Krotov iteration '
                                 '(backward sweep + forward/update sweep)' % (
                                     K_total, ' (%d per GPU)' % eng.K if world > 1 else '', args.N, args.nt - 1, args.L),
-                    'objectives': K_total, 'N': args.N, 'time_steps': args.nt - 1, 'controls': args.L,
+                    'objectives': K_total, 'objectives_total': K_total, 'objectives_per_gpu': eng.K,
+                    'N': args.N, 'time_steps': args.nt - 1, 'controls': args.L,
                     'distinct_drifts': bool(args.distinct),
                     'parallelism': 'objectives sharded over %d GPU(s); per time step the L update sums cross the '
                                    'GPUs %s' % (world, 'inside the persistent kernel (peer-mapped windows over xGMI)'
@@ -805,13 +806,27 @@ def main():
         finally:
             watchdog.cancel()
 
+    def name_the_baseline_job(strong_line):
+        # BASELINE.json's config 5 is 256 objectives IN TOTAL: on N > 1 GPUs that is the strong-scaling job, whichever of
+        # the two is the headline.  A reader of `value` alone at N = 8 (weak: 2 048 objectives) finds the figure for the
+        # job BASELINE names right next to it, under a name that says so.
+        if rank == 0 and strong_line is not None and args.workload == 'c5':
+            out['value_baseline_config5'] = strong_line['value']
+            out['ms_per_step_baseline_config5'] = strong_line['ms_per_step']
+            out['baseline_config5_objectives_total'] = strong_line['config']['objectives_total']
+
+    if world == 1 or args.scaling == 'strong':
+        name_the_baseline_job(out if rank == 0 else None)
     if world > 1 and args.workload == 'c5':
         # the same job with the other partitioning of the objectives (see the module docstring) -- like every side
         # measurement of a sharded run under the watchdog: the headline line above must get out whatever happens here
         second = guarded(other, args.rccl_leg_timeout, lambda: measure(other))
+        if other == 'strong':
+            name_the_baseline_job(second)
         if rank == 0 and second is not None:
             out[other] = {k: second[k] for k in ('value', 'unit', 'iterations_per_sec', 'ms_per_step', 'scaling')}
             out[other]['objectives'] = second['config']['objectives']
+            out[other]['objectives_total'] = second['config']['objectives_total']
             out[other]['kernels'] = {k: second['kernels'][k] for k in ('backward_sweep_ms', 'update_sweep_ms')}
             for k in ('ranks', 'predicted'):
                 if k in second:

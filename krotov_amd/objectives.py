@@ -542,16 +542,24 @@ def ensemble_objectives(objectives, Hs, *, keep_original_objectives=True):
 
 
 def _dense_liouvillian(H, c_ops):
-    """Column-stacking Liouvillian of dense arrays (cf. configs.liouvillian_dense)."""
+    """Column-stacking Liouvillian (cf. configs.liouvillian_dense): a dense array for array operators; for a
+    QuTiP-like ``H`` (``.full()`` and ``.dims``) an object of the same class built through its constructor with
+    the super-operator dims ``[[rows, rows], [cols, cols]]`` of ``qutip.liouvillian`` -- so that it carries
+    ``.type == 'super'``, which the propagators and ``mu`` dispatch on (reference propagators.py:96-114, mu.py:130)."""
     from .configs import liouvillian_dense
     from ._ingest import to_dense
 
-    return liouvillian_dense(to_dense(H), [to_dense(c) for c in c_ops])
+    arr = liouvillian_dense(to_dense(H), [to_dense(c) for c in c_ops])
+    dims = getattr(H, 'dims', None)
+    if hasattr(H, 'full') and dims is not None:
+        return H.__class__(arr, dims=[[list(dims[0]), list(dims[0])], [list(dims[1]), list(dims[1])]])
+    return arr
 
 
 def liouvillian(H, c_ops):
     """Liouvillian of a (possibly nested-list) Hamiltonian and constant
-    Lindblad operators, as dense arrays for column-stacked vec(rho)
+    Lindblad operators for column-stacked vec(rho): dense arrays for array
+    operators, super-operators of the operators' own class for QuTiP-like ones
     (reference objectives.py:1097-1121 delegates to qutip.liouvillian)."""
     c_ops = list(c_ops or [])
     if not isinstance(H, list):

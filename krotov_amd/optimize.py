@@ -35,7 +35,7 @@ from functools import partial
 import numpy as np
 
 from . import functionals as _functionals
-from ._ingest import obj_type, state_to_vector, to_dense, to_sparse, vector_to_state
+from ._ingest import obj_type, state_array, state_to_vector, to_dense, to_sparse, vector_to_state
 from .conversions import (
     control_onto_interval,
     discretize,
@@ -482,7 +482,7 @@ class _HipBackend:
             if obj_type(first_op) is not None:
                 liouville = obj_type(first_op) == 'super'
             else:
-                s0 = np.asarray(objectives[self.k0].initial_state)
+                s0 = state_array(objectives[self.k0].initial_state)
                 liouville = bool(s0.ndim == 2 and s0.shape[0] == s0.shape[1] and s0.shape[0] > 1 and s0.size == N)
         self.is_super = liouville
         self.N, self.L = N, L

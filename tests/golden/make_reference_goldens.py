@@ -329,18 +329,18 @@ def run_reference(spec, iter_stop, krotov=None, sigma=None):
 
 REF_CASES = {
     # name: (builder kwargs -> spec, iter_stop)
-    'ref_c1_tls': (lambda c: c.config_c1(), 3),
-    'ref_c2_hilbert': (lambda c: c.config_c2_hilbert(), 2),
-    'ref_c2_liouville': (lambda c: c.config_c2_liouville(), 2),
-    'ref_c3_iswap': (lambda c: c.config_c3(), 2),
-    'ref_c4_small': (lambda c: c.config_c4(d=5, nt=201, n_logical=2), 2),
-    'ref_c5_small': (lambda c: c.config_c5(K=6, N=16, nt=201, L=1), 2),
-    'ref_c5_small_L3': (lambda c: c.config_c5(K=5, N=12, nt=151, L=3, distinct=True), 2),
-    'ref_c5_n64': (lambda c: c.config_c5(K=8, N=64, nt=401, L=1), 2),
+    'ref_c1_tls': (lambda c: c.config_c1(), 5),
+    'ref_c2_hilbert': (lambda c: c.config_c2_hilbert(), 5),
+    'ref_c2_liouville': (lambda c: c.config_c2_liouville(), 5),
+    'ref_c3_iswap': (lambda c: c.config_c3(), 5),
+    'ref_c4_small': (lambda c: c.config_c4(d=5, nt=201, n_logical=2), 5),
+    'ref_c5_small': (lambda c: c.config_c5(K=6, N=16, nt=201, L=1), 5),
+    'ref_c5_small_L3': (lambda c: c.config_c5(K=5, N=12, nt=151, L=3, distinct=True), 5),
+    'ref_c5_n64': (lambda c: c.config_c5(K=8, N=64, nt=401, L=1), 5),
     # chis_hs (functionals.py:389-437): the boundary co-state depends on rho(T) itself, not only on tau
     # (config_c2_liouville is no use here: one of its three states is invariant, chi_k(T) = 0, and the reference
     # divides by its norm -- NaN pulses)
-    'ref_c4_small_hs': (lambda c: _with_chi(c.config_c4(d=5, nt=201, n_logical=2), 'hs'), 2),
+    'ref_c4_small_hs': (lambda c: _with_chi(c.config_c4(d=5, nt=201, n_logical=2), 'hs'), 5),
 }
 
 

@@ -15,7 +15,10 @@ from oracle import krotov_oracle as ko
 
 class OracleEngineDouble:
     def __init__(self, ops, dt, is_super=False, **kw):
-        self.ops = [[None if o is None else np.asarray(o, dtype=np.complex128) for o in row] for row in ops]
+        def dense(o):  # (CSR operators of the sparse engine form: the oracle works on dense arrays)
+            return np.asarray(o.toarray() if hasattr(o, 'toarray') else o, dtype=np.complex128)
+
+        self.ops = [[None if o is None else dense(o) for o in row] for row in ops]
         self.K, self.L = len(ops), len(ops[0]) - 1
         self.N = self.ops[0][0].shape[0]
         self.dt = np.asarray(dt, dtype=np.float64)
@@ -35,8 +38,18 @@ class OracleEngineDouble:
 
     def forward(self, pulses, init, store=False):
         init = np.asarray(self.dev(init, torch.complex128).numpy())
-        fw = ko.forward_propagation(self._prob(init), list(self.dev(pulses, torch.float64).numpy()))
-        return torch.from_numpy(fw)
+        pulses = list(self.dev(pulses, torch.float64).numpy())
+        if store:
+            fw, states = ko.forward_propagation(self._prob(init), pulses, store=True)
+            return torch.from_numpy(fw), torch.from_numpy(states)
+        return torch.from_numpy(ko.forward_propagation(self._prob(init), pulses))
+
+    _so = None
+
+    def set_second_order(self, fw_prev=None, fw_store=None, sigma_vals=None):
+        """As HipKrotovEngine.set_second_order: the following update sweeps add 0.5 sigma_n <phi - phi_prev|mu|phi>
+        and write their trajectory into ``fw_store`` (in place: the caller swaps the two buffers)."""
+        self._so = None if fw_prev is None else (fw_prev, fw_store, self.dev(sigma_vals, torch.float64).numpy())
 
     def backward(self, chi_T, pulses, out=None):
         chi_T = self.dev(chi_T, torch.complex128).numpy()
@@ -44,6 +57,16 @@ class OracleEngineDouble:
         return torch.from_numpy(res)
 
     def forward_update(self, chi_store, chi_norms, init, guess, shape, lambdas):
+        if self._so is not None:
+            fw_prev, fw_store, sig = self._so
+            init_h = np.asarray(self.dev(init, torch.complex128).numpy())
+            opt, fw, g_a, out = ko.forward_update_sweep(
+                self._prob(init_h), self.dev(chi_store, torch.complex128).numpy(),
+                self.dev(chi_norms, torch.float64).numpy(), list(self.dev(guess, torch.float64).numpy()),
+                list(self.dev(shape, torch.float64).numpy()), list(self.dev(lambdas, torch.float64).numpy()),
+                sigma_vals=sig, fw_prev=fw_prev.numpy(), store=True)
+            fw_store.copy_(torch.from_numpy(out))
+            return torch.from_numpy(np.array(opt)), torch.from_numpy(fw), torch.from_numpy(g_a)
         return self.forward_update_sharded(chi_store, chi_norms, init, guess, shape, lambdas, lambda t: t)
 
     def forward_update_sharded(self, chi_store, chi_norms, init, guess, shape, lambdas, all_reduce, graph_chunk=None):

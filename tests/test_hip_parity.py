@@ -1187,6 +1187,67 @@ def test_full_size_c5_properties():
     eng.close()
 
 
+FULL_SIZE_LEGS = {
+    # what bench.py publishes next to the headline, at the sizes it publishes them
+    'L4': (dict(L=4), 'tile64/512'),
+    'distinct': (dict(distinct=True), 'tile64q2/512'),
+    'N96': (dict(N=96), 'tile128/512'),
+    'K1024': (dict(K=1024), 'ens64/mfma'),
+    'K1024_distinct': (dict(K=1024, distinct=True), 'tile64/stream'),
+}
+
+
+@pytest.mark.parametrize('leg', sorted(FULL_SIZE_LEGS))
+def test_full_size_published_legs_properties(leg, monkeypatch):
+    """The side legs of the bench line at FULL size (4000 intervals): no oracle finishes there, so
+    size-independent properties -- norms conserved along the stored trajectory, <chi(t_n)|phi(t_n)> constant in n,
+    tau = the stored overlap at T, the update sweep bitwise repeatable and shape-limited -- and the first 200 intervals
+    of the update sweep against the GENERIC kernels on the same co-states (the sequential update of interval n depends
+    on intervals <= n only, so a prefix is a complete problem of its own)."""
+    import torch
+
+    kw, want_kernel = FULL_SIZE_LEGS[leg]
+    spec = configs.config_c5(**kw)
+    eng = _engine(spec)
+    assert eng.kernel == want_kernel
+    gp, S, lam = oracle_controls(spec)
+    pulses, S, lam = np.array(gp), np.array(S), np.array(lam)
+    fw_T, states = eng.forward(pulses, spec.init, store=True)
+    assert float((torch.linalg.vector_norm(states, dim=2) - 1).abs().max()) < 1e-11
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    chi = eng.backward(chi_T, pulses)
+    ov = (chi.conj() * states).sum(dim=2)  # (K, nt)
+    assert float((ov - ov[:, -1:]).abs().max()) < 1e-10
+    assert float((eng.tau(spec.target, fw_T) - ov[:, -1]).abs().max()) < 1e-13
+    del states, ov
+    norms = np.full(spec.K, 1.0 / (2 * spec.K))
+    a = eng.forward_update(chi, norms, spec.init, pulses, S, lam)
+    eng.check()
+    b = eng.forward_update(chi, norms, spec.init, pulses, S, lam)
+    eng.check()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    opt = a[0].cpu().numpy()
+    assert np.all(np.isfinite(opt)) and np.array_equal(opt[:, 0], pulses[:, 0]) and np.array_equal(opt[:, -1], pulses[:, -1])
+    assert np.abs(opt - pulses).max() > 1e-6  # (the sweep did update)
+    assert float((torch.linalg.vector_norm(a[1], dim=1) - 1).abs().max()) < 1e-11
+    # the 200-interval prefix on the generic kernels: same operators, same co-states, same guess
+    n_pre = 200
+    chi_pre = chi[:, :n_pre + 1].contiguous()
+    eng.close()
+    del chi, a, b
+    monkeypatch.setenv('KH_KERNEL', 'generic')
+    from krotov_amd.engine import HipKrotovEngine
+
+    ops = [[spec.H0[k]] + [spec.Hc[k][l] for l in range(spec.L)] for k in range(spec.K)]
+    gen = HipKrotovEngine(ops, np.diff(spec.tlist)[:n_pre], is_super=False)
+    assert gen.kernel == 'generic'
+    g_opt, _, _ = gen.forward_update(chi_pre, norms, spec.init, pulses[:, :n_pre].copy(), S[:, :n_pre].copy(), lam)
+    gen.check()
+    scale = max(1.0, np.abs(opt).max())
+    assert np.abs(g_opt.cpu().numpy() - opt[:, :n_pre]).max() < 1e-12 * scale
+    gen.close()
+
+
 def _two_rank_spec(case):
     """'c5': per-objective operators, register-tile kernels; 'c4': objectives sharing one
     operator list with N > 64 (BASELINE config 4's shape, small): cooperative matrix-core
@@ -1227,10 +1288,22 @@ def _two_rank_spec(case):
     return configs.config_c4(d=9, nt=41, n_logical=3)  # N = 81, K = 9 -> 5 + 4 objectives
 
 
+def _rank_placement(rank, world):
+    """(device index, backend, one_device_per_rank) of a test rank: with at least ``world`` GPUs in the box every rank
+    gets its own device and the host collectives are RCCL (``nccl``) -- the sums then cross xGMI through real peer
+    windows --; with fewer (the one-GPU box these tests were written on) the ranks share devices round-robin and gloo
+    moves the tensors through the host (RCCL refuses two ranks on one device).  The same rule as bench.py."""
+    import torch
+
+    n_dev = max(1, torch.cuda.device_count())
+    own = n_dev >= world
+    return rank % n_dev, os.environ.get('KH_DIST_BACKEND', 'nccl' if own else 'gloo'), own
+
+
 def _two_rank_worker(rank, world, port, queue, case='c5'):
-    """One of two ranks sharing the single GPU (gloo moves the CUDA tensors through
-    the host): the real multi-rank device path -- kh_update_begin/step/end with an
-    all-reduce per interval, tau / state all-gathers -- minus RCCL itself."""
+    """One of ``world`` ranks (see _rank_placement: one GPU each where the box has them, else sharing the single GPU with
+    gloo moving the CUDA tensors through the host): the real multi-rank device path -- peer windows inside the
+    persistent kernels, or kh_update_begin/step/end with an all-reduce per interval; tau / state all-gathers."""
     import os
     import sys
 
@@ -1241,8 +1314,17 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    from test_hip_parity import _rank_placement
+
+    dev, backend, own_device = _rank_placement(rank, world)
+    torch.cuda.set_device(dev)
+    if not own_device:
+        os.environ.setdefault('KH_COOP_XCD', '0')  # (ranks sharing a device must not claim the same XCDs: DESIGN.md 4)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         import krotov_amd as ka
         from krotov_amd import configs as cfg
@@ -1280,7 +1362,13 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
         used_p2p = bool(getattr(eng, '_p2p_used', False))
         if used_p2p and getattr(eng, '_p2p_fell_back', False):
             used_p2p = 'fallback'  # (peer windows first, then -- after a failed sweep -- the per-interval transport)
-        queue.put((rank, np.array(res.all_pulses), np.array(res.tau_vals), used_p2p, eng.kernel))
+        try:
+            p2p = eng.p2p_stats() if used_p2p else None
+        except Exception as exc:
+            p2p = {'error': repr(exc)[:200]}
+        diag = {'device': dev, 'backend': dist.get_backend(), 'own_device': own_device, 'world': dist.get_world_size(),
+                'p2p': p2p, 'why': getattr(eng, 'p2p_why', None)}
+        queue.put((rank, np.array(res.all_pulses), np.array(res.tau_vals), used_p2p, eng.kernel, diag))
     finally:
         dist.destroy_process_group()
 
@@ -1312,7 +1400,7 @@ def test_two_ranks_sharded_on_one_gpu(case):
     else:
         ref = oracle_optimize(spec, 2)
     tol = 1e-12 if case in ('c5', 'c3', 'k1100', 'k1100ens', 'n80', 'sparse') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
-    for _, pulses, tau, used_p2p, kernel in out:
+    for _, pulses, tau, used_p2p, kernel, _diag in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
         assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/stream', 'k1100ens': 'ens64/mfma',
@@ -1322,13 +1410,15 @@ def test_two_ranks_sharded_on_one_gpu(case):
     # peer-mapped windows -- not through the per-interval fallback
     if case == 'k1100':
         assert not any(o[3] for o in out)
+        _check_placement(out, 2, windows=False)
     elif os.environ.get('KH_P2P', '1') != '0':
-        assert all(o[3] for o in out), "peer-window exchange was not used: %r" % ([o[3] for o in out],)
+        assert all(o[3] for o in out), "peer-window exchange was not used: %r" % ([(o[3], o[5]['why']) for o in out],)
+        _check_placement(out, 2, windows=True)
 
 
 def _run_ranks(world, case, env=None, timeout=600):
     """`world` ranks sharing the one GPU (spawned processes, gloo for the host collectives); returns their records
-    (rank, all_pulses, tau_vals, used_p2p, kernel) in rank order."""
+    (rank, all_pulses, tau_vals, used_p2p, kernel, diag) in rank order."""
     import socket
 
     import torch.multiprocessing as mp
@@ -1358,6 +1448,27 @@ def _run_ranks(world, case, env=None, timeout=600):
     return out
 
 
+def _check_placement(out, world, windows):
+    """What a box with one GPU per rank must show (nothing to assert where the ranks share a device): every rank on its
+    own device, RCCL underneath ``torch.distributed`` with ``world`` ranks, and -- when the sums went through the peer
+    windows -- ``kh_p2p_stats`` reporting ``world`` ranks and a non-zero wait between publishing this GPU's sum and
+    holding every GPU's (the cross-GPU hop: over xGMI here)."""
+    import torch
+
+    diags = [o[5] for o in out]
+    assert all(d['world'] == world for d in diags)
+    if torch.cuda.device_count() < world:
+        assert not any(d['own_device'] for d in diags)
+        return False
+    assert sorted(d['device'] for d in diags) == list(range(world)), diags
+    assert all(d['own_device'] and d['backend'] == 'nccl' for d in diags), diags
+    if windows:
+        for d in diags:
+            assert d['p2p'] is not None and 'error' not in d['p2p'], d
+            assert d['p2p']['ranks'] == world and d['p2p']['cross_gpu_wait_us'] > 0.0, d
+    return True
+
+
 @pytest.mark.parametrize('case,world', [('c5w8', 8), ('c5w4', 4), ('c4w4', 4), ('c4w8', 8), ('c5w4L2', 4)])
 def test_ranks_sharded_on_one_gpu_world_4_and_8(case, world):
     """BASELINE's partitions at world = 4 and 8: config 5 as 8 x 32 objectives of N = 64 -- its
@@ -1371,13 +1482,14 @@ def test_ranks_sharded_on_one_gpu_world_4_and_8(case, world):
     tol = 1e-12 if case.startswith('c5') else 1e-11
     want_kernel = {'c5w8': 'tile64q2/512', 'c5w4': 'tile64q2/512', 'c5w4L2': 'tile64/512'}.get(case, 'coop16/mfma')
     assert len(out) == world
-    for _, pulses, tau, used_p2p, kernel in out:
+    for _, pulses, tau, used_p2p, kernel, _diag in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
         assert kernel == want_kernel
         assert np.array_equal(pulses, out[0][1]) and np.array_equal(tau, out[0][2])
     if os.environ.get('KH_P2P', '1') != '0':
-        assert all(o[3] for o in out), "peer-window exchange was not used: %r" % ([o[3] for o in out],)
+        assert all(o[3] for o in out), "peer-window exchange was not used: %r" % ([(o[3], o[5]['why']) for o in out],)
+        _check_placement(out, world, windows=True)
 
 
 @pytest.mark.parametrize('case,world,fail_rank', [('c5w4', 4, 2), ('c4w4', 4, 0)])
@@ -1392,12 +1504,30 @@ def test_exchange_timeout_mid_sweep_falls_back_on_all_ranks(case, world, fail_ra
     spec = _two_rank_spec(case)
     ref = oracle_optimize(spec, 2)
     tol = 1e-12 if case.startswith('c5') else 1e-11
-    for _, pulses, tau, used_p2p, kernel in out:
+    for _, pulses, tau, used_p2p, kernel, _diag in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
         assert np.array_equal(pulses, out[0][1])
     # the first sweep went through the windows, the second one fell back: the engine records both
     assert all(o[3] == 'fallback' for o in out), [o[3] for o in out]
+    _check_placement(out, world, windows=False)
+
+
+@pytest.mark.parametrize('case,world', [('c5', 2), ('c5w4', 4)])
+def test_ranks_with_one_all_reduce_per_interval(case, world):
+    """The north star's transport with more than one rank (``KH_P2P=0``): kh_update_begin / step_dev / end with one
+    all-reduce of the L sums per time interval -- RCCL with ``world`` ranks and HIP-graph replay of the interval loop
+    where the box has a GPU per rank, gloo through the host where the ranks share the one GPU.  Same numbers either
+    way: the oracle's, bit-identical on all ranks."""
+    out = _run_ranks(world, case, env={'KH_P2P': '0'})
+    spec = _two_rank_spec(case)
+    ref = oracle_optimize(spec, 2)
+    for _, pulses, tau, used_p2p, kernel, diag in out:
+        assert np.abs(pulses - ref['all_pulses']).max() < 1e-12 * max(1.0, np.abs(ref['all_pulses']).max())
+        assert np.abs(tau - ref['tau_vals']).max() < 1e-12
+        assert np.array_equal(pulses, out[0][1]) and np.array_equal(tau, out[0][2])
+        assert not used_p2p and diag['why'] == 'KH_P2P=0'
+    _check_placement(out, world, windows=False)
 
 
 def test_full_size_c4_liouville_properties(monkeypatch):
@@ -1976,7 +2106,40 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert 'error' not in rec['config4'], rec['config4']
     assert rec['config4']['kernel'].startswith('coop') and rec['config4']['value'] > 0
     assert rec['value'] > 0 and rec['roofline']['frac'] > 0
+    # the weak headline names its total, and the figure of the job BASELINE names (--K objectives IN TOTAL) sits beside it
+    assert rec['config']['objectives_total'] == 256 and rec['config']['objectives_per_gpu'] == 128
+    assert rec['value_baseline_config5'] == rec['strong']['value'] and rec['baseline_config5_objectives_total'] == 128
     _check_rank_diagnostics(rec, 2)
+
+
+@pytest.mark.no_oracle
+def test_bench_two_gpus_strong_scaling_where_the_box_has_them():
+    """``python bench.py --gpus 2 --scaling strong`` on a box with at least two GPUs: BASELINE config 5 to the letter (256
+    objectives in total, 128 per GPU) with one rank per device -- RCCL underneath, the sums through peer windows over
+    xGMI.  Skipped on the one-GPU box these tests were written on (the same command line with ranks sharing the device
+    is test_bench_self_launches_two_ranks)."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU in this box: nothing crosses xGMI")
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.pop('KH_DIST_BACKEND', None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--scaling', 'strong', '--steps', '2', '--warmup', '1',
+           '--no-cpu-baseline', '--nt', '401']
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    rec = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{')][0])
+    assert rec['n_gpus'] == 2 and rec['n_ranks_seen'] == 2 and rec['scaling'] == 'strong'
+    assert rec['config']['objectives_total'] == 256 and rec['config']['objectives_per_gpu'] == 128
+    assert rec['value_baseline_config5'] == rec['value'] and rec['weak']['objectives_total'] == 512
+    assert sorted(r['device'] for r in rec['ranks']) == [0, 1]
+    assert all(r['transport'] == 'peer windows' and r['p2p']['cross_gpu_wait_us'] > 0.0 for r in rec['ranks']), rec['ranks']
+    assert 'RCCL all-reduce per time step' in rec['rccl']['parallelism'] and not rec.get('degraded', False)
 
 
 def _check_rank_diagnostics(rec, world):
