@@ -13,12 +13,39 @@
 
 typedef double2 cplx;
 
+// Translation units.  `krotov_hip.hip` compiled by itself (no -DKH_TU) is the whole library in one unit -- what the
+// timing / stress builds of scripts/ and a plain `hipcc ... krotov_hip.hip` do.  krotov_amd/build.py compiles the same
+// sources as several units in parallel: KH_TU_MAIN (host code, dispatch, the small set-up kernels) sees the sweep-kernel
+// templates but instantiates none of those listed in kh_instances.inc (`extern template`); every other unit
+// (csrc/kh_tu.hip with -DKH_TU=<family>) holds the explicit instantiations of its family and the family's
+// non-template kernels, which everywhere else are declarations only (KH_DEFINES).  A kernel launch is a host-side
+// reference to the kernel's handle, so no relocatable device code is needed: every unit registers its own code object.
+#define KH_TU_ALL 0
+#define KH_TU_MAIN 1
+#define KH_TU_GENERIC 2
+#define KH_TU_MINI 3
+#define KH_TU_TILE 4
+#define KH_TU_Q2 5
+#define KH_TU_STREAM 6
+#define KH_TU_ENS 7
+#define KH_TU_TILEN 8
+#define KH_TU_COOP_STORE 9
+#define KH_TU_COOP_UPDATE_A 10
+#define KH_TU_COOP_UPDATE_B 11
+#define KH_TU_ELL_STORE 12
+#define KH_TU_ELL_UPDATE_A 13
+#define KH_TU_ELL_UPDATE_B 14
+#ifndef KH_TU
+#define KH_TU KH_TU_ALL
+#endif
+#define KH_DEFINES(owner) (KH_TU == KH_TU_ALL || KH_TU == (owner))
+
 #define KH_MAX_L 8          // controls per problem the kernels are compiled for
 #define KH_MAX_DEGREE 64    // hard cap on the Taylor degree per sub-step
 
 // 1/j for the Taylor coefficients: a scalar load instead of two fp64 divisions
 // (v_rcp_f64 + Newton steps, ~60 cycles each) on the critical path of every term
-__constant__ double kh_inv_table[KH_MAX_DEGREE + 1] = {0.0, 1.0 / 1, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11, 1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18, 1.0 / 19, 1.0 / 20, 1.0 / 21, 1.0 / 22, 1.0 / 23, 1.0 / 24, 1.0 / 25, 1.0 / 26, 1.0 / 27, 1.0 / 28, 1.0 / 29, 1.0 / 30, 1.0 / 31, 1.0 / 32, 1.0 / 33, 1.0 / 34, 1.0 / 35, 1.0 / 36, 1.0 / 37, 1.0 / 38, 1.0 / 39, 1.0 / 40, 1.0 / 41, 1.0 / 42, 1.0 / 43, 1.0 / 44, 1.0 / 45, 1.0 / 46, 1.0 / 47, 1.0 / 48, 1.0 / 49, 1.0 / 50, 1.0 / 51, 1.0 / 52, 1.0 / 53, 1.0 / 54, 1.0 / 55, 1.0 / 56, 1.0 / 57, 1.0 / 58, 1.0 / 59, 1.0 / 60, 1.0 / 61, 1.0 / 62, 1.0 / 63, 1.0 / 64};
+static __constant__ double kh_inv_table[KH_MAX_DEGREE + 1] = {0.0, 1.0 / 1, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11, 1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18, 1.0 / 19, 1.0 / 20, 1.0 / 21, 1.0 / 22, 1.0 / 23, 1.0 / 24, 1.0 / 25, 1.0 / 26, 1.0 / 27, 1.0 / 28, 1.0 / 29, 1.0 / 30, 1.0 / 31, 1.0 / 32, 1.0 / 33, 1.0 / 34, 1.0 / 35, 1.0 / 36, 1.0 / 37, 1.0 / 38, 1.0 / 39, 1.0 / 40, 1.0 / 41, 1.0 / 42, 1.0 / 43, 1.0 / 44, 1.0 / 45, 1.0 / 46, 1.0 / 47, 1.0 / 48, 1.0 / 49, 1.0 / 50, 1.0 / 51, 1.0 / 52, 1.0 / 53, 1.0 / 54, 1.0 / 55, 1.0 / 56, 1.0 / 57, 1.0 / 58, 1.0 / 59, 1.0 / 60, 1.0 / 61, 1.0 / 62, 1.0 / 63, 1.0 / 64};
 
 // ---------------------------------------------------------------------------
 // complex arithmetic

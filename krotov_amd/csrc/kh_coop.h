@@ -171,7 +171,9 @@ struct KhCoopRegFrag {
 __host__ __device__ inline size_t kh_coop_table_stride(int ks) { return (size_t)KH_COOP_WAVES * ks * 64 + KH_COOP_TABLE_PAD; }
 __host__ __device__ inline size_t kh_coop_table_elems(int G, int ks) { return (size_t)G * kh_coop_table_stride(ks); }
 __global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, int N, int G, int ks,
-                                       int cols) {
+                                       int cols)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     const size_t total = (size_t)G * KH_COOP_WAVES * ks * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -192,6 +194,9 @@ __global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__rest
             (row < N && col < N) ? in[(size_t)row * N + col] : c_make(0.0, 0.0);
     }
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // Zero slots.  Operators of physical models are often sparse in places (a control Hamiltonian's commutator
 // superoperator has a few entries per row; so has its square), and every table is zero-padded from N to the waves'
@@ -199,7 +204,9 @@ __global__ void kh_coop_permute_kernel(const cplx *__restrict__ in, cplx *__rest
 // marked once, at engine creation, in a 32-bit word per (row block, wave) stored BEHIND the table; fragment loads,
 // updates and (for the control operators' products) matrix-core instructions skip such slots.  Exact: skipped
 // terms are exact zeros.
-__global__ void kh_coop_mask_kernel(const cplx *__restrict__ tab, unsigned int *__restrict__ mask, int ks) {
+__global__ void kh_coop_mask_kernel(const cplx *__restrict__ tab, unsigned int *__restrict__ mask, int ks)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     const int lane = threadIdx.x;  // one wave per (row block, wave)
     const cplx *src = tab + (size_t)(blockIdx.x / KH_COOP_WAVES) * kh_coop_table_stride(ks) +
                       (size_t)(blockIdx.x % KH_COOP_WAVES) * ks * 64 + lane;
@@ -210,6 +217,9 @@ __global__ void kh_coop_mask_kernel(const cplx *__restrict__ tab, unsigned int *
     }
     if (lane == 0) mask[blockIdx.x] = m;
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 __device__ __forceinline__ unsigned int kh_coop_frag_mask(const cplx *op, int G, int g, int wave, int ks) {
     if (op == nullptr) return 0u;
     const unsigned int *m = (const unsigned int *)(op + kh_coop_table_elems(G, ks));
@@ -1272,7 +1282,9 @@ __device__ __forceinline__ bool kh_coop_expm_action_sq_ahead(const KhCoopArgs &c
 // that is a commutator with a diagonal operator (the transmon of BASELINE config 4) has ONE non-zero block per row
 // block: the product is then a streaming pass over the store (read 16 N K nt bytes, write as many).
 __global__ void kh_coop_adj_mask_kernel(const cplx *__restrict__ op /*row-major N x N*/, int N, int G,
-                                        unsigned char *__restrict__ nz /*[G][G]*/) {
+                                        unsigned char *__restrict__ nz /*[G][G]*/)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     const int g = blockIdx.x / G, kb = blockIdx.x % G;
     const int r = 16 * g + (threadIdx.x >> 4), col = 16 * kb + (threadIdx.x & 15);
     bool any = false;
@@ -1283,11 +1295,16 @@ __global__ void kh_coop_adj_mask_kernel(const cplx *__restrict__ op /*row-major 
     const int found = __syncthreads_or(any ? 1 : 0);
     if (threadIdx.x == 0) nz[blockIdx.x] = found ? 1 : 0;
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 #define KH_COOP_ADJ_THREADS 256  // 4 waves x 16 vectors
 __global__ void __launch_bounds__(KH_COOP_ADJ_THREADS)
 kh_coop_adjoint_side(const cplx *__restrict__ op /*H_1^+, row-major N x N*/, const unsigned char *__restrict__ nz,
-                     const cplx *__restrict__ X /*[M][N]*/, cplx *__restrict__ V /*[M][N]*/, int N, int G, long long M) {
+                     const cplx *__restrict__ X /*[M][N]*/, cplx *__restrict__ V /*[M][N]*/, int N, int G, long long M)
+#if KH_DEFINES(KH_TU_COOP_STORE)
+{
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, kq = lane >> 4;
     const long long vec = ((long long)blockIdx.x * 4 + wave) * 16 + j;  // this lane's vector (B operand column)
@@ -1320,6 +1337,9 @@ kh_coop_adjoint_side(const cplx *__restrict__ op /*H_1^+, row-major N x N*/, con
         }
     }
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // ---------------------------------------------------------------------------
 // plain propagation with storage (backward sweep / iteration-0 forward sweep)

@@ -46,7 +46,9 @@ __host__ inline size_t kh_ens_lds_bytes(int ncg) { return (size_t)2 * kh_ens_buf
 // (what "mu[k] * H1" in double precision produces -- configs.py config_c5, the reference's notebook 08: both operators
 // are rounded products, and so is the ratio s taken from their largest element: up to 5 roundings, 2^-53 each).
 __global__ void __launch_bounds__(256)
-kh_ens_detect_kernel(const cplx *const *ops, int K, int N, int ref_idx, int ref_comp, double *scale, int *flags) {
+kh_ens_detect_kernel(const cplx *const *ops, int K, int N, int ref_idx, int ref_comp, double *scale, int *flags)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     const int k = blockIdx.x;
     const cplx *H0 = ops[(size_t)k * 2], *H1 = ops[(size_t)k * 2 + 1], *R0 = ops[0], *R1 = ops[1];
     if (H1 == nullptr || R1 == nullptr) {
@@ -70,6 +72,9 @@ kh_ens_detect_kernel(const cplx *const *ops, int K, int N, int ref_idx, int ref_
     if (bad1 || !(fabs(s) < 1e300)) flags[1] = 1;
     if (threadIdx.x == 0) scale[k] = s;
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 template <int NCG, bool SO>
 __global__ void __launch_bounds__(KH_ENS_THREADS, 2)

@@ -289,7 +289,9 @@ __device__ __forceinline__ int kh_gen_expm_action(const KhSweepArgs &p, const cp
 // direction -1: n = nt-2..0, state index n+1 -> n (optimize.py:849-886)
 __global__ void __launch_bounds__(KH_GEN_THREADS)
 kh_gen_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx *__restrict__ state_in,
-                   cplx *__restrict__ store, cplx *__restrict__ state_out, int direction) {
+                   cplx *__restrict__ store, cplx *__restrict__ state_out, int direction)
+#if KH_DEFINES(KH_TU_GENERIC)
+{
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KhGenLds s = kh_gen_carve(smem, p.N, p.csr == nullptr);
     const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
@@ -320,6 +322,9 @@ kh_gen_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx 
     }
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // ---------------------------------------------------------------------------
 // forward sweep with sequential pulse update (optimize.py:444-508)
@@ -410,7 +415,9 @@ __device__ __forceinline__ void kh_gen_partials(const KhSweepArgs &p, const KhUp
 }
 
 __global__ void __launch_bounds__(KH_GEN_THREADS)
-kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
+kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex)
+#if KH_DEFINES(KH_TU_GENERIC)
+{
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (u.n_dev != nullptr) {
         u.n_begin = *u.n_dev;
@@ -497,10 +504,15 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex) {
         for (int l = 0; l < L; ++l) u.g_a[l] = (u.internal_exchange ? 0.0 : u.g_a[l]) + g_a_loc[l];
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // sum of per-workgroup partials in workgroup order -> out[L]  (stepwise mode)
 __global__ void kh_reduce_partials(const double *__restrict__ wg_partial, int G, int L, double *__restrict__ out,
-                                   int *n_dev) {
+                                   int *n_dev)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     // one wave; fixed order: lane-strided partial sums in workgroup order, then the sum64 tree
     const int lane = threadIdx.x;
     for (int l = 0; l < L; ++l) {
@@ -511,10 +523,15 @@ __global__ void kh_reduce_partials(const double *__restrict__ wg_partial, int G,
     }
     if (n_dev != nullptr && lane == 0) *n_dev += 1;
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // tau_k = <target_k | psi_k>  (second_order.py:69-83); one wave per objective
 __global__ void kh_tau_kernel(const cplx *__restrict__ targets, const cplx *__restrict__ psi, cplx *__restrict__ tau,
-                              int K, int N) {
+                              int K, int N)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     const int k = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (k >= K) return;
@@ -523,6 +540,9 @@ __global__ void kh_tau_kernel(const cplx *__restrict__ targets, const cplx *__re
     const double re = sum64(acc.x), im = sum64(acc.y);
     if (lane == 0) tau[k] = c_make(re, im);
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // chi_k(T) of the built-in functionals (functionals.py:177-197, 225-253, 293-317, 389-437) is a
 // linear combination of the target and the propagated state with per-objective scalars:
@@ -531,7 +551,9 @@ __global__ void kh_tau_kernel(const cplx *__restrict__ targets, const cplx *__re
 // One wave per objective, fixed summation order.
 __global__ void kh_chi_kernel(const cplx *__restrict__ targets, const cplx *__restrict__ psi,
                               const cplx *__restrict__ c, const cplx *__restrict__ d, cplx *__restrict__ out,
-                              double *__restrict__ norms, int K, int N) {
+                              double *__restrict__ norms, int K, int N)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     const int k = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (k >= K) return;
@@ -550,9 +572,14 @@ __global__ void kh_chi_kernel(const cplx *__restrict__ targets, const cplx *__re
     }
     if (lane == 0) norms[k] = nrm;
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // Frobenius norms of the operators (fallback when the caller gives no bounds)
-__global__ void kh_fro_norms(const cplx *const *ops, int count, int N, double *norms) {
+__global__ void kh_fro_norms(const cplx *const *ops, int count, int N, double *norms)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     const int idx = blockIdx.x;
     if (idx >= count) return;
     const cplx *a = ops[idx];
@@ -569,13 +596,18 @@ __global__ void kh_fro_norms(const cplx *const *ops, int count, int N, double *n
         norms[idx] = sqrt(t);
     }
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // flags[0] (flags[1]) is raised when some control operator (index i with i % Lp1 != 0) differs from
 // plus (minus) its staged adjoint in any bit: decides KhUpdateArgs::adj_sign at engine creation;
 // flags[2] when some drift operator (i % Lp1 == 0) differs from its adjoint (flags[0] == flags[2] == 0: every
 // generator H0 + sum eps_l H_l is Hermitian, its spectrum real)
 __global__ void kh_adjoint_sign_kernel(const cplx *const *__restrict__ ops, const cplx *const *__restrict__ ops_adj,
-                                       int nops, int Lp1, int N, int *__restrict__ flags) {
+                                       int nops, int Lp1, int N, int *__restrict__ flags)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     for (int i = blockIdx.x; i < nops; i += gridDim.x) {
         if (ops[i] == nullptr) continue;
         const bool drift = i % Lp1 == 0;
@@ -594,11 +626,16 @@ __global__ void kh_adjoint_sign_kernel(const cplx *const *__restrict__ ops, cons
         }
     }
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // max over the drift operators of || (A + sign A^dagger) / 2 ||_F^2  (sign = +1: Hermitian part, -1: anti-Hermitian
 // part) -> *out (bits of a non-negative double, atomicMax); one workgroup per operator
 __global__ void kh_herm_defect_kernel(const cplx *const *__restrict__ ops, const cplx *const *__restrict__ ops_adj,
-                                      int nops, int Lp1, int N, double sign, unsigned long long *__restrict__ out) {
+                                      int nops, int Lp1, int N, double sign, unsigned long long *__restrict__ out)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     __shared__ double red[256];
     for (int i = blockIdx.x * Lp1; i < nops; i += gridDim.x * Lp1) {
         double acc = 0.0;
@@ -619,9 +656,14 @@ __global__ void kh_herm_defect_kernel(const cplx *const *__restrict__ ops, const
         __syncthreads();
     }
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // out[c][r] = conj(in[r][c]); 32x32 tiles through LDS
-__global__ void kh_adjoint_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, int N) {
+__global__ void kh_adjoint_kernel(const cplx *__restrict__ in, cplx *__restrict__ out, int N)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     __shared__ cplx tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -638,3 +680,6 @@ __global__ void kh_adjoint_kernel(const cplx *__restrict__ in, cplx *__restrict_
         }
     }
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif

@@ -158,7 +158,9 @@ __device__ __forceinline__ void kh_mini_build(double eps, const cplx (&h0)[4], c
 __global__ void __launch_bounds__(64)
 kh_mini_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const double *__restrict__ pulses,
                     const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out,
-                    int direction) {
+                    int direction)
+#if KH_DEFINES(KH_TU_MINI)
+{
     __shared__ KhMiniLds s;
     const int lane = threadIdx.x, r = lane >> 2, k = blockIdx.x;
     const bool writer = (lane & 3) == 0;
@@ -206,6 +208,9 @@ kh_mini_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const dou
     if (state_out != nullptr && writer && r < N) state_out[(size_t)k * N + r] = state;
     if (lane == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // ---------------------------------------------------------------------------
 // forward sweep with sequential pulse update (optimize.py:444-508): ONE workgroup, wave k = objective k
@@ -424,7 +429,9 @@ __device__ __forceinline__ void kh_quad_build(const KhQuadTiles &t, double eps, 
 __global__ void __launch_bounds__(64)
 kh_quad_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const double *__restrict__ pulses,
                     const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out,
-                    int direction) {
+                    int direction)
+#if KH_DEFINES(KH_TU_MINI)
+{
     __shared__ KhMiniLds s;
     const int lane = threadIdx.x, k = lane >> 4, r = (lane >> 2) & 3, c = lane & 3;
     const int N = p.N, nt = p.nt;
@@ -464,6 +471,9 @@ kh_quad_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const dou
     if (state_out != nullptr && owner) state_out[(size_t)k * N + r] = state;
     if (lane == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs * p.K);
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 template <bool SO>
 __global__ void __launch_bounds__(64)

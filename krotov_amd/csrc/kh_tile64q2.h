@@ -238,7 +238,9 @@ __device__ __forceinline__ int kh_q2_expm_action(const cplx (&a)[8], const cplx 
 __global__ void __launch_bounds__(KH_Q2_THREADS)
 kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const double *__restrict__ pulses,
                   const cplx *__restrict__ state_in, cplx *__restrict__ store, cplx *__restrict__ state_out,
-                  int direction) {
+                  int direction)
+#if KH_DEFINES(KH_TU_Q2)
+{
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KhQ2Lds s = kh_q2_carve(smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -324,6 +326,9 @@ kh_q2_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ sq, const doubl
     }
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // ---------------------------------------------------------------------------
 // forward sweep with sequential pulse update (optimize.py:444-508), grid == K
@@ -620,7 +625,9 @@ kh_q2_forward_update(KhSweepArgs p, const cplx *const *__restrict__ sq, KhUpdate
 
 // C = X Y (+ Y X if symmetrize) for N <= 64; grid-stride over the N*N outputs (engine set-up only)
 __global__ void kh_q2_product(const cplx *__restrict__ X, const cplx *__restrict__ Y, cplx *__restrict__ C, int N,
-                              int symmetrize) {
+                              int symmetrize)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N * N; idx += gridDim.x * blockDim.x) {
         const int i = idx / N, j = idx % N;
         cplx acc = c_make(0.0, 0.0);
@@ -630,3 +637,6 @@ __global__ void kh_q2_product(const cplx *__restrict__ X, const cplx *__restrict
         C[idx] = acc;
     }
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif

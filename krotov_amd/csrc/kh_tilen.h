@@ -52,13 +52,18 @@ __device__ __forceinline__ KhTnLds kh_tn_carve(char *smem) {
 }
 
 // row-major N x N -> lane order: out[j * 512 + tid] = in[row tid >> 2][column (tid & 3) + 4 j], j < 32 (zero beyond N)
-__global__ void kh_tn_permute(const cplx *__restrict__ in, cplx *__restrict__ out, int N) {
+__global__ void kh_tn_permute(const cplx *__restrict__ in, cplx *__restrict__ out, int N)
+#if KH_DEFINES(KH_TU_MAIN)
+{
     const int tid = threadIdx.x, row = tid >> 2, cg = tid & 3;
     for (int j = blockIdx.x; j < KH_TN_NMAX / 4; j += gridDim.x) {
         const int col = cg + 4 * j;
         out[(size_t)j * KH_TN_THREADS + tid] = (row < N && col < N) ? in[(size_t)row * N + col] : c_make(0.0, 0.0);
     }
 }
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 template <int EPL>
 __device__ __forceinline__ void kh_tn_load(const cplx *__restrict__ tab, int tid, cplx (&a)[EPL]) {

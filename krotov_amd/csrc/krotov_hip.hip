@@ -13,9 +13,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <tuple>
@@ -39,6 +42,9 @@
 #include "kh_ell.h"
 #include "kh_tilen.h"
 #include "kh_ens.h"
+// the parallel build (krotov_amd/build.py, -DKH_TU=KH_TU_MAIN): the sweep kernels are instantiated in the family units
+// (kh_tu.hip), here they are `extern template`; compiled by itself this file is the whole library in one unit
+#include "kh_instances.inc"
 
 static thread_local std::string g_last_error;
 
@@ -200,13 +206,16 @@ static int ensure_dynamic_lds(kh_engine *e, const void *func, size_t bytes) {
 // Every launch of a sweep kernel goes through launch_plain<Kernel> / launch_persistent<Kernel>; naming the kernel as a
 // template argument instantiates KhKernelTag<Kernel>, whose static member registers the instantiation when the library
 // is loaded: the registry is exactly the set of instantiations some dispatch can select.
+// (engines may be driven from different host threads -- one engine per thread, INTEGRATION.md 4 --: the flags are atomics,
+// the registry itself is only appended to while the library is loaded)
 struct KhKernelRecord {
     std::string name;
-    bool launched = false;
-    bool logged = false;  // written to KH_LAUNCH_LOG by this process
+    std::atomic<bool> launched{false};
+    std::atomic<bool> logged{false};  // written to KH_LAUNCH_LOG by this process
+    explicit KhKernelRecord(std::string n) : name(std::move(n)) {}
 };
-static std::vector<KhKernelRecord> &kh_kernel_registry() {
-    static std::vector<KhKernelRecord> reg;
+static std::deque<KhKernelRecord> &kh_kernel_registry() {
+    static std::deque<KhKernelRecord> reg;
     return reg;
 }
 static int kh_register_kernel(const void *host_stub) {
@@ -225,7 +234,7 @@ static int kh_register_kernel(const void *host_stub) {
         const size_t paren = s.find('(');
         if (paren != std::string::npos) s = s.substr(0, paren);
     }
-    kh_kernel_registry().push_back({s, false, false});
+    kh_kernel_registry().emplace_back(s);
     return (int)kh_kernel_registry().size() - 1;
 }
 template <auto Kernel>
@@ -234,8 +243,8 @@ struct KhKernelTag {
 };
 static void kh_note_launch(int index) {
     KhKernelRecord &rec = kh_kernel_registry()[index];
-    rec.launched = true;
-    if (rec.logged) return;
+    rec.launched.store(true, std::memory_order_relaxed);
+    if (rec.logged.load(std::memory_order_relaxed)) return;
     // (tests: one line per instantiation and process, appended; the variable is read at every launch so that a test
     // session can switch the log on for its oracle-comparing tests only -- tests/conftest.py)
     if (const char *path = getenv("KH_LAUNCH_LOG")) {
@@ -243,7 +252,7 @@ static void kh_note_launch(int index) {
         if (FILE *f = fopen(path, "a")) {
             fprintf(f, "%s\n", rec.name.c_str());
             fclose(f);
-            rec.logged = true;
+            rec.logged.store(true, std::memory_order_relaxed);
         }
     }
 }
@@ -269,16 +278,23 @@ static int launch_persistent(const kh_engine *e, dim3 grid, dim3 block, size_t l
         // a grid that cannot be co-resident is refused here (KH_ERR_UNSUPPORTED: the caller takes a smaller grid or one
         // launch per interval) instead of ending in a timeout
         static std::map<std::tuple<const void *, unsigned, size_t, int>, int> per_cu_of;
+        static std::mutex per_cu_lock;  // (two engines launching from two host threads share the cache)
         const auto key = std::make_tuple((const void *)Kernel, block.x, lds, e->device);
-        auto it = per_cu_of.find(key);
-        if (it == per_cu_of.end()) {
-            int per_cu = 0;
-            KH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)Kernel, (int)block.x, lds));
-            it = per_cu_of.emplace(key, per_cu).first;
+        int per_cu = -1;
+        {
+            std::lock_guard<std::mutex> hold(per_cu_lock);
+            auto it = per_cu_of.find(key);
+            if (it != per_cu_of.end()) per_cu = it->second;
         }
-        if ((long long)it->second * e->num_cus < (long long)grid.x * grid.y * grid.z)
+        if (per_cu < 0) {
+            per_cu = 0;
+            KH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)Kernel, (int)block.x, lds));
+            std::lock_guard<std::mutex> hold(per_cu_lock);
+            per_cu_of.emplace(key, per_cu);
+        }
+        if ((long long)per_cu * e->num_cus < (long long)grid.x * grid.y * grid.z)
             return kh_fail(KH_ERR_UNSUPPORTED, "the update sweep's %u workgroups cannot all be resident on this device (%d per CU)",
-                           grid.x * grid.y * grid.z, it->second);
+                           grid.x * grid.y * grid.z, per_cu);
         hipLaunchKernelGGL(Kernel, grid, block, lds, st, args...);
         return KH_OK;
     }
@@ -360,18 +376,19 @@ static KhSweepArgs sweep_args(const kh_engine *e, bool backward) {
 }
 
 // The generic kernels' scratch generators (kh_generic.h: dense operators with N > 96): one N x N matrix per workgroup,
-// allocated at the first launch that can use it; at most 4 GiB, and a failed allocation just leaves the streamed form.
+// allocated at the first launch that can use it; at most 4 GiB: a launch that asks for more workgroups than that holds
+// gets as many scratch matrices as fit (the kernel forms the generator for blockIdx.x < gen_scratch_wgs and streams the
+// operators per term in the others), and only a failed allocation leaves the streamed form for good.
 static void ensure_gen_scratch(kh_engine *e, int wgs) {
-    if (e->d_csr_fw != nullptr || kh_gen_lds_A(e->N, true) || e->gen_scratch_wgs >= wgs || e->gen_scratch_failed) return;
-    const size_t bytes = sizeof(cplx) * (size_t)wgs * e->N * e->N;
-    if (bytes > ((size_t)4 << 30)) {
-        e->gen_scratch_failed = true;
-        return;
-    }
+    if (e->d_csr_fw != nullptr || kh_gen_lds_A(e->N, true) || e->gen_scratch_failed) return;
+    const size_t per_wg = sizeof(cplx) * (size_t)e->N * e->N;
+    const size_t fit = ((size_t)4 << 30) / per_wg;
+    if ((size_t)wgs > fit) wgs = (int)fit;
+    if (wgs < 1 || e->gen_scratch_wgs >= wgs) return;
     if (e->d_gen_scratch != nullptr) (void)hipFree(e->d_gen_scratch);
     e->d_gen_scratch = nullptr;
     e->gen_scratch_wgs = 0;
-    if (hipMalloc(&e->d_gen_scratch, bytes) != hipSuccess) {
+    if (hipMalloc(&e->d_gen_scratch, per_wg * (size_t)wgs) != hipSuccess) {
         (void)hipGetLastError();
         e->d_gen_scratch = nullptr;
         e->gen_scratch_failed = true;
@@ -1279,7 +1296,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                     hipError_t err = hipMemset(d_flags, 0, sizeof(flags));
                     if (err == hipSuccess) {
                         kh_ens_detect_kernel<<<e->K, 256>>>(e->d_ops_fw, e->K, e->N, ref_idx, ref_comp, e->d_ens_scale, d_flags);
-                        err = hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost);
+                        err = hipGetLastError();  // (the launch's own verdict, not whatever the copy below reports)
+                        if (err == hipSuccess) err = hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost);
                     }
                     (void)hipFree(d_flags);
                     KH_HIP_E(err);

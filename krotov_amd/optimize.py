@@ -49,6 +49,7 @@ from ._lib import KrotovHipError as _KrotovHipError
 from ._lib import KH_ERR_TIMEOUT as _KH_ERR_TIMEOUT, KH_ERR_UNSUPPORTED as _KH_ERR_UNSUPPORTED
 
 _KH_MAX_CONTROLS = 8  # KH_MAX_L of krotov_amd/csrc/kh_common.h
+_FULL_GRID_PROBE_EVERY = 16  # update sweeps in a row on a reduced grid before the full one is tried again
 from .info_hooks import chain
 from .mu import derivative_wrt_pulse
 from .parallelization import serial_map
@@ -514,6 +515,7 @@ class _HipBackend:
         self._single_launch_failures = 0
         self._update_grid = None  # workgroups of the single-launch update sweep after a retry (None: the engine's choice)
         self._reduced_in_a_row = 0
+        self._last_good_grid = None  # the reduced grid that got through the last time the full one timed out
         self.p2p = False
         self.engine.p2p_why = "KH_P2P=0" if self.world > 1 else None
         if self.world > 1 and os.environ.get('KH_P2P', '1') != '0':
@@ -611,10 +613,16 @@ class _HipBackend:
                 # the single-launch sweep needs all its workgroups resident at once; if the GPU could not give it that
                 # (CUs held by another stream or process: its in-kernel exchange times out; or the device cannot hold
                 # the grid at all), redo it on HALF the workgroups, each walking through twice the objectives (about
-                # twice the time: kh_set_update_workgroups), halve again, ... and only then interval by interval -- one
-                # launch each, nothing waits inside a kernel, ten times the time -- like the sharded path does.
+                # twice the time: kh_set_update_workgroups), then on an eighth, and only then interval by interval -- one
+                # launch each, nothing waits inside a kernel, ten times the time -- like the sharded path does.  A
+                # reduced grid that got through stays.
                 # Anything else than a timeout / "cannot be resident" is a real error.
                 grid = self._update_grid  # (None: the engine's own choice)
+                if grid is not None and self._reduced_in_a_row >= _FULL_GRID_PROBE_EVERY:
+                    # a co-tenant may have gone away: one sweep on the full grid again (at worst one more timeout)
+                    eng.set_update_workgroups(0)
+                    grid, self._reduced_in_a_row = None, 0
+                rungs = 0
                 while not done:
                     try:
                         opt, psi_T, g_a = eng.forward_update(self.chi_store, norms_loc, self.init, guess, shapes, lambdas)
@@ -624,8 +632,17 @@ class _HipBackend:
                         if exc.code not in (_KH_ERR_TIMEOUT, _KH_ERR_UNSUPPORTED):
                             raise
                         try:
+                            # every rung costs a timed-out sweep (KH_TIMEOUT_MS, 1 s by default): two of them at most --
+                            # half the workgroups (what gets through next to a stream holding half of the device), then
+                            # an eighth -- before the form that cannot time out
+                            rungs += 1
+                            if rungs > 2:
+                                raise _KrotovHipError("two reduced grids timed out", _KH_ERR_UNSUPPORTED)
                             full = eng.set_update_workgroups(0)
-                            nxt = (grid if grid is not None else full) // 2
+                            if grid is None and self._last_good_grid is not None and self._last_good_grid < full:
+                                nxt = self._last_good_grid  # (what got through the last time this happened)
+                            else:
+                                nxt = (grid if grid is not None else full) // (2 if rungs == 1 else 4)
                             if nxt < 1:
                                 raise _KrotovHipError("no smaller grid", _KH_ERR_UNSUPPORTED)
                             grid = eng.set_update_workgroups(nxt)
@@ -634,8 +651,10 @@ class _HipBackend:
                         except _KrotovHipError as exc2:
                             if exc2.code != _KH_ERR_UNSUPPORTED:
                                 raise
+                            # back to the engine's own grid, in the engine AND in what this object remembers of it
                             grid = None
                             eng.set_update_workgroups(0)
+                            self._update_grid, self._reduced_in_a_row, self._last_good_grid = None, 0, None
                             self._single_launch_failures += 1
                             # a co-tenant may go away, but not after three sweeps in a row
                             if exc.code == _KH_ERR_UNSUPPORTED or self._single_launch_failures >= 3:
@@ -647,12 +666,11 @@ class _HipBackend:
                 if done:
                     self._single_launch_failures = 0
                     if grid is not None:
-                        # a reduced grid got through: the next sweep tries the full one again, unless that has failed
-                        # three sweeps in a row (then the grid that works is kept)
+                        # a reduced grid got through: it is KEPT (trying the full one first would cost a timed-out sweep
+                        # per iteration for as long as the co-tenant stays); the full grid gets its chance again after
+                        # _FULL_GRID_PROBE_EVERY sweeps in a row on the reduced one
                         self._reduced_in_a_row += 1
-                        if self._reduced_in_a_row < 3:
-                            eng.set_update_workgroups(0)
-                            grid = None
+                        self._last_good_grid = grid
                     else:
                         self._reduced_in_a_row = 0
                     self._update_grid = grid

@@ -394,10 +394,11 @@ def test_bench_starts_its_own_ranks(monkeypatch):
 
 def test_update_sweep_retry_ladder_on_the_host(monkeypatch, caplog):
     """``_HipBackend.iterate`` after KH_ERR_TIMEOUT (the single-launch update sweep's workgroups were not all resident):
-    half the workgroups, half again, ... through ``set_update_workgroups``; only when the engine has no smaller grid one
-    launch per interval; the full grid again at the next iteration, a reduced one kept after three iterations in a row
-    that needed it.  Driven on the CPU with the oracle-backed engine double, whose single-launch sweep
-    "times out" above a scripted number of workgroups; the pulses must be the oracle's whatever path was taken."""
+    half the workgroups, then an eighth, through ``set_update_workgroups`` -- two rungs at most, each costs a timed-out
+    sweep --; only then (or when the engine has no smaller grid) one launch per interval; a reduced grid that got through
+    is kept, the full one probed again after ``_FULL_GRID_PROBE_EVERY`` sweeps in a row.  Driven on the
+    CPU with the oracle-backed engine double, whose single-launch sweep "times out" above a scripted number of
+    workgroups; the pulses must be the oracle's whatever path was taken."""
     import logging
 
     import krotov_amd
@@ -437,23 +438,36 @@ def test_update_sweep_retry_ladder_on_the_host(monkeypatch, caplog):
     kw = dict(propagator=krotov_amd.propagators.expm, chi_constructor=krotov_amd.functionals.chis_re, store_all_pulses=True)
     ref = oracle_optimize(spec, 5)
 
-    # 8 workgroups never fit, 2 do: 8 -> 4 -> 2 in every iteration; after three such iterations the 2 are kept
+    # 8 workgroups never fit, 2 do: 8 -> 4 (times out) -> 1 (an eighth: two rungs at most) in the first iteration; the
+    # grid that got through is kept: no further call, no further timed-out sweep
     res = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=5, **kw)
     assert np.abs(np.array(res.all_pulses) - ref['all_pulses']).max() < 1e-12
     assert script['stepwise'] == 0
-    # iterations 1..3: query the full grid (0), ask for 4, query (0), ask for 2, and reset (0) afterwards -- except after
-    # the third, where the reduced grid stays; iterations 4, 5: no call at all (the sweep runs on 2 straight away)
-    assert script['calls'] == [0, 4, 0, 2, 0] * 2 + [0, 4, 0, 2]
-    assert caplog.text.count('repeating it on 4 workgroups') == 3 and caplog.text.count('repeating it on 2 workgroups') == 3
+    assert script['calls'] == [0, 4, 0, 1]  # (query the full grid, ask for half; query, ask for an eighth)
+    assert caplog.text.count('repeating it on 4 workgroups') == 1 and caplog.text.count('repeating it on 1 workgroups') == 1
 
-    # no grid fits and the engine refuses anything below 4: one launch per interval, for good after three sweeps
+    # ... and after _FULL_GRID_PROBE_EVERY sweeps in a row on it the full grid gets one more chance (the co-tenant may
+    # be gone); the reduced grid of the last time is then asked for directly
+    import krotov_amd.optimize as optimize_mod
+
+    monkeypatch.setattr(optimize_mod, '_FULL_GRID_PROBE_EVERY', 2)
+    script.update(fits=4, calls=[])
+    caplog.clear()
+    res = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=5, **kw)
+    assert np.abs(np.array(res.all_pulses) - ref['all_pulses']).max() < 1e-12
+    # it 1: 8 -> 4 fits; it 2: kept; it 3: probe (reset 0), times out, back to 4 at once; it 4: kept; it 5: probe again
+    assert script['calls'] == [0, 4] + [0, 0, 4] * 2
+    monkeypatch.setattr(optimize_mod, '_FULL_GRID_PROBE_EVERY', 16)
+
+    # no grid fits and the engine refuses anything below 4: half (times out), an eighth (refused) -> one launch per
+    # interval and the engine's own grid again; for good after three such sweeps
     script.update(fits=0, floor=4, calls=[], stepwise=0)
     caplog.clear()
     res = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, iter_stop=5, **kw)
     assert np.abs(np.array(res.all_pulses) - ref['all_pulses']).max() < 1e-12
     assert script['stepwise'] == 5
     assert caplog.text.count('one launch per interval') == 3 and 'staying with that form' in caplog.text
-    assert script['calls'] == [0, 4, 0, 2, 0] * 3  # (4 is tried and times out, 2 is refused: reset) -- then never again
+    assert script['calls'] == [0, 4, 0, 1, 0] * 3  # (4 is tried and times out, 1 is refused: reset) -- then never again
 
 
 def test_bench_leg_traffic_is_keyed_on_the_build_and_scaled_per_interval(tmp_path, monkeypatch):
