@@ -1532,7 +1532,9 @@ kh_coop_forward_update(KhSweepArgs p, KhCoopArgs c_in, KhUpdateArgs u, KhExchang
                 if (lane == 0) s.red[par][wave][0] = piece;
             }
             // the dense table of the coming fragment update, on its way while the sums are exchanged
+#ifndef KH_COOP_X_NOP1  // (traffic experiment with KH_COOP_X_NOREBUILD: wrong results) no table read per interval at all
             kh_coop_reg_load<MAXKS>(c.tab[3], g, wave, lane, c.ks, p1pre, mk.p1);
+#endif
         }
 #pragma unroll
         for (int l = 0; l < KH_COOP_MAX_L; ++l) {
