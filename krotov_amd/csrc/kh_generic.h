@@ -354,16 +354,128 @@ struct KhUpdateArgs {
     double adj_sign;            // +1 / -1 if every control operator equals +/- its own adjoint (exactly), else 0:
                                 // <chi|H phi> may then be taken as <(sign H) chi|phi> (kernels with ADJ = true)
     const cplx *adj_store;      // [K][nt][N] H_1^+ chi_k(t_n) (cooperative kernels, one control, first order:
-                                // kh_coop_adjoint_side), or NULL
+                                // kh_coop_adjoint_side); generic kernels, first order, dense operators:
+                                // [L][K][nt][N] H_lk^+ chi_k(t_n) (kh_gen_adjoint_side); or NULL
 };
+
+// ---------------------------------------------------------------------------
+// Update sums on the adjoint side (first order, dense operators; round 6)
+// ---------------------------------------------------------------------------
+// <chi_k(t_n) | H_lk phi_k(t_n)> = <H_lk^+ chi_k(t_n) | phi_k(t_n)> (optimize.py:454-470), and the left factor does not
+// depend on the running forward state: V_lk = H_lk^+ [chi_k(t_0) ... chi_k(t_{nt-1})] for every objective and control
+// is a batch of dense (N x N)(N x nt) products IN FRONT of the update sweep, off its serial chain, on the fp64 matrix
+// cores -- instead of L streamed matrix-vector products per objective inside every interval of it (L = 8, N = 64,
+// K = 256: 41 of the 81 us per interval).  In the sweep a control's partial sum is then one dot product of two vectors.
+// Operators: the engine's staged adjoints (what the backward sweep propagates with), any N the generic kernels take.
+// v_mfma_f64_16x16x4: A = operator block [row lane & 15][k lane >> 4], B = sixteen co-states [k lane >> 4][vector
+// lane & 15], D = [row 4 reg + (lane >> 4)][vector lane & 15]; blockIdx.x: (control l, objective k) as l K + k,
+// blockIdx.y: 64 time points.
+typedef double kh_gen_d4 __attribute__((ext_vector_type(4)));
+#define KH_GEN_ADJ_THREADS 256  // 4 waves x 16 vectors
+__global__ void __launch_bounds__(KH_GEN_ADJ_THREADS)
+kh_gen_adjoint_side(const cplx *const *__restrict__ ops_adj /*[K (1 + L)] adjoint operators, row-major N x N*/,
+                    const cplx *__restrict__ chi_store /*[K][nt][N]*/, cplx *__restrict__ V /*[L][K][nt][N]*/, int K,
+                    int N, int L, int nt)
+#if KH_DEFINES(KH_TU_GENERIC)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, kq = lane >> 4;
+    const int l = blockIdx.x / K, k = blockIdx.x % K;
+    const cplx *op = ops_adj[(size_t)k * (1 + L) + 1 + l];
+    if (op == nullptr) return;  // (the control does not occur in this objective: its sums are skipped in the sweep too)
+    const int n = (blockIdx.y * 4 + wave) * 16 + j;  // this lane's time point (B operand column)
+    const bool vec_ok = n < nt;
+    const cplx *x = chi_store + ((size_t)k * nt + (vec_ok ? n : 0)) * N;
+    cplx *v = V + (((size_t)l * K + k) * nt + (vec_ok ? n : 0)) * N;
+    const int G = (N + 15) / 16;
+    for (int g = 0; g < G; ++g) {
+        kh_gen_d4 dr = {0.0, 0.0, 0.0, 0.0}, di = {0.0, 0.0, 0.0, 0.0};
+        const int arow = 16 * g + j;  // A operand: row lane & 15
+        for (int kb = 0; kb < G; ++kb) {
+            cplx a[4], b[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {  // (the eight loads of a block in flight together)
+                const int kk = 16 * kb + 4 * ks + kq;
+                a[ks] = (kk < N && arow < N) ? op[(size_t)arow * N + kk] : c_make(0.0, 0.0);
+                b[ks] = (kk < N && vec_ok) ? x[kk] : c_make(0.0, 0.0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                dr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].x, b[ks].x, dr, 0, 0, 0);
+                dr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].y, -b[ks].y, dr, 0, 0, 0);
+                di = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].x, b[ks].y, di, 0, 0, 0);
+                di = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].y, b[ks].x, di, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * g + 4 * reg + kq;
+            if (vec_ok && row < N) v[row] = c_make(dr[reg], di[reg]);
+        }
+    }
+}
+#else
+    ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
+#endif
 
 // Im( mu * norm_k * <chi_k(t_n) | H_l phi_k> ) summed over this workgroup's
 // objectives, for every control l -> part[l] (valid in every thread).
+// ... first order with the adjoint-side store (u.adj_store, kh_gen_adjoint_side): <H_l^+ chi_k(t_n) | phi_k> is an
+// element-wise product of two vectors -- no LDS staging, no matrix; the element loads of all controls (and of phi, which
+// this thread itself wrote) are in flight together, one reduction tree per control, one barrier pair per objective.
+// `resident`: the workgroup owns ONE objective whose running state sits in s.acc (kh_gen_forward_update keeps it there
+// from interval to interval): read from LDS instead of the copy in global memory.
+__device__ __forceinline__ void kh_gen_partials_adj(const KhSweepArgs &p, const KhUpdateArgs &u, int n, const KhGenLds &s,
+                                                    double (&part)[KH_MAX_L], bool resident) {
+    const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
+        cplx ov[KH_MAX_L];
+#pragma unroll
+        for (int l = 0; l < KH_MAX_L; ++l) ov[l] = c_make(0.0, 0.0);
+        for (int i = tid; i < N; i += KH_GEN_THREADS) {
+            const cplx x = resident ? s.acc[i] : u.phi[(size_t)k * N + i];
+            cplx v[KH_MAX_L];
+#pragma unroll
+            for (int l = 0; l < KH_MAX_L; ++l)
+                v[l] = (l < L && p.ops[(size_t)k * (1 + L) + 1 + l] != nullptr)
+                           ? u.adj_store[(((size_t)l * p.K + k) * nt + n) * N + i]
+                           : c_make(0.0, 0.0);
+#pragma unroll
+            for (int l = 0; l < KH_MAX_L; ++l) c_fma_conj(ov[l], v[l], x);
+        }
+#pragma unroll
+        for (int l = 0; l < KH_MAX_L; ++l) {
+            if (l >= L) break;
+            const double re = sum64(ov[l].x), im = sum64(ov[l].y);
+            if (lane == 0) {
+                s.red[(wave * KH_MAX_L + l) * 2 + 0] = re;
+                s.red[(wave * KH_MAX_L + l) * 2 + 1] = im;
+            }
+        }
+        __syncthreads();
+        const double nrm = u.chi_norms[k];
+        for (int l = 0; l < L; ++l) {
+            double re = 0.0, im = 0.0;
+            for (int w = 0; w < KH_GEN_THREADS / 64; ++w) {
+                re += s.red[(w * KH_MAX_L + l) * 2 + 0];
+                im += s.red[(w * KH_MAX_L + l) * 2 + 1];
+            }
+            part[l] += nrm * (u.mu_re * im + u.mu_im * re);  // Im(mu * ov) * norm  (optimize.py:466-467, 473)
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ void kh_gen_partials(const KhSweepArgs &p, const KhUpdateArgs &u, int n,
-                                                const KhGenLds &s, double (&part)[KH_MAX_L]) {
+                                                const KhGenLds &s, double (&part)[KH_MAX_L], bool resident = false) {
     const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
     const int grp = tid >> 4, c16 = tid & 15, wave = tid >> 6, lane = tid & 63;
     for (int l = 0; l < KH_MAX_L; ++l) part[l] = 0.0;
+    if (u.adj_store != nullptr) {
+        kh_gen_partials_adj(p, u, n, s, part, resident);
+        return;
+    }
     const double zero_eps[1] = {0.0};
     for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
         for (int i = tid; i < N; i += KH_GEN_THREADS) {
@@ -434,11 +546,19 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex)
     double g_a_loc[KH_MAX_L];
     for (int l = 0; l < KH_MAX_L; ++l) g_a_loc[l] = 0.0;
 
+    // One objective per workgroup and the sums on the adjoint side (no stage of the sweep then needs the state in global
+    // memory): the running state stays in s.acc from interval to interval -- read once, written back once -- instead of
+    // a global round trip in front of and behind every step.
+    const bool resident = (int)gridDim.x >= p.K && u.adj_store != nullptr;
+    if (resident && (int)blockIdx.x < p.K) {
+        for (int i = tid; i < N; i += KH_GEN_THREADS) s.acc[i] = u.phi[(size_t)blockIdx.x * N + i];
+        __syncthreads();
+    }
     // partial sums of the first interval handled by this launch
     if (u.internal_exchange || u.n_begin == u.n_end) {
         // (stepwise mode enters with the partials of n_begin already reduced in D_in,
         //  except for the begin call n_begin == n_end == 0 which only emits them)
-        if (u.n_begin < nt - 1) kh_gen_partials(p, u, u.n_begin, s, part);
+        if (u.n_begin < nt - 1) kh_gen_partials(p, u, u.n_begin, s, part, resident);
     }
     if (!u.internal_exchange && u.n_begin == u.n_end) {
         if (tid == 0)
@@ -480,13 +600,16 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex)
         for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
             const cplx *const *ops_k = p.ops + (size_t)k * (1 + L);
             const double *norms_k = p.op_norms + (size_t)k * (1 + L);
-            for (int i = tid; i < N; i += KH_GEN_THREADS) s.acc[i] = u.phi[(size_t)k * N + i];
-            __syncthreads();
+            if (!resident) {
+                for (int i = tid; i < N; i += KH_GEN_THREADS) s.acc[i] = u.phi[(size_t)k * N + i];
+                __syncthreads();
+            }
             if (u.fw_store != nullptr && n == 0)
                 for (int i = tid; i < N; i += KH_GEN_THREADS) u.fw_store[((size_t)k * nt) * N + i] = s.acc[i];
             matvecs += kh_gen_expm_action(p, ops_k, p.csr ? p.csr + (size_t)k * (1 + L) : nullptr, norms_k, eps, dt,
                                           s);
-            for (int i = tid; i < N; i += KH_GEN_THREADS) u.phi[(size_t)k * N + i] = s.acc[i];
+            if (!resident || n + 1 == u.n_end)
+                for (int i = tid; i < N; i += KH_GEN_THREADS) u.phi[(size_t)k * N + i] = s.acc[i];
             if (u.fw_store != nullptr)
                 for (int i = tid; i < N; i += KH_GEN_THREADS) u.fw_store[((size_t)k * nt + n + 1) * N + i] = s.acc[i];
             __syncthreads();
@@ -494,7 +617,7 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex)
         // ---- partial sums of the next interval ----
         if (n + 1 < nt - 1) {
             // phi written above by this same workgroup: visible after the barrier
-            kh_gen_partials(p, u, n + 1, s, part);
+            kh_gen_partials(p, u, n + 1, s, part, resident);
             matvecs += (double)L;
         }
     }

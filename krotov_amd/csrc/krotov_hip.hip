@@ -124,6 +124,11 @@ struct kh_engine {
     double *d_stats = nullptr;        // [4] (+ 64 trace stamps behind them in a KH_TIMING build)
     double *d_wg_partial = nullptr;   // [G][L]
     cplx *d_gen_scratch = nullptr;    // [gen_scratch_wgs][N][N] generic kernels: the interval's generator (ensure_gen_scratch)
+    // generic kernels, first order, dense operators: the update sums on the adjoint side (kh_gen_adjoint_side):
+    // H_lk^+ chi_k(t_n) for the whole co-state store, [L][K][nt][N], formed in front of every update sweep
+    cplx *d_gen_adj = nullptr;
+    bool gen_adj_failed = false;      // the allocation did not fit: the sums stay on the forward side
+    bool gen_adj_ready = false;       // d_gen_adj holds the store of the sweep in progress (stepwise launches reuse it)
     int gen_scratch_wgs = 0;
     bool gen_scratch_failed = false;
     const double *guess_dev = nullptr;  // remembered by kh_update_begin
@@ -397,6 +402,28 @@ static void ensure_gen_scratch(kh_engine *e, int wgs) {
     e->gen_scratch_wgs = wgs;
 }
 
+// The generic kernels' adjoint-side store [L][K][nt][N]: allocated at the first update sweep that can use it, at most
+// a quarter of the device memory that is free then (KH_GEN_ADJ=0: never); a store that does not fit leaves the sums on the
+// forward side for good.
+static bool ensure_gen_adj(kh_engine *e) {
+    if (e->d_gen_adj != nullptr) return true;
+    if (e->gen_adj_failed) return false;
+    if (const char *d = getenv("KH_GEN_ADJ"))
+        if (atoi(d) == 0) {
+            e->gen_adj_failed = true;
+            return false;
+        }
+    const size_t bytes = sizeof(cplx) * (size_t)e->L * e->K * e->nt * e->N;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4 || hipMalloc(&e->d_gen_adj, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        e->d_gen_adj = nullptr;
+        e->gen_adj_failed = true;
+        return false;
+    }
+    return true;
+}
+
 extern "C" void kh_engine_destroy(kh_engine *e) {
     if (e == nullptr) return;
     for (void *ptr : e->owned) (void)hipFree(ptr);
@@ -432,6 +459,7 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree(e->d_abort);
     (void)hipFree(e->d_wait_ticks);
     (void)hipFree(e->d_gen_scratch);
+    (void)hipFree(e->d_gen_adj);
     (void)hipFree(e->d_ell_scratch);
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_wg_partial);
@@ -1920,10 +1948,28 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         KhSweepArgs pg = p;
         pg.gen_scratch = e->d_gen_scratch;
         pg.gen_scratch_wgs = e->gen_scratch_wgs;
-        if (rc == KH_OK && !u.internal_exchange)
-            launch_plain<kh_gen_forward_update>(dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, pg, u, ex);
+        // first order, dense operators: V_lk = H_lk^+ chi_k for the whole store in front of the sweep (kh_generic.h,
+        // kh_gen_adjoint_side) -- at the sweep's first launch (the single launch, or kh_update_begin's); the launches
+        // of a stepwise sweep that follow reuse it
+        KhUpdateArgs ug = u;
+        if (rc == KH_OK) {
+            const bool first_launch = u.internal_exchange || (u.n_dev == nullptr && u.n_begin == 0 && u.n_end == 0);
+            if (first_launch) {
+                e->gen_adj_ready = false;
+                if (u.sigma == nullptr && e->d_csr_fw == nullptr && ensure_gen_adj(e)) {
+                    const dim3 grid((unsigned)(e->K * e->L), (unsigned)((e->nt + 63) / 64));
+                    kh_gen_adjoint_side<<<grid, KH_GEN_ADJ_THREADS, 0, st>>>(e->d_ops_bw, u.chi_store, e->d_gen_adj, e->K, e->N,
+                                                                              e->L, e->nt);
+                    KH_HIP(hipGetLastError());
+                    e->gen_adj_ready = true;
+                }
+            }
+            if (e->gen_adj_ready && u.sigma == nullptr) ug.adj_store = e->d_gen_adj;
+        }
+        if (rc == KH_OK && !ug.internal_exchange)
+            launch_plain<kh_gen_forward_update>(dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, pg, ug, ex);
         else if (rc == KH_OK)
-            rc = launch_persistent<kh_gen_forward_update>(e, dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, pg, u, ex);
+            rc = launch_persistent<kh_gen_forward_update>(e, dim3(e->grid_update), dim3(KH_GEN_THREADS), lds, st, pg, ug, ex);
     }
     if (rc != KH_OK) return rc;
     KH_HIP(hipGetLastError());

@@ -240,6 +240,58 @@ def test_full_gpu_ensemble_with_several_controls_vs_oracle_and_generic(L, monkey
     assert np.abs(out['tile'] - out['generic']).max() < 1e-13 * scale
 
 
+GEN_ADJ_CASES = {
+    'L6_n20': lambda: configs.config_c5(K=5, N=20, nt=31, L=6, distinct=True),
+    'L8_n64': lambda: configs.config_c5(K=4, N=64, nt=21, L=8),
+    'L5_n100': lambda: configs.config_c5(K=3, N=100, nt=13, L=5, distinct=True),   # (N not a multiple of 16)
+    'L2_n160': lambda: configs.config_c5(K=2, N=160, nt=7, L=2, distinct=True),    # (generator in the scratch matrix)
+    'c4_d6': lambda: configs.config_c4(d=6, nt=41, n_logical=2),                    # Liouville space: mu = i dL/d eps
+}
+
+
+@pytest.mark.parametrize('name', sorted(GEN_ADJ_CASES))
+def test_generic_update_sums_on_the_adjoint_side(name, monkeypatch):
+    """Generic kernels, first order, dense operators (what problems with 5...8 controls and per-objective operators
+    beyond N = 128 run): the update sums are taken as <H_l^+ chi_k(t_n) | phi_k(t_n)> with the left factors formed for the
+    whole co-state store in front of the sweep (kh_gen_adjoint_side, fp64 matrix cores) instead of L streamed
+    matrix-vector products per objective and interval (reference optimize.py:454-470).  Single launch and one launch per
+    interval, against the oracle and against the forward-side form (``KH_GEN_ADJ=0``); one objective without its last
+    control (a null operator: the store has a hole there and the sweep skips the sum)."""
+    spec = GEN_ADJ_CASES[name]()
+    if name == 'L6_n20':
+        spec.Hc[2][5] = None
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses, Sa, lama = np.array(gp), np.array(S), np.array(lam)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.37)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    tol = 1e-11 if spec.is_super else 1e-12
+    monkeypatch.setenv('KH_KERNEL', 'generic')
+    out = {}
+    for adj in ('1', '0'):
+        monkeypatch.setenv('KH_GEN_ADJ', adj)
+        eng = _engine(spec)
+        assert eng.kernel == 'generic'
+        chi = eng.backward(chi_T, pulses)
+        for form in ('single', 'stepwise'):
+            if form == 'single':
+                opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, Sa, lama)
+            else:
+                opt, psi_T, g_a = eng.forward_update_sharded(chi, norms, spec.init, pulses, Sa, lama, lambda t: None,
+                                                             graph_chunk=0)
+            eng.check()
+            out[adj, form] = opt.cpu().numpy()
+            assert np.abs(out[adj, form] - np.array(ref_opt)).max() < tol * scale
+            assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < tol
+            assert np.abs(g_a.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
+        eng.close()
+    assert np.array_equal(out['1', 'single'], out['1', 'stepwise'])
+    assert np.abs(out['1', 'single'] - out['0', 'single']).max() < 1e-13 * scale
+
+
 @pytest.mark.parametrize('name', ['c1', 'c2l', 'c3', 'c5_n64', 'c5_n33'])
 def test_q2_update_forward_side_partial_sums(name, monkeypatch):
     """The q2 update sweep normally takes <chi|H phi> on the adjoint side when the control operators are
