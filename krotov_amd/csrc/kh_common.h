@@ -40,7 +40,8 @@ typedef double2 cplx;
 #endif
 #define KH_DEFINES(owner) (KH_TU == KH_TU_ALL || KH_TU == (owner))
 
-#define KH_MAX_L 8          // controls per problem the kernels are compiled for
+#define KH_MAX_L 8          // controls per problem the register-resident kernel families are compiled for
+#define KH_GEN_MAX_L 32     // ... and the generic kernels (kh_generic.h), whose per-control values live in LDS
 #define KH_MAX_DEGREE 64    // hard cap on the Taylor degree per sub-step
 
 // 1/j for the Taylor coefficients: a scalar load instead of two fp64 divisions
@@ -431,10 +432,22 @@ __device__ __forceinline__ void kh_publish(const KhExchange &ex, int parity, int
 // all workgroups, accumulated in a fixed order (per lane: workgroups lane,
 // lane+64, ...; then the sum64 tree) that is identical in every workgroup, so
 // every workgroup derives bit-identical pulse values.
+// kh_gather_range: the controls l0 ... l0 + MAXL - 1 of L (the generic kernels gather more than KH_MAX_L controls in
+// groups of KH_MAX_L: a round's granules must fit the registers).
+template <int MAXL, int CH>
+__device__ __forceinline__ bool kh_gather_range(const KhExchange &ex, int parity, int L, int l0, unsigned int epoch, int lane,
+                                                double (&out)[MAXL]);
 template <int MAXL, int CH = KH_GATHER_CHUNKS>
 __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int L, unsigned int epoch, int lane,
                                           double (&out)[MAXL]) {
-    const kh_u64 *base = ex.slots + (size_t)parity * ex.G * L * 2;
+    return kh_gather_range<MAXL, CH>(ex, parity, L, 0, epoch, lane, out);
+}
+template <int MAXL, int CH>
+__device__ __forceinline__ bool kh_gather_range(const KhExchange &ex, int parity, int L, int l0, unsigned int epoch, int lane,
+                                                double (&out)[MAXL]) {
+    const kh_u64 *base = ex.slots + ((size_t)parity * ex.G * L + l0) * 2;
+    L -= l0;  // (controls left from l0 on; the slot stride below keeps the full count)
+    const int Lfull = L + l0;
     kh_u64 a[MAXL][CH], b[MAXL][CH];
     long long t0 = 0;  // (taken when the first poll fails: s_memrealtime is an SMEM read that the next lgkmcnt wait -- the
                        // LDS write of the result -- would sit behind in every interval)
@@ -450,7 +463,7 @@ __device__ __forceinline__ bool kh_gather(const KhExchange &ex, int parity, int 
             for (int c = 0; c < CH; ++c) {
                 const int wg = lane + 64 * c;
                 if (l < L && wg < ex.G) {
-                    const kh_u64 *g = base + ((size_t)wg * L + l) * 2;
+                    const kh_u64 *g = base + ((size_t)wg * Lfull + l) * 2;
                     a[l][c] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     b[l][c] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {

@@ -42,10 +42,16 @@ struct KhSweepArgs {
 };
 
 // LDS layout (dynamic): xa[N] xb[N] acc[N] chi[N] + scratch [+ the interval's generator A(eps), N x N, where it fits]
+// Everything per control is an LDS array of KH_GEN_MAX_L entries (thread l works on control l): the generic kernels take
+// up to KH_GEN_MAX_L = 32 controls (the reference loops over any number of pulses, optimize.py:454-477; the
+// register-resident families stop at KH_MAX_L = 8, where per-control values still fit registers).
 struct KhGenLds {
     cplx *xa, *xb, *acc, *chi;
-    double *red;  // [KH_GEN_THREADS/64 * 2 * KH_MAX_L] reduction scratch
-    double *D;    // [KH_MAX_L] cross-objective sums of the current interval
+    double *red;  // [KH_GEN_THREADS/64 * 2 * KH_GEN_MAX_L] reduction scratch
+    double *D;    // [KH_GEN_MAX_L] cross-objective sums of the current interval
+    double *eps;  // [KH_GEN_MAX_L] the interval's pulse values
+    double *part; // [KH_GEN_MAX_L] this workgroup's partial sums of the coming interval
+    double *ga;   // [KH_GEN_MAX_L] running g_a integrals
     int *ok;      // exchange status broadcast
     double *ratio;  // [KH_RATIO_STRIDE] the series' term ratios of the current degree (a global load per term otherwise)
     cplx *A;      // [N][N] A(eps) = H0 + sum_l eps_l H_l of the objective and interval at hand, or NULL (does not fit / CSR)
@@ -58,7 +64,7 @@ struct KhGenLds {
 __host__ __device__ inline bool kh_gen_lds_A(int N, bool dense) { return dense && N <= KH_GEN_LDS_A_NMAX; }
 
 __host__ __device__ inline size_t kh_gen_lds_base_bytes(int N) {
-    return ((size_t)4 * N * sizeof(cplx) + ((KH_GEN_THREADS / 64) * 2 * KH_MAX_L + KH_MAX_L + KH_RATIO_STRIDE) * sizeof(double) + 64 + 15) / 16 * 16;
+    return ((size_t)4 * N * sizeof(cplx) + ((KH_GEN_THREADS / 64) * 2 * KH_GEN_MAX_L + 4 * KH_GEN_MAX_L + KH_RATIO_STRIDE) * sizeof(double) + 64 + 15) / 16 * 16;
 }
 
 __device__ __forceinline__ KhGenLds kh_gen_carve(char *smem, int N, bool dense) {
@@ -68,8 +74,11 @@ __device__ __forceinline__ KhGenLds kh_gen_carve(char *smem, int N, bool dense) 
     s.acc = s.xb + N;
     s.chi = s.acc + N;
     s.red = (double *)(s.chi + N);
-    s.D = s.red + (KH_GEN_THREADS / 64) * 2 * KH_MAX_L;
-    s.ok = (int *)(s.D + KH_MAX_L);
+    s.D = s.red + (KH_GEN_THREADS / 64) * 2 * KH_GEN_MAX_L;
+    s.eps = s.D + KH_GEN_MAX_L;
+    s.part = s.eps + KH_GEN_MAX_L;
+    s.ga = s.part + KH_GEN_MAX_L;
+    s.ok = (int *)(s.ga + KH_GEN_MAX_L);
     s.ratio = (double *)(s.ok + 8);
     s.A = kh_gen_lds_A(N, dense) ? (cplx *)(smem + kh_gen_lds_base_bytes(N)) : nullptr;
     return s;
@@ -307,9 +316,11 @@ kh_gen_sweep_store(KhSweepArgs p, const double *__restrict__ pulses, const cplx 
         }
         for (int step = 0; step < nt - 1; ++step) {
             const int n = direction > 0 ? step : nt - 2 - step;
-            double eps[KH_MAX_L];
-            for (int l = 0; l < L; ++l) eps[l] = pulses[(size_t)l * (nt - 1) + n];
-            matvecs += kh_gen_expm_action(p, ops_k, p.csr ? p.csr + (size_t)k * (1 + L) : nullptr, norms_k, eps,
+            // (the interval's pulse values in LDS, thread l fetching control l: up to KH_GEN_MAX_L of them; the previous
+            // step's readers are behind the barrier that ends its last term)
+            if (tid < L) s.eps[tid] = pulses[(size_t)tid * (nt - 1) + n];
+            __syncthreads();
+            matvecs += kh_gen_expm_action(p, ops_k, p.csr ? p.csr + (size_t)k * (1 + L) : nullptr, norms_k, s.eps,
                                           p.dt[n], s);
             if (store != nullptr) {
                 const int idx = direction > 0 ? n + 1 : n;
@@ -418,62 +429,65 @@ kh_gen_adjoint_side(const cplx *const *__restrict__ ops_adj /*[K (1 + L)] adjoin
     ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
 #endif
 
-// Im( mu * norm_k * <chi_k(t_n) | H_l phi_k> ) summed over this workgroup's
-// objectives, for every control l -> part[l] (valid in every thread).
 // ... first order with the adjoint-side store (u.adj_store, kh_gen_adjoint_side): <H_l^+ chi_k(t_n) | phi_k> is an
-// element-wise product of two vectors -- no LDS staging, no matrix; the element loads of all controls (and of phi, which
-// this thread itself wrote) are in flight together, one reduction tree per control, one barrier pair per objective.
+// element-wise product of two vectors -- no LDS staging, no matrix; the element loads of a group of eight controls (and
+// of phi, which this thread itself wrote) are in flight together, one reduction tree per control.
 // `resident`: the workgroup owns ONE objective whose running state sits in s.acc (kh_gen_forward_update keeps it there
 // from interval to interval): read from LDS instead of the copy in global memory.
+// Both forms ADD this workgroup's pieces to s.part[l] (thread l; zeroed by kh_gen_partials) and end behind a barrier.
 __device__ __forceinline__ void kh_gen_partials_adj(const KhSweepArgs &p, const KhUpdateArgs &u, int n, const KhGenLds &s,
-                                                    double (&part)[KH_MAX_L], bool resident) {
+                                                    bool resident) {
     const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
     const int wave = tid >> 6, lane = tid & 63;
     for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
-        cplx ov[KH_MAX_L];
+        for (int l0 = 0; l0 < L; l0 += KH_MAX_L) {
+            cplx ov[KH_MAX_L];
 #pragma unroll
-        for (int l = 0; l < KH_MAX_L; ++l) ov[l] = c_make(0.0, 0.0);
-        for (int i = tid; i < N; i += KH_GEN_THREADS) {
-            const cplx x = resident ? s.acc[i] : u.phi[(size_t)k * N + i];
-            cplx v[KH_MAX_L];
+            for (int l = 0; l < KH_MAX_L; ++l) ov[l] = c_make(0.0, 0.0);
+            for (int i = tid; i < N; i += KH_GEN_THREADS) {
+                const cplx x = resident ? s.acc[i] : u.phi[(size_t)k * N + i];
+                cplx v[KH_MAX_L];
 #pragma unroll
-            for (int l = 0; l < KH_MAX_L; ++l)
-                v[l] = (l < L && p.ops[(size_t)k * (1 + L) + 1 + l] != nullptr)
-                           ? u.adj_store[(((size_t)l * p.K + k) * nt + n) * N + i]
-                           : c_make(0.0, 0.0);
+                for (int l = 0; l < KH_MAX_L; ++l)
+                    v[l] = (l0 + l < L && p.ops[(size_t)k * (1 + L) + 1 + l0 + l] != nullptr)
+                               ? u.adj_store[(((size_t)(l0 + l) * p.K + k) * nt + n) * N + i]
+                               : c_make(0.0, 0.0);
 #pragma unroll
-            for (int l = 0; l < KH_MAX_L; ++l) c_fma_conj(ov[l], v[l], x);
-        }
+                for (int l = 0; l < KH_MAX_L; ++l) c_fma_conj(ov[l], v[l], x);
+            }
 #pragma unroll
-        for (int l = 0; l < KH_MAX_L; ++l) {
-            if (l >= L) break;
-            const double re = sum64(ov[l].x), im = sum64(ov[l].y);
-            if (lane == 0) {
-                s.red[(wave * KH_MAX_L + l) * 2 + 0] = re;
-                s.red[(wave * KH_MAX_L + l) * 2 + 1] = im;
+            for (int l = 0; l < KH_MAX_L; ++l) {
+                if (l0 + l >= L) break;
+                const double re = sum64(ov[l].x), im = sum64(ov[l].y);
+                if (lane == 0) {
+                    s.red[(wave * KH_GEN_MAX_L + l0 + l) * 2 + 0] = re;
+                    s.red[(wave * KH_GEN_MAX_L + l0 + l) * 2 + 1] = im;
+                }
             }
         }
         __syncthreads();
-        const double nrm = u.chi_norms[k];
-        for (int l = 0; l < L; ++l) {
+        if (tid < L) {
             double re = 0.0, im = 0.0;
             for (int w = 0; w < KH_GEN_THREADS / 64; ++w) {
-                re += s.red[(w * KH_MAX_L + l) * 2 + 0];
-                im += s.red[(w * KH_MAX_L + l) * 2 + 1];
+                re += s.red[(w * KH_GEN_MAX_L + tid) * 2 + 0];
+                im += s.red[(w * KH_GEN_MAX_L + tid) * 2 + 1];
             }
-            part[l] += nrm * (u.mu_re * im + u.mu_im * re);  // Im(mu * ov) * norm  (optimize.py:466-467, 473)
+            s.part[tid] += u.chi_norms[k] * (u.mu_re * im + u.mu_im * re);  // Im(mu * ov) * norm  (optimize.py:466-467, 473)
         }
         __syncthreads();
     }
 }
 
+// Im( mu * norm_k * <chi_k(t_n) | H_l phi_k> ) summed over this workgroup's objectives, for every control l -> s.part[l]
+// (LDS; complete behind the function's last barrier).
 __device__ __forceinline__ void kh_gen_partials(const KhSweepArgs &p, const KhUpdateArgs &u, int n,
-                                                const KhGenLds &s, double (&part)[KH_MAX_L], bool resident = false) {
+                                                const KhGenLds &s, bool resident = false) {
     const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
     const int grp = tid >> 4, c16 = tid & 15, wave = tid >> 6, lane = tid & 63;
-    for (int l = 0; l < KH_MAX_L; ++l) part[l] = 0.0;
+    if (tid < L) s.part[tid] = 0.0;
+    __syncthreads();
     if (u.adj_store != nullptr) {
-        kh_gen_partials_adj(p, u, n, s, part, resident);
+        kh_gen_partials_adj(p, u, n, s, resident);
         return;
     }
     const double zero_eps[1] = {0.0};
@@ -508,19 +522,19 @@ __device__ __forceinline__ void kh_gen_partials(const KhSweepArgs &p, const KhUp
             // workgroup reduction in a fixed order: lanes (sum64) then waves
             const double re = sum64(ov.x), im = sum64(ov.y);
             if (lane == 0) {
-                s.red[(wave * KH_MAX_L + l) * 2 + 0] = re;
-                s.red[(wave * KH_MAX_L + l) * 2 + 1] = im;
+                s.red[(wave * KH_GEN_MAX_L + l) * 2 + 0] = re;
+                s.red[(wave * KH_GEN_MAX_L + l) * 2 + 1] = im;
             }
         }
         __syncthreads();
-        for (int l = 0; l < L; ++l) {
+        if (tid < L) {
             double re = 0.0, im = 0.0;
             for (int w = 0; w < KH_GEN_THREADS / 64; ++w) {
-                re += s.red[(w * KH_MAX_L + l) * 2 + 0];
-                im += s.red[(w * KH_MAX_L + l) * 2 + 1];
+                re += s.red[(w * KH_GEN_MAX_L + tid) * 2 + 0];
+                im += s.red[(w * KH_GEN_MAX_L + tid) * 2 + 1];
             }
             // Im(mu * ov) * norm  (optimize.py:466-467, 473)
-            part[l] += nrm * (u.mu_re * im + u.mu_im * re);
+            s.part[tid] += nrm * (u.mu_re * im + u.mu_im * re);
         }
         __syncthreads();
     }
@@ -542,9 +556,7 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex)
     const int tid = threadIdx.x, N = p.N, L = p.L, nt = p.nt;
     const int wave = tid >> 6, lane = tid & 63;
     double matvecs = 0.0;
-    double part[KH_MAX_L];
-    double g_a_loc[KH_MAX_L];
-    for (int l = 0; l < KH_MAX_L; ++l) g_a_loc[l] = 0.0;
+    if (tid < L) s.ga[tid] = 0.0;  // (thread l keeps control l's scalars: eps, g_a, partial sum -- all in LDS)
 
     // One objective per workgroup and the sums on the adjoint side (no stage of the sweep then needs the state in global
     // memory): the running state stays in s.acc from interval to interval -- read once, written back once -- instead of
@@ -558,11 +570,10 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex)
     if (u.internal_exchange || u.n_begin == u.n_end) {
         // (stepwise mode enters with the partials of n_begin already reduced in D_in,
         //  except for the begin call n_begin == n_end == 0 which only emits them)
-        if (u.n_begin < nt - 1) kh_gen_partials(p, u, u.n_begin, s, part, resident);
+        if (u.n_begin < nt - 1) kh_gen_partials(p, u, u.n_begin, s, resident);
     }
     if (!u.internal_exchange && u.n_begin == u.n_end) {
-        if (tid == 0)
-            for (int l = 0; l < L; ++l) u.wg_partial[(size_t)blockIdx.x * L + l] = part[l];
+        if (tid < L) u.wg_partial[(size_t)blockIdx.x * L + tid] = u.n_begin < nt - 1 ? s.part[tid] : 0.0;
         return;
     }
 
@@ -570,32 +581,53 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex)
         // ---- cross-objective sum D_l (optimize.py:470) ----
         if (u.internal_exchange) {
             if (wave == 0) {
-                double D[KH_MAX_L];
-                const bool ok = kh_exchange<KH_MAX_L>(ex, n, blockIdx.x, L, lane, part, D);
-                if (lane == 0) {
-                    *ok_sh_p = ok ? 1 : 0;
-                    for (int l = 0; l < L; ++l) D_sh[l] = D[l];
+                bool ok;
+                if (L <= KH_MAX_L) {
+                    double part[KH_MAX_L], D[KH_MAX_L];
+#pragma unroll
+                    for (int l = 0; l < KH_MAX_L; ++l) part[l] = l < L ? s.part[l] : 0.0;
+                    ok = kh_exchange<KH_MAX_L>(ex, n, blockIdx.x, L, lane, part, D);
+                    if (lane == 0)
+                        for (int l = 0; l < L; ++l) D_sh[l] = D[l];
+                } else {
+                    // more controls than a polling round keeps in registers: published at once (two granules per control
+                    // and lane: 2 L <= 64), gathered in groups of KH_MAX_L.  One GPU only (the host sees to it: with more
+                    // than KH_MAX_L controls a sharded run takes the all-reduce per interval, kh_p2p_create_window).
+                    kh_exchange_publish(ex, n, blockIdx.x, L, lane, s.part);
+                    ok = true;
+                    for (int l0 = 0; l0 < L && ok; l0 += KH_MAX_L) {
+                        double D[KH_MAX_L];
+                        if (ex.G == 1) {
+#pragma unroll
+                            for (int l = 0; l < KH_MAX_L; ++l) D[l] = l0 + l < L ? s.part[l0 + l] : 0.0;
+                        } else {
+                            ok = kh_gather_range<KH_MAX_L, KH_GATHER_CHUNKS>(ex, n & 1, L, l0, (unsigned)(n + 1), lane, D);
+                        }
+                        if (lane == 0)
+                            for (int l = 0; l < KH_MAX_L && l0 + l < L; ++l) D_sh[l0 + l] = D[l];
+                    }
                 }
+                if (lane == 0) *ok_sh_p = ok ? 1 : 0;
             }
             __syncthreads();
             if (!*ok_sh_p) return;
         } else {
-            if (tid == 0)
-                for (int l = 0; l < L; ++l) D_sh[l] = u.D_in[l];
+            if (tid < L) D_sh[tid] = u.D_in[tid];
             __syncthreads();
         }
-        // ---- pulse update (optimize.py:471-477) ----
+        // ---- pulse update (optimize.py:471-477): thread l takes control l ----
         const double dt = p.dt[n];
-        double eps[KH_MAX_L];
-        for (int l = 0; l < L; ++l) {
+        if (tid < L) {
+            const int l = tid;
             const double S = u.shape[(size_t)l * (nt - 1) + n];
             const double lam = u.lambda[l];
             const double d1 = D_sh[l];
-            eps[l] = u.guess[(size_t)l * (nt - 1) + n] + (S / lam) * d1;
-            g_a_loc[l] += (S / lam) * (d1 * d1) * dt;
+            const double e = u.guess[(size_t)l * (nt - 1) + n] + (S / lam) * d1;
+            s.eps[l] = e;
+            s.ga[l] += (S / lam) * (d1 * d1) * dt;
+            if (blockIdx.x == 0) u.opt[(size_t)l * (nt - 1) + n] = e;
         }
-        if (blockIdx.x == 0 && tid == 0)
-            for (int l = 0; l < L; ++l) u.opt[(size_t)l * (nt - 1) + n] = eps[l];
+        __syncthreads();
         // ---- propagate every local objective over interval n (optimize.py:479-491) ----
         for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
             const cplx *const *ops_k = p.ops + (size_t)k * (1 + L);
@@ -606,7 +638,7 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex)
             }
             if (u.fw_store != nullptr && n == 0)
                 for (int i = tid; i < N; i += KH_GEN_THREADS) u.fw_store[((size_t)k * nt) * N + i] = s.acc[i];
-            matvecs += kh_gen_expm_action(p, ops_k, p.csr ? p.csr + (size_t)k * (1 + L) : nullptr, norms_k, eps, dt,
+            matvecs += kh_gen_expm_action(p, ops_k, p.csr ? p.csr + (size_t)k * (1 + L) : nullptr, norms_k, s.eps, dt,
                                           s);
             if (!resident || n + 1 == u.n_end)
                 for (int i = tid; i < N; i += KH_GEN_THREADS) u.phi[(size_t)k * N + i] = s.acc[i];
@@ -617,14 +649,12 @@ kh_gen_forward_update(KhSweepArgs p, KhUpdateArgs u, KhExchange ex)
         // ---- partial sums of the next interval ----
         if (n + 1 < nt - 1) {
             // phi written above by this same workgroup: visible after the barrier
-            kh_gen_partials(p, u, n + 1, s, part, resident);
+            kh_gen_partials(p, u, n + 1, s, resident);
             matvecs += (double)L;
         }
     }
-    if (!u.internal_exchange && u.n_end < nt - 1 && tid == 0)
-        for (int l = 0; l < L; ++l) u.wg_partial[(size_t)blockIdx.x * L + l] = part[l];
-    if (blockIdx.x == 0 && tid == 0)
-        for (int l = 0; l < L; ++l) u.g_a[l] = (u.internal_exchange ? 0.0 : u.g_a[l]) + g_a_loc[l];
+    if (!u.internal_exchange && u.n_end < nt - 1 && tid < L) u.wg_partial[(size_t)blockIdx.x * L + tid] = s.part[tid];
+    if (blockIdx.x == 0 && tid < L) u.g_a[tid] = (u.internal_exchange ? 0.0 : u.g_a[tid]) + s.ga[tid];
     if (tid == 0 && p.stats != nullptr) atomicAdd(p.stats, matvecs);
 }
 #else

@@ -636,7 +636,8 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     *out = nullptr;
     if (pr->K < 1 || pr->N < 1 || pr->L < 0 || pr->nt < 2)
         return kh_fail(KH_ERR_INVALID, "bad sizes K=%d N=%d L=%d nt=%d", pr->K, pr->N, pr->L, pr->nt);
-    if (pr->L > KH_MAX_L) return kh_fail(KH_ERR_UNSUPPORTED, "L=%d controls > %d", pr->L, KH_MAX_L);
+    // (the register-resident families take up to KH_MAX_L controls; with more the generic kernels run, up to KH_GEN_MAX_L)
+    if (pr->L > KH_GEN_MAX_L) return kh_fail(KH_ERR_UNSUPPORTED, "L=%d controls > %d", pr->L, KH_GEN_MAX_L);
     if (pr->dt == nullptr || pr->ops == nullptr) return kh_fail(KH_ERR_INVALID, "dt/ops missing");
     for (int n = 0; n < pr->nt - 1; ++n)
         if (!(pr->dt[n] > 0.0)) return kh_fail(KH_ERR_INVALID, "dt[%d] = %g is not positive", n, pr->dt[n]);
@@ -800,7 +801,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
         const bool want_stream = force_k && strcmp(force_k, "ellstream") == 0;
         for (int form = want_stream ? 1 : 0; form < 2 && !ell_ok; ++form) {
             const bool stream = form == 1;
-            if (e->N > (stream ? KH_ELLS_NMAX : KH_ELL_NMAX) || (force_k && strcmp(force_k, "generic") == 0)) continue;
+            if (e->N > (stream ? KH_ELLS_NMAX : KH_ELL_NMAX) || e->L > KH_MAX_L || (force_k && strcmp(force_k, "generic") == 0)) continue;
             if (stream && getenv("KH_NO_ELLSTREAM") && atoi(getenv("KH_NO_ELLSTREAM"))) continue;
             ell_ok = true;
             e->ell_E = 0;
@@ -995,7 +996,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     bool tilen_ok = false;
     {
         const bool forced = force && strcmp(force, "tilen") == 0;
-        if (csr_fw == nullptr && e->N > KH_TILE_N && e->N <= KH_TN_NMAX && e->L >= 1 &&
+        if (csr_fw == nullptr && e->N > KH_TILE_N && e->N <= KH_TN_NMAX && e->L >= 1 && e->L <= KH_MAX_L &&
             ((e->kind == KIND_GENERIC && force == nullptr) || forced)) {
             tilen_ok = true;
             if (forced) {
@@ -2225,7 +2226,8 @@ extern "C" int kh_p2p_create_window(kh_engine *e, int32_t world, int32_t rank, u
     if (e == nullptr || ipc_handle_out == nullptr) return kh_fail(KH_ERR_INVALID, "null argument");
     if (world < 1 || rank < 0 || rank >= world) return kh_fail(KH_ERR_INVALID, "bad world/rank %d/%d", rank, world);
     const int Lx = e->L > 0 ? e->L : 1;
-    if (world * Lx * 2 > 64) return kh_fail(KH_ERR_UNSUPPORTED, "world * L = %d exceeds the 32 exchange lanes", world * Lx);
+    if (world * Lx * 2 > 64 || Lx > KH_MAX_L)
+        return kh_fail(KH_ERR_UNSUPPORTED, "world * L = %d exceeds the 32 exchange lanes (or more than %d controls)", world * Lx, KH_MAX_L);
     if (e->stepwise_only && !e->ens)  // (the caller falls back to kh_update_step + an all-reduce per interval)
         return kh_fail(KH_ERR_UNSUPPORTED, "%d objectives per GPU are not co-resident: no in-kernel exchange", e->K);
     if (e->p2p_window != nullptr) return kh_fail(KH_ERR_INVALID, "window already created");

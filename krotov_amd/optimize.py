@@ -48,7 +48,7 @@ from .conversions import (
 from ._lib import KrotovHipError as _KrotovHipError
 from ._lib import KH_ERR_TIMEOUT as _KH_ERR_TIMEOUT, KH_ERR_UNSUPPORTED as _KH_ERR_UNSUPPORTED
 
-_KH_MAX_CONTROLS = 8  # KH_MAX_L of krotov_amd/csrc/kh_common.h
+_KH_MAX_CONTROLS = 32  # KH_GEN_MAX_L of krotov_amd/csrc/kh_common.h (the register-resident kernel families: 8)
 _FULL_GRID_PROBE_EVERY = 16  # update sweeps in a row on a reduced grid before the full one is tried again
 from .info_hooks import chain
 from .mu import derivative_wrt_pulse
@@ -824,9 +824,10 @@ def optimize_pulses(
         )
     g_a_integrals = np.zeros(len(guess_pulses))
     if device_path and len(guess_pulses) > _KH_MAX_CONTROLS and process_group is None:
-        # the sweep kernels are compiled for at most 8 controls (KH_MAX_L); the reference takes any number
-        # (optimize.py:33-55, conversions.py:140-254).  More than that runs the reference's own structure: the host loop
-        # around single-interval propagations (each of them on the GPU) -- correct, and slow
+        # the sweep kernels are compiled for at most 32 controls (KH_GEN_MAX_L: the generic kernels; the register-resident
+        # families take 8); the reference takes any number (optimize.py:33-55, conversions.py:140-254).  More than that
+        # runs the reference's own structure: the host loop around single-interval propagations (each of them on the
+        # GPU) -- correct, and slow
         logger.warning("%d controls: the device sweeps take at most %d; running the host loop around single-step "
                        "propagations on the GPU", len(guess_pulses), _KH_MAX_CONTROLS)
         device_path = False

@@ -865,13 +865,17 @@ def _optimize_on_device(spec, iters, **kw):
 
 
 def test_more_controls_than_the_kernels_take(caplog):
-    """The reference takes any number of controls (optimize.py:33-55); the sweep kernels are compiled for 8.  Nine
-    controls must not raise: ``optimize_pulses`` runs the host loop around single-interval propagations on the GPU and
-    arrives at the oracle's pulses; eight controls stay on the device sweeps (generic kernels)."""
+    """The reference takes any number of controls (optimize.py:33-55).  The register-resident kernel families are
+    compiled for 8, the generic kernels for 32 (round 6: their per-control values live in LDS): 9, 17 and 32 controls stay
+    on the device sweeps -- single launch with the sums gathered in groups of eight --; 33 must not raise either:
+    ``optimize_pulses`` runs the host loop around single-interval propagations on the GPU.  All arrive at the oracle's
+    pulses."""
     import logging
 
-    for L, on_device in ((9, False), (8, True)):
-        spec = configs.config_c5(K=2, N=6, nt=7, L=L, distinct=True)
+    from krotov_amd.engine import LAST_ENGINE
+
+    for L, on_device in ((33, False), (32, True), (17, True), (9, True), (8, True)):
+        spec = configs.config_c5(K=3 if L > 9 else 2, N=6, nt=7, L=L, distinct=True)
         caplog.clear()
         caplog.set_level(logging.WARNING, logger='krotov')
         res = _optimize_on_device(spec, 2)
@@ -881,6 +885,61 @@ def test_more_controls_than_the_kernels_take(caplog):
         assert np.abs(got - ref['all_pulses']).max() < 1e-12 * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(np.array(res.tau_vals) - ref['tau_vals']).max() < 1e-12
         assert ('host loop around single-step' in caplog.text) == (not on_device)
+        if on_device:
+            assert LAST_ENGINE().kernel == 'generic' and LAST_ENGINE().L == L
+
+
+def test_seventeen_controls_every_form_of_the_generic_update():
+    """More than eight controls at engine level (generic kernels): single launch over 20 workgroups (in-kernel exchange in
+    groups of eight controls), one launch per interval, adjoint-side and forward-side sums, second order -- the oracle's
+    pulses, final states and g_a integrals in every form."""
+    spec = configs.config_c5(K=20, N=10, nt=9, L=17, distinct=True)
+    spec.Hc[3][16] = None
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses, Sa, lama = np.array(gp), np.array(S), np.array(lam)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.linspace(0.2, 0.5, spec.K)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    for adj in ('1', '0'):
+        os.environ['KH_GEN_ADJ'] = adj
+        try:
+            eng = _engine(spec)
+            assert eng.kernel == 'generic'
+            chi = eng.backward(chi_T, pulses)
+            assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-12
+            for form in ('single', 'stepwise'):
+                if form == 'single':
+                    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, Sa, lama)
+                else:
+                    opt, psi_T, g_a = eng.forward_update_sharded(chi, norms, spec.init, pulses, Sa, lama, lambda t: None,
+                                                                 graph_chunk=0)
+                eng.check()
+                assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * scale
+                assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+                assert np.abs(g_a.cpu().numpy() - ref_ga).max() < 1e-12 * max(1.0, np.abs(ref_ga).max())
+            eng.close()
+        finally:
+            os.environ.pop('KH_GEN_ADJ', None)
+    # second order (forward-side sums with the folded bra)
+    fw_T, fw_prev = None, None
+    eng = _engine(spec)
+    fw_T, fw_prev = eng.forward(pulses, spec.init, store=True)
+    sig = np.full(len(spec.tlist) - 1, -3.0)
+    import torch
+
+    fw_store = torch.empty_like(fw_prev)
+    eng.set_second_order(fw_prev, fw_store, sig)
+    chi = eng.backward(chi_T, pulses)
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, Sa, lama)
+    eng.check()
+    so_opt, so_psi, so_ga, so_states = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam, sigma_vals=sig,
+                                                               fw_prev=fw_prev.cpu().numpy(), store=True)
+    assert np.abs(opt.cpu().numpy() - np.array(so_opt)).max() < 1e-12 * max(1.0, np.abs(np.array(so_opt)).max())
+    assert np.abs(fw_store.cpu().numpy() - so_states).max() < 1e-12
+    eng.close()
 
 
 @pytest.mark.parametrize('cols', ['2', '4', '16'])
