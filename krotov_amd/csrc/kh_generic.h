@@ -380,9 +380,12 @@ struct KhUpdateArgs {
 // Operators: the engine's staged adjoints (what the backward sweep propagates with), any N the generic kernels take.
 // v_mfma_f64_16x16x4: A = operator block [row lane & 15][k lane >> 4], B = sixteen co-states [k lane >> 4][vector
 // lane & 15], D = [row 4 reg + (lane >> 4)][vector lane & 15]; blockIdx.x: (control l, objective k) as l K + k,
-// blockIdx.y: 64 time points.
+// blockIdx.y: KH_GEN_ADJ_POINTS time points (every wave takes KH_GEN_ADJ_VG groups of sixteen with one fetch of an
+// operator block).
 typedef double kh_gen_d4 __attribute__((ext_vector_type(4)));
-#define KH_GEN_ADJ_THREADS 256  // 4 waves x 16 vectors
+#define KH_GEN_ADJ_THREADS 256  // 4 waves
+#define KH_GEN_ADJ_VG 4         // groups of 16 time points per wave: an operator block fetched once serves 64 co-states
+#define KH_GEN_ADJ_POINTS (4 * 16 * KH_GEN_ADJ_VG)  // time points per workgroup
 __global__ void __launch_bounds__(KH_GEN_ADJ_THREADS)
 kh_gen_adjoint_side(const cplx *const *__restrict__ ops_adj /*[K (1 + L)] adjoint operators, row-major N x N*/,
                     const cplx *__restrict__ chi_store /*[K][nt][N]*/, cplx *__restrict__ V /*[L][K][nt][N]*/, int K,
@@ -394,34 +397,49 @@ kh_gen_adjoint_side(const cplx *const *__restrict__ ops_adj /*[K (1 + L)] adjoin
     const int l = blockIdx.x / K, k = blockIdx.x % K;
     const cplx *op = ops_adj[(size_t)k * (1 + L) + 1 + l];
     if (op == nullptr) return;  // (the control does not occur in this objective: its sums are skipped in the sweep too)
-    const int n = (blockIdx.y * 4 + wave) * 16 + j;  // this lane's time point (B operand column)
-    const bool vec_ok = n < nt;
-    const cplx *x = chi_store + ((size_t)k * nt + (vec_ok ? n : 0)) * N;
-    cplx *v = V + (((size_t)l * K + k) * nt + (vec_ok ? n : 0)) * N;
+    // this lane's time points (B operand columns): one per vector group
+    const int n0 = (blockIdx.y * 4 + wave) * 16 * KH_GEN_ADJ_VG + j;
+    const cplx *xk = chi_store + (size_t)k * nt * N;
+    cplx *vk = V + ((size_t)l * K + k) * nt * N;
     const int G = (N + 15) / 16;
     for (int g = 0; g < G; ++g) {
-        kh_gen_d4 dr = {0.0, 0.0, 0.0, 0.0}, di = {0.0, 0.0, 0.0, 0.0};
+        kh_gen_d4 dr[KH_GEN_ADJ_VG], di[KH_GEN_ADJ_VG];
+#pragma unroll
+        for (int vg = 0; vg < KH_GEN_ADJ_VG; ++vg) dr[vg] = di[vg] = kh_gen_d4{0.0, 0.0, 0.0, 0.0};
         const int arow = 16 * g + j;  // A operand: row lane & 15
         for (int kb = 0; kb < G; ++kb) {
-            cplx a[4], b[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {  // (the eight loads of a block in flight together)
-                const int kk = 16 * kb + 4 * ks + kq;
-                a[ks] = (kk < N && arow < N) ? op[(size_t)arow * N + kk] : c_make(0.0, 0.0);
-                b[ks] = (kk < N && vec_ok) ? x[kk] : c_make(0.0, 0.0);
-            }
+            cplx a[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                dr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].x, b[ks].x, dr, 0, 0, 0);
-                dr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].y, -b[ks].y, dr, 0, 0, 0);
-                di = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].x, b[ks].y, di, 0, 0, 0);
-                di = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].y, b[ks].x, di, 0, 0, 0);
+                const int kk = 16 * kb + 4 * ks + kq;
+                a[ks] = (kk < N && arow < N) ? op[(size_t)arow * N + kk] : c_make(0.0, 0.0);
+            }
+#pragma unroll
+            for (int vg = 0; vg < KH_GEN_ADJ_VG; ++vg) {
+                const int n = n0 + 16 * vg;
+                cplx b[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kk = 16 * kb + 4 * ks + kq;
+                    b[ks] = (kk < N && n < nt) ? xk[(size_t)n * N + kk] : c_make(0.0, 0.0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    dr[vg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].x, b[ks].x, dr[vg], 0, 0, 0);
+                    dr[vg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].y, -b[ks].y, dr[vg], 0, 0, 0);
+                    di[vg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].x, b[ks].y, di[vg], 0, 0, 0);
+                    di[vg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].y, b[ks].x, di[vg], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = 16 * g + 4 * reg + kq;
-            if (vec_ok && row < N) v[row] = c_make(dr[reg], di[reg]);
+        for (int vg = 0; vg < KH_GEN_ADJ_VG; ++vg) {
+            const int n = n0 + 16 * vg;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * g + 4 * reg + kq;
+                if (n < nt && row < N) vk[(size_t)n * N + row] = c_make(dr[vg][reg], di[vg][reg]);
+            }
         }
     }
 }

@@ -173,6 +173,7 @@ struct kh_engine {
     bool ens = false;
     int ens_ncg = 0, ens_G = 0;
     const cplx *ens_H0 = nullptr, *ens_H1 = nullptr;
+    bool ens2 = true;  // first order, 4 objectives per workgroup: the A^2-chain form (kh_ens2_forward_update); KH_ENS2=0: off
     double *d_ens_scale = nullptr;     // [K]
     bool mini = false;           // kind q2, N <= 16, K <= 8: the one-wave-per-objective kernels (kh_mini.h)
     bool quad = false;           // mini with N <= 4, K <= 4: the whole problem in one wave
@@ -1332,6 +1333,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
                     KH_HIP_E(err);
                     if (flags[0] == 0 && flags[1] == 0) {
                         e->ens = true;
+                        e->ens2 = !(getenv("KH_ENS2") && atoi(getenv("KH_ENS2")) == 0);
                         e->ens_ncg = ncg;
                         e->ens_G = (e->K + 2 * ncg - 1) / (2 * ncg);
                         e->ens_H0 = fw[0];
@@ -1813,6 +1815,19 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         e->last_update_grid = G;
         const size_t lds = kh_ens_lds_bytes(ncg);
         const bool so = u.sigma != nullptr;
+        // first order, four objectives per workgroup (512 < K <= 1024): the A^2 chain with the update sums on the adjoint
+        // side (kh_ens2_forward_update; KH_ENS2=0: the term-by-term kernel, A/B switch and what second order and the other
+        // column-group counts run -- with one column group it measured 2 % slower, with 4 and 8 its operands do not fit)
+        if (!so && ncg == 2 && e->ens2 && e->d_sq_fw != nullptr && ensure_gen_adj(e)) {
+            const dim3 agrid((unsigned)e->K, (unsigned)((e->nt + KH_GEN_ADJ_POINTS - 1) / KH_GEN_ADJ_POINTS));
+            kh_gen_adjoint_side<<<agrid, KH_GEN_ADJ_THREADS, 0, st>>>(e->d_ops_bw, u.chi_store, e->d_gen_adj, e->K, e->N, 1, e->nt);
+            KH_HIP(hipGetLastError());
+            KhUpdateArgs ua = u;
+            ua.adj_store = e->d_gen_adj;
+            const size_t lds2 = kh_ens2_lds_bytes(ncg);
+            rc = ensure_dynamic_lds(e, (const void *)kh_ens2_forward_update<2>, lds2);
+            if (rc == KH_OK) rc = launch_persistent<kh_ens2_forward_update<2>>(e, g, b, lds2, st, p, en, e->d_sq_fw, ua, exe);
+        } else
 #define KH_ENS_UPDATE(NCG)                                                                          \
     (so ? launch_persistent<kh_ens_forward_update<NCG, true>>(e, g, b, lds, st, p, en, u, exe)      \
         : launch_persistent<kh_ens_forward_update<NCG, false>>(e, g, b, lds, st, p, en, u, exe))
@@ -1958,7 +1973,7 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             if (first_launch) {
                 e->gen_adj_ready = false;
                 if (u.sigma == nullptr && e->d_csr_fw == nullptr && ensure_gen_adj(e)) {
-                    const dim3 grid((unsigned)(e->K * e->L), (unsigned)((e->nt + 63) / 64));
+                    const dim3 grid((unsigned)(e->K * e->L), (unsigned)((e->nt + KH_GEN_ADJ_POINTS - 1) / KH_GEN_ADJ_POINTS));
                     kh_gen_adjoint_side<<<grid, KH_GEN_ADJ_THREADS, 0, st>>>(e->d_ops_bw, u.chi_store, e->d_gen_adj, e->K, e->N,
                                                                               e->L, e->nt);
                     KH_HIP(hipGetLastError());
