@@ -259,6 +259,26 @@ kh_tn_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
 
     // pieces of Im(mu <chi(t_n) + 0.5 sigma/||chi|| (phi - phi_prev) | H_l phi(t_n)>) -> red[wave][l]; phi(t_n) = `state`
     auto partial_pieces = [&](int n) {
+        if constexpr (!SO && !H1REG) {
+            if (u.adj_store != nullptr) {
+                // adjoint side (first order; u.adj_store = [L][K][nt][N] H_lk^+ chi_k(t_n), kh_gen_adjoint_side): a control's
+                // piece is conj(V_l[row]) phi[row] on the row's writer lane -- no staging of phi, no operator stream
+                for (int l = 0; l < L; ++l) {
+                    double v = 0.0;
+                    if (writer && tab_k[1 + l] != nullptr) {
+                        const cplx vl = u.adj_store[(((size_t)l * p.K + k) * nt + n) * N + row];
+                        cplx ov = c_make(0.0, 0.0);
+                        c_fma_conj(ov, vl, state);
+                        v = u.mu_re * ov.y + u.mu_im * ov.x;
+                    }
+                    v = sum64(v);
+                    if (lane == 0) s.red[wave * KH_MAX_L + l] = v;
+                }
+                matvecs += (double)L;
+                __syncthreads();
+                return;
+            }
+        }
         cplx bra = c_make(0.0, 0.0);
         if (writer) {
             bra = u.chi_store[((size_t)k * nt + n) * N + row];

@@ -1902,6 +1902,17 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         const dim3 g(e->K), b(KH_TN_THREADS);
         const size_t lds = kh_tn_lds_bytes();
         const bool so = u.sigma != nullptr;
+        // first order with the control operators NOT in registers (several controls, or N > 96): the update sums on the
+        // adjoint side, H_lk^+ chi_k for the whole store in front of the sweep (kh_generic.h, kh_gen_adjoint_side) instead
+        // of L streamed control products per interval (N = 100, L = 6: 60 of the update sweep's 106 us per interval)
+        KhUpdateArgs ut = u;
+        if (!so && !e->tn_h1reg && ensure_gen_adj(e)) {
+            const dim3 agrid((unsigned)(e->K * e->L), (unsigned)((e->nt + KH_GEN_ADJ_POINTS - 1) / KH_GEN_ADJ_POINTS));
+            kh_gen_adjoint_side<<<agrid, KH_GEN_ADJ_THREADS, 0, st>>>(e->d_ops_bw, u.chi_store, e->d_gen_adj, e->K, e->N, e->L, e->nt);
+            KH_HIP(hipGetLastError());
+            ut.adj_store = e->d_gen_adj;
+        }
+        const KhUpdateArgs &u = ut;
 #define KH_TN_UPDATE(EP, HR)                                                                                                  \
     (so ? launch_persistent<kh_tn_forward_update<EP, true, HR>>(e, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex) \
         : launch_persistent<kh_tn_forward_update<EP, false, HR>>(e, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex))

@@ -202,6 +202,16 @@ def test_register_generator_kernels_for_n_up_to_128(name, kernel, monkeypatch):
     assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < tol
     assert np.abs(g_a.cpu().numpy() - ref_ga).max() < tol * max(1.0, np.abs(ref_ga).max())
     eng.close()
+    if kernel == 'tilen':
+        # (round 6) with the control operators not in registers the update sums above were taken on the adjoint side
+        # (kh_gen_adjoint_side); the forward-side form of the same sweep
+        monkeypatch.setenv('KH_GEN_ADJ', '0')
+        eng = _engine(spec)
+        opt0, psi0, _ = eng.forward_update(chi, norms, spec.init, pulses, np.array(S), np.array(lam))
+        eng.check()
+        assert np.abs(opt0.cpu().numpy() - np.array(ref_opt)).max() < tol * scale
+        assert np.abs(psi0.cpu().numpy() - ref_psi).max() < tol
+        eng.close()
 
 
 @pytest.mark.parametrize('L', [2, 3, 4])
