@@ -63,7 +63,8 @@ enum kh_status {
 typedef struct kh_problem {
     int32_t K;        /* objectives handled by this engine (this GPU's shard) */
     int32_t N;        /* state dimension */
-    int32_t L;        /* controls */
+    int32_t L;        /* controls: at most 32 (KH_ERR_UNSUPPORTED beyond); the register-resident kernel families
+                         take up to 8 (4, 2 for some), with more the generic kernels run */
     int32_t nt;       /* len(tlist); nt-1 intervals */
     int32_t is_super; /* 0: Hilbert space, eqm factor -i (propagators.py:94);
                          1: Liouville space, factor 1 (propagators.py:96-98),
