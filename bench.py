@@ -569,6 +569,12 @@ def main():
             # matrix cores, several objectives per workgroup (kh_ens.h); plain sweeps as above
             'ens64/mfma': ('kh_ens_forward_update', 'kh_q2_sweep_store'),
         }.get(eng.kernel, ('kh_tile_forward_update', 'kh_tile_sweep_store'))
+        if eng.kernel == 'ens64/mfma':
+            # two objectives' columns per wave and one control: the A^2-chain form of the ensemble kernel (kh_ens.h:
+            # kh_ens2_forward_update); which one ran is read off the library's launch record
+            from krotov_amd import _lib as _khlib
+            if any(name.startswith('kh_ens2_forward_update') for name in _khlib.kernel_instantiations(launched_only=True)):
+                kernel_names = ('kh_ens2_forward_update', kernel_names[1])
         if group is not None and not getattr(eng, '_p2p_used', False) and eng.kernel != 'generic':
             # per-interval launches (RCCL path) run the two-tile kernel, see krotov_hip.hip:launch_update
             kernel_names = ('kh_tile_forward_update', kernel_names[1])
