@@ -40,7 +40,7 @@ At N = 1 the line carries instead, measured after the headline and not part of
 matrices under one 400-dim Liouvillian: the cooperative fp64 matrix-core
 kernels; ``--no-config4`` skips it, ``--workload c4`` makes it the line itself)
 and the two variants SURVEY.md 8d asks for, ``"L4"`` (four controls) and
-``"distinct"`` (256 distinct random drifts), three iterations each
+``"distinct"`` (256 distinct random drifts), three iterations each, ``"L8"`` (eight controls)
 (``--no-variants`` skips them).
 """
 import argparse
@@ -562,6 +562,7 @@ def main():
             'generic': ('kh_gen_forward_update', 'kh_gen_sweep_store'),
             'coop16/mfma': ('kh_coop_forward_update', 'kh_coop_sweep_store'),
             'tile128/512': ('kh_tn_forward_update', 'kh_tn_sweep_store'),
+            'tile64x/512': ('kh_tx_forward_update', 'kh_tx_sweep_store'),  # five to eight controls (kh_tile64x.h)
             # more objectives than the GPU keeps co-resident: the streaming update kernel (kh_tile64s.h); the plain sweeps
             # take the objectives in turns
             'tile64/stream': ('kh_stream_forward_update', 'kh_q2_sweep_store' if args.L == 1 else 'kh_tile_sweep_store'),
@@ -873,6 +874,8 @@ def main():
             # "L=1 (also report L=4)" and "a second variant with K distinct random H0_k"
             out['L4'] = leg(L=4, steps=3, warmup=1, pmc_case='L4')
             out['distinct'] = leg(distinct=True, steps=3, warmup=1)
+            # five to eight controls: the register-tile kernels with streamed operators (kh_tile64x.h)
+            out['L8'] = leg(L=8, steps=2, warmup=1)
             # per-objective operators beyond the N <= 64 register tiles (kh_tilen.h: the generator in registers up to N = 128)
             out['N96'] = leg(N=96, steps=3, warmup=1, pmc_case='N96')
             # an ensemble that does not fit the GPU's co-resident workgroups: one drift and scaled control operators run

@@ -29,7 +29,7 @@ OUT = os.path.join(HERE, 'libkrotov_hip.so')
 FAMILY_UNITS = [
     'KH_TU_COOP_UPDATE_A', 'KH_TU_COOP_UPDATE_B', 'KH_TU_ELL_UPDATE_A', 'KH_TU_ELL_UPDATE_B', 'KH_TU_TILE',
     'KH_TU_COOP_STORE', 'KH_TU_TILEN', 'KH_TU_STREAM', 'KH_TU_ELL_STORE', 'KH_TU_Q2', 'KH_TU_ENS', 'KH_TU_MINI',
-    'KH_TU_GENERIC',
+    'KH_TU_GENERIC', 'KH_TU_TILEX',
 ]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 

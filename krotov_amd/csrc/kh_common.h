@@ -35,6 +35,7 @@ typedef double2 cplx;
 #define KH_TU_ELL_STORE 12
 #define KH_TU_ELL_UPDATE_A 13
 #define KH_TU_ELL_UPDATE_B 14
+#define KH_TU_TILEX 15
 #ifndef KH_TU
 #define KH_TU KH_TU_ALL
 #endif

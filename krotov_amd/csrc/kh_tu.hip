@@ -17,6 +17,8 @@
 #include "kh_tile64.h"
 #elif KH_TU == KH_TU_Q2
 #include "kh_tile64q2.h"
+#elif KH_TU == KH_TU_TILEX
+#include "kh_tile64x.h"
 #elif KH_TU == KH_TU_STREAM
 #include "kh_tile64s.h"
 #elif KH_TU == KH_TU_ENS

@@ -30,6 +30,7 @@
 #include "kh_generic.h"
 #include "kh_tile64.h"
 #include "kh_tile64s.h"
+#include "kh_tile64x.h"
 #include "kh_tile64q2.h"
 #ifdef KH_WITH_Q4  // experiment build only (scripts/experiments/kh_tile64q4.h: 1024-thread plain sweep, measured 71 % slower)
 #include "../../scripts/experiments/kh_tile64q4.h"
@@ -66,7 +67,7 @@ static int kh_fail(int code, const char *fmt, ...) {
                            __FILE__, __LINE__);                                               \
     } while (0)
 
-enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3, KIND_COOP = 4, KIND_ELL = 5, KIND_TILEN = 6 };
+enum KernelKind { KIND_GENERIC = 0, KIND_TILE_RPT2 = 1, KIND_TILE_RPT1 = 2, KIND_TILE_Q2 = 3, KIND_COOP = 4, KIND_ELL = 5, KIND_TILEN = 6, KIND_TILEX = 7 /* plain sweeps only: kind_store */ };
 
 struct kh_engine {
     int K, N, L, nt, is_super;
@@ -114,6 +115,8 @@ struct kh_engine {
     const cplx **d_sq_fw = nullptr;   // [K*3] P0, P1, P2 of A^2 (q2 kernels), forward operators
     const cplx **d_sq_bw = nullptr;   // [K*3] the same for the adjoint operators
     const cplx **d_tn_fw = nullptr, **d_tn_bw = nullptr;  // [K*(1+L)] lane-order operator copies (kh_tilen.h), or NULL
+    const cplx **d_tx_fw = nullptr, **d_tx_bw = nullptr;  // [K*(1+L)] lane-order 64 x 64 operator copies (kh_tile64x.h), or NULL
+    bool tx_update = false;           // ... and the update sweep may take that family too (K <= co-resident workgroups)
     bool tn_h1reg = false;            // ... one control, present in every objective, N <= 96: it stays in registers too
     std::vector<void *> owned;        // adjoint operator copies
     // workspaces
@@ -333,7 +336,7 @@ static int check_residency(const kh_engine *e, const void *func, int threads, si
     return KH_OK;
 }
 
-extern "C" const char *kh_version(void) { return "krotov_hip 0.6 (gfx950; tile64q2, tile64, tile64/stream, ens64/mfma, mini16, mini4, coop16/mfma, ell/csr, ellstream/csr, tile128, generic, generic/csr kernels)"; }
+extern "C" const char *kh_version(void) { return "krotov_hip 0.6 (gfx950; tile64q2, tile64, tile64/stream, tile64x, ens64/mfma, mini16, mini4, coop16/mfma, ell/csr, ellstream/csr, tile128, generic, generic/csr kernels)"; }
 
 extern "C" const char *kh_engine_kernel(const kh_engine *e) {
     if (e == nullptr) return "";
@@ -345,7 +348,7 @@ extern "C" const char *kh_engine_kernel(const kh_engine *e) {
         case KIND_COOP: return "coop16/mfma";
         case KIND_ELL: return e->ell_stream ? "ellstream/csr" : "ell/csr";
         case KIND_TILEN: return "tile128/512";
-        default: return e->d_csr_fw != nullptr ? "generic/csr" : "generic";
+        default: return e->d_csr_fw != nullptr ? "generic/csr" : (e->d_tx_fw != nullptr ? "tile64x/512" : "generic");
     }
 }
 
@@ -455,6 +458,8 @@ extern "C" void kh_engine_destroy(kh_engine *e) {
     (void)hipFree((void *)e->d_sq_bw);
     (void)hipFree((void *)e->d_tn_fw);
     (void)hipFree((void *)e->d_tn_bw);
+    (void)hipFree((void *)e->d_tx_fw);
+    (void)hipFree((void *)e->d_tx_bw);
     (void)hipFree(e->d_phi);
     (void)hipFree(e->d_slots);
     (void)hipFree(e->d_abort);
@@ -1034,6 +1039,45 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
             }
         }
     }
+    // Five to eight controls, N <= 64: the register-tile kernels with the operators beyond the CU's room streamed
+    // (kh_tile64x.h) instead of the generic kernels.  The plain sweeps take their objectives in turns (any K); the
+    // update sweep needs one resident workgroup per objective, first order and the adjoint-side store (launch_update:
+    // otherwise the generic kernels, which stay this engine's `kind`).  KH_TX=0: off (A/B switch); KH_KERNEL=tilex: testing
+    bool tx_ok = false;
+    {
+        const bool forced = force && strcmp(force, "tilex") == 0;
+        const bool off = getenv("KH_TX") && atoi(getenv("KH_TX")) == 0;
+        if (csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= KH_TX_MIN_L && e->L <= KH_MAX_L && e->kind == KIND_GENERIC &&
+            (force == nullptr || forced) && !off) {
+            tx_ok = true;
+            std::map<const void *, cplx *> perm_of;
+            cplx *zero_tile = nullptr;  // stands in for a control an objective does not have (no branches in the kernels' loads)
+            KH_HIP_E(hipMalloc(&zero_tile, sizeof(cplx) * 8 * KH_TX_THREADS));
+            e->owned.push_back(zero_tile);
+            KH_HIP_E(hipMemset(zero_tile, 0, sizeof(cplx) * 8 * KH_TX_THREADS));
+            for (int dir = 0; dir < 2; ++dir) {
+                const std::vector<const cplx *> &tab = dir == 0 ? fw : bw;
+                std::vector<const cplx *> out(nops, zero_tile);
+                for (size_t i = 0; i < nops; ++i) {
+                    if (tab[i] == nullptr) continue;
+                    auto it = perm_of.find(tab[i]);
+                    if (it == perm_of.end()) {
+                        cplx *dst = nullptr;
+                        KH_HIP_E(hipMalloc(&dst, sizeof(cplx) * 8 * KH_TX_THREADS));
+                        e->owned.push_back(dst);
+                        kh_tx_permute<<<8, KH_TX_THREADS>>>(tab[i], dst, e->N);
+                        it = perm_of.emplace(tab[i], dst).first;
+                    }
+                    out[i] = it->second;
+                }
+                const cplx ***slot = dir == 0 ? &e->d_tx_fw : &e->d_tx_bw;
+                KH_HIP_E(hipMalloc((void **)slot, sizeof(cplx *) * nops));
+                KH_HIP_E(hipMemcpy((void *)*slot, out.data(), sizeof(cplx *) * nops, hipMemcpyHostToDevice));
+            }
+            KH_HIP_E(hipGetLastError());
+            e->tx_update = e->K <= max_wgs;
+        }
+    }
     // Sparse operators in the padded row form: one 1024-thread workgroup per objective, the matrix in registers
     // (kh_ell.h).  The update sweep exchanges the sums in-kernel, so all K workgroups must be resident (one per CU);
     // with more objectives it stays with the generic CSR kernels, the plain sweeps take their objectives in turns.
@@ -1057,7 +1101,7 @@ static int engine_create(const kh_problem *pr, const kh_csr *csr_fw, const kh_cs
     }
     // The plain sweeps have no cross-objective coupling, so the register-tile kernel serves them for any
     // number of objectives (workgroups simply run in turns) even when the update sweep needs the generic one.
-    e->kind_store = ell_ok ? KIND_ELL : (tilen_ok ? KIND_TILEN : e->kind);
+    e->kind_store = ell_ok ? KIND_ELL : (tilen_ok ? KIND_TILEN : (tx_ok ? KIND_TILEX : e->kind));
     if (e->kind == KIND_GENERIC && csr_fw == nullptr && e->N <= KH_TILE_N && e->L >= 1 && e->L <= 4 &&
         !(force && strcmp(force, "generic") == 0))
         e->kind_store = KIND_TILE_RPT1;
@@ -1622,6 +1666,23 @@ static int sweep_store(kh_engine *e, bool backward, const double *pulses, const 
             KH_TN_STORE(32, false);
         }
 #undef KH_TN_STORE
+    } else if (e->kind_store == KIND_TILEX) {
+        const int grid = e->K < e->num_cus ? e->K : e->num_cus;
+        const cplx *const *tabs = backward ? e->d_tx_bw : e->d_tx_fw;
+#define KH_TX_STORE(LT)                                                                                                    \
+    do {                                                                                                                   \
+        rc = ensure_dynamic_lds(e, (const void *)kh_tx_sweep_store<LT>, kh_tx_lds_bytes());                                \
+        if (rc == KH_OK)                                                                                                   \
+            launch_plain<kh_tx_sweep_store<LT>>(dim3(grid), dim3(KH_TX_THREADS), kh_tx_lds_bytes(), st, p, tabs, pulses, in, \
+                                                store, out, direction);                                                    \
+    } while (0)
+        switch (e->L) {
+            case 5: KH_TX_STORE(5); break;
+            case 6: KH_TX_STORE(6); break;
+            case 7: KH_TX_STORE(7); break;
+            default: KH_TX_STORE(8); break;
+        }
+#undef KH_TX_STORE
     } else if (e->kind_store == KIND_ELL) {
         const KhEll *ells = backward ? e->d_ell_bw : e->d_ell_fw;
         const int grid = e->ell_stream ? (e->K < e->num_cus ? e->K : e->num_cus) : (e->K < 4 * e->num_cus ? e->K : 4 * e->num_cus);
@@ -1966,6 +2027,31 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             case 4: rc = launch_tile_update<1, 4>(e, p, u, ex, st); break;
             default: return kh_fail(KH_ERR_UNSUPPORTED, "tile kernels handle 1..4 controls");
         }
+    } else if (e->tx_update && whole && u.sigma == nullptr && e->reduced_G == 0 && e->grid_update >= e->K && ensure_gen_adj(e)) {
+        // five to eight controls, N <= 64, one resident workgroup per objective, first order: the register-tile form with
+        // streamed operators (kh_tile64x.h); V_lk = H_lk^+ chi_k for the whole store in front of the sweep as below
+        const dim3 agrid((unsigned)(e->K * e->L), (unsigned)((e->nt + KH_GEN_ADJ_POINTS - 1) / KH_GEN_ADJ_POINTS));
+        kh_gen_adjoint_side<<<agrid, KH_GEN_ADJ_THREADS, 0, st>>>(e->d_ops_bw, u.chi_store, e->d_gen_adj, e->K, e->N, e->L, e->nt);
+        KH_HIP(hipGetLastError());
+        KhUpdateArgs ux = u;
+        ux.adj_store = e->d_gen_adj;
+        KhExchange exx = ex;
+        exx.G = e->K;
+        e->last_update_grid = e->K;
+#define KH_TX_UPDATE(LT)                                                                                              \
+    do {                                                                                                              \
+        rc = ensure_dynamic_lds(e, (const void *)kh_tx_forward_update<LT>, kh_tx_lds_bytes());                        \
+        if (rc == KH_OK)                                                                                              \
+            rc = launch_persistent<kh_tx_forward_update<LT>>(e, dim3(e->K), dim3(KH_TX_THREADS), kh_tx_lds_bytes(), st, p, \
+                                                             (const cplx *const *)e->d_tx_fw, ux, exx);                \
+    } while (0)
+        switch (e->L) {
+            case 5: KH_TX_UPDATE(5); break;
+            case 6: KH_TX_UPDATE(6); break;
+            case 7: KH_TX_UPDATE(7); break;
+            default: KH_TX_UPDATE(8); break;
+        }
+#undef KH_TX_UPDATE
     } else {
         if (!e->gen_fits)
             return kh_fail(KH_ERR_UNSUPPORTED, "N=%d: this form of the update sweep needs the generic kernels, whose vectors do not fit LDS", e->N);

@@ -20,7 +20,7 @@ B. ``ref``     -- the reference's real ``krotov.optimize_pulses`` loop executed
    replaced by empty stub modules (they are not installed), on the seeded
    synthetic inputs of ``krotov_amd.configs``.  Outputs: all pulses, tau_vals.
 
-Usage:  python tests/golden/make_reference_goldens.py [dumps] [ref] [c5full] [c4full] [second_order]
+Usage:  python tests/golden/make_reference_goldens.py [dumps] [ref] [c5full] [c4full] [c5full5] [c4full5] [second_order]
 
 The reference is BSD-3-Clause (c) 2018-2024 Michael Goerz et al.; the fixtures
 derived from its shipped data keep that attribution (tests/golden/README.md).
@@ -280,8 +280,9 @@ def import_reference_krotov():
     return krotov
 
 
-def run_reference(spec, iter_stop, krotov=None, sigma=None):
-    """Run the reference loop on a ProblemSpec; returns dict of outputs."""
+def run_reference(spec, iter_stop, krotov=None, sigma=None, after_iter=None):
+    """Run the reference loop on a ProblemSpec; returns dict of outputs.  ``after_iter(outputs so far)`` is called
+    from the reference's ``check_convergence`` hook after every iteration (optimize.py:550-551)."""
     import scipy.linalg as la
 
     from krotov_amd import configs
@@ -312,19 +313,30 @@ def run_reference(spec, iter_stop, krotov=None, sigma=None):
 
     chi = getattr(krotov.functionals, 'chis_' + spec.chi)
     t0 = time.time()
+
+    def outputs(res, with_controls=True):
+        out = dict(
+            all_pulses=np.array([np.array(p) for p in res.all_pulses]),
+            tau_vals=np.array(res.tau_vals),
+            fw_T=np.array([np.asarray(s).ravel() for s in res.states]),
+            seconds=time.time() - t0,
+        )
+        if with_controls:
+            out['optimized_controls'] = np.array(res.optimized_controls)
+        return out
+
+    def hook(result):
+        if after_iter is not None:
+            after_iter(outputs(result, with_controls=False))
+        return None
+
     res = krotov.optimize_pulses(
         objectives, pulse_options, spec.tlist,
         propagator=expm, chi_constructor=chi, mu=mu, overlap=overlap,
         norm=np.linalg.norm, iter_stop=iter_stop, store_all_pulses=True, sigma=sigma,
+        check_convergence=hook,
     )
-    secs = time.time() - t0
-    return dict(
-        all_pulses=np.array([np.array(p) for p in res.all_pulses]),
-        tau_vals=np.array(res.tau_vals),
-        fw_T=np.array([np.asarray(s).ravel() for s in res.states]),
-        optimized_controls=np.array(res.optimized_controls),
-        seconds=secs,
-    )
+    return outputs(res)
 
 
 REF_CASES = {
@@ -558,8 +570,33 @@ def make_c4_full():
     print('ref_c4_full: %.0fs' % out['seconds'])
 
 
+def make_full5(which):
+    """FIVE iterations of the reference's loop at full size ("after 1, 2, 5 iterations on every config"):
+    BASELINE config 5 (11 sweeps * 256 * 4000 dense 64 x 64 expm, ~2.6 CPU-hours) -> ref_c5_full5.npz; config 4
+    (11 * 16 * 1000 dense 400 x 400 expm, ~3.2 CPU-hours) -> ref_c4_full5.npz.  The fixture is written after EVERY
+    iteration (iter_stop = iterations it holds so far): an interrupted run still leaves a usable one."""
+    from krotov_amd import configs
+
+    spec = configs.config_c5() if which == 'c5' else configs.config_c4()
+    path = os.path.join(HERE, 'ref_%s_full5.npz' % which)
+
+    def save(out):
+        n_done = len(out['all_pulses']) - 1
+        if n_done >= 1:
+            np.savez_compressed(path + '.tmp.npz', iter_stop=n_done, **out)
+            os.replace(path + '.tmp.npz', path)
+            print('ref_%s_full5: %d iteration(s), %.0fs' % (which, n_done, out['seconds']), flush=True)
+
+    out = run_reference(spec, 5, after_iter=save)
+    save(out)
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['dumps', 'ref']
+    if 'c5full5' in what:
+        make_full5('c5')
+    if 'c4full5' in what:
+        make_full5('c4')
     if 'dumps' in what:
         make_dump_fixtures()
     if 'ref' in what:

@@ -250,6 +250,94 @@ def test_full_gpu_ensemble_with_several_controls_vs_oracle_and_generic(L, monkey
     assert np.abs(out['tile'] - out['generic']).max() < 1e-13 * scale
 
 
+TILEX_CASES = {
+    # five to eight controls, N <= 64 (kh_tile64x.h): which operators are resident / streamed changes with L
+    'L5_n64': lambda: configs.config_c5(K=4, N=64, nt=21, L=5),
+    'L6_n20': lambda: configs.config_c5(K=5, N=20, nt=31, L=6, distinct=True),
+    'L7_n33': lambda: configs.config_c5(K=3, N=33, nt=17, L=7, distinct=True),
+    'L8_n64': lambda: configs.config_c5(K=4, N=64, nt=21, L=8, distinct=True),
+    'L5_k260': lambda: configs.config_c5(K=260, N=6, nt=6, L=5),  # more objectives than CUs: plain sweeps in turns only
+}
+
+
+@pytest.mark.parametrize('name', sorted(TILEX_CASES))
+def test_five_to_eight_controls_register_tiles(name, monkeypatch):
+    """N <= 64 with 5 ... 8 controls (reference optimize.py:393-418, 444-508 loop over any number of pulses): the
+    register-tile kernels with the operators beyond the CU's room streamed per interval (kh_tile64x.h) -- plain sweeps in
+    both directions, the update sweep with its sums on the adjoint side, against the oracle; objectives without one of
+    their controls (a register-resident one, an LDS-resident one, a streamed one: the engine's zero tile and a hole in
+    the adjoint-side store); the second-order update and the per-interval form fall to the generic kernels on the same
+    engine; ``KH_TX=0`` is the generic family throughout."""
+    import torch
+
+    from krotov_amd import _lib
+
+    spec = TILEX_CASES[name]()
+    if name == 'L6_n20':
+        spec.Hc[2][5] = None   # streamed
+        spec.Hc[0][3] = None   # in LDS
+    if name == 'L7_n33':
+        spec.Hc[1][1] = None   # in registers
+        spec.Hc[2][6] = None   # streamed, fetched ahead
+    prob = spec_to_oracle(spec)
+    gp, S, lam = oracle_controls(spec)
+    pulses, Sa, lama = np.array(gp), np.array(S), np.array(lam)
+    chi_T = spec.target / np.linalg.norm(spec.target, axis=1)[:, None]
+    norms = np.full(spec.K, 0.37 * min(1.0, 8.0 / spec.K))
+    ref_T, ref_states = ko.forward_propagation(prob, gp, store=True)
+    ref_chi = ko.backward_sweep(prob, chi_T, gp)
+    ref_opt, ref_psi, ref_ga = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam)
+    scale = max(1.0, np.abs(np.array(ref_opt)).max())
+    _lib.forget_launched_kernels()
+    eng = _engine(spec)
+    assert eng.kernel == 'tile64x/512'
+    fw_T, states = eng.forward(pulses, spec.init, store=True)
+    assert np.abs(states.cpu().numpy() - ref_states).max() < 1e-12
+    assert np.abs(fw_T.cpu().numpy() - ref_T).max() < 1e-12
+    chi = eng.backward(chi_T, pulses)
+    assert np.abs(chi.cpu().numpy() - ref_chi).max() < 1e-12
+    opt, psi_T, g_a = eng.forward_update(chi, norms, spec.init, pulses, Sa, lama)
+    eng.check()
+    assert np.abs(opt.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * scale
+    assert np.abs(psi_T.cpu().numpy() - ref_psi).max() < 1e-12
+    assert np.abs(g_a.cpu().numpy() - ref_ga).max() < 1e-12 * max(1.0, np.abs(ref_ga).max())
+    again = eng.forward_update(chi, norms, spec.init, pulses, Sa, lama)
+    assert torch.equal(again[0], opt) and torch.equal(again[1], psi_T)  # (bitwise repeatable)
+    launched = _lib.kernel_instantiations(launched_only=True)
+    assert 'kh_tx_sweep_store<%d>' % spec.L in launched
+    assert ('kh_tx_forward_update<%d>' % spec.L in launched) == (name != 'L5_k260')
+    # one launch per interval (what a sharded sweep over RCCL runs): the generic kernels on the same engine
+    opt2, psi2, _ = eng.forward_update_sharded(chi, norms, spec.init, pulses, Sa, lama, lambda t: None, graph_chunk=0)
+    eng.check()
+    assert np.abs(opt2.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * scale
+    assert np.abs(psi2.cpu().numpy() - ref_psi).max() < 1e-12
+    if name in ('L5_n64', 'L7_n33'):
+        # second order (optimize.py:434-443, 468-469): the update sweep of the generic family, stores of this one
+        rng = np.random.default_rng(5)
+        sigma_vals = -(1.0 + rng.random(len(spec.tlist) - 1))
+        prev = ref_states
+        so_opt, so_psi, so_ga, so_store = ko.forward_update_sweep(prob, ref_chi, norms, gp, S, lam, sigma_vals=sigma_vals,
+                                                                  fw_prev=prev, store=True)
+        store = torch.full((spec.K, len(spec.tlist), spec.N), float('nan'), dtype=torch.complex128, device=eng.device)
+        eng.set_second_order(prev, store, sigma_vals)
+        opt3, psi3, _ = eng.forward_update(chi, norms, spec.init, pulses, Sa, lama)
+        eng.check()
+        assert np.abs(opt3.cpu().numpy() - np.array(so_opt)).max() < 1e-12 * max(1.0, np.abs(np.array(so_opt)).max())
+        assert np.abs(store.cpu().numpy() - so_store).max() < 1e-12
+        eng.set_second_order()
+    eng.close()
+    # the switch
+    monkeypatch.setenv('KH_TX', '0')
+    gen = _engine(spec)
+    assert gen.kernel == 'generic'
+    chi_g = gen.backward(chi_T, pulses)
+    assert float((chi_g - chi).abs().max()) < 1e-12
+    opt_g = gen.forward_update(chi_g, norms, spec.init, pulses, Sa, lama)[0]
+    gen.check()
+    assert float((opt_g - opt).abs().max()) < 1e-12 * scale
+    gen.close()
+
+
 GEN_ADJ_CASES = {
     'L6_n20': lambda: configs.config_c5(K=5, N=20, nt=31, L=6, distinct=True),
     'L8_n64': lambda: configs.config_c5(K=4, N=64, nt=21, L=8),
@@ -911,7 +999,8 @@ def test_more_controls_than_the_kernels_take(caplog):
         assert np.abs(np.array(res.tau_vals) - ref['tau_vals']).max() < 1e-12
         assert ('host loop around single-step' in caplog.text) == (not on_device)
         if on_device:
-            assert LAST_ENGINE().kernel == 'generic' and LAST_ENGINE().L == L
+            # (five to eight controls at N <= 64: the register-tile kernels with streamed operators, kh_tile64x.h)
+            assert LAST_ENGINE().kernel == ('tile64x/512' if L <= 8 else 'generic') and LAST_ENGINE().L == L
 
 
 def test_seventeen_controls_every_form_of_the_generic_update():
@@ -1000,6 +1089,39 @@ def test_optimize_pulses_vs_reference_loop_goldens(name):
     fw_T = np.array([np.asarray(s).ravel(order='F') for s in res.states])
     assert np.abs(fw_T - g['fw_T']).max() < tol
     assert np.abs(np.array(res.optimized_controls) - g['optimized_controls']).max() < tol * scale
+
+
+FULL5_CASES = {
+    # fixture: (spec, kernel the engine must pick, tolerance)
+    'ref_c5_full5': (lambda: configs.config_c5(), 'tile64q2/512', 1e-10),
+    'ref_c4_full5': (lambda: configs.config_c4(), 'coop16/mfma', 1e-9),
+}
+
+
+@pytest.mark.parametrize('name', sorted(FULL5_CASES))
+def test_full_size_five_iterations_vs_reference_loop(name):
+    """SURVEY.md 8d's acceptance at FULL size: BASELINE config 5 (256 x N = 64 x 4000 intervals) and config 4 (16 density
+    matrices, 400-dim Liouvillian, 1000 intervals) through ``optimize_pulses`` on the GPU for as many iterations as the
+    fixture holds (five; tests/golden/make_reference_goldens.py c5full5 / c4full5: the reference's own loop, 2.6 / 3.2
+    CPU-hours) -- the pulses after EVERY iteration, tau of every objective after every iteration, the final states.  A
+    lost fixture fails the test."""
+    import krotov_amd.engine as engine_mod
+
+    make, kernel, tol = FULL5_CASES[name]
+    g = golden(name)
+    iters = int(g['iter_stop'])
+    assert iters >= 1
+    spec = make()
+    res = _optimize_on_device(spec, iters)
+    assert engine_mod.LAST_ENGINE().kernel == kernel
+    got = np.array([np.array(p) for p in res.all_pulses])
+    assert got.shape == g['all_pulses'].shape
+    scale = max(1.0, np.abs(g['all_pulses']).max())
+    for i in range(iters + 1):  # (per iteration: a drift that grows with the iteration count shows where it starts)
+        assert np.abs(got[i] - g['all_pulses'][i]).max() < tol * scale, 'pulses after iteration %d' % i
+        assert np.abs(np.array(res.tau_vals[i]) - g['tau_vals'][i]).max() < tol, 'tau after iteration %d' % i
+    fw_T = np.array([np.asarray(s).ravel(order='F') for s in res.states])
+    assert np.abs(fw_T - g['fw_T']).max() < tol
 
 
 @pytest.mark.parametrize('name,ncg', [('ref_c5_n64', '1'), ('ref_c5_n64', '2'), ('ref_c5_small', '4')])
