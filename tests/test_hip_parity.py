@@ -311,7 +311,7 @@ def test_five_to_eight_controls_register_tiles(name, monkeypatch):
     eng.check()
     assert np.abs(opt2.cpu().numpy() - np.array(ref_opt)).max() < 1e-12 * scale
     assert np.abs(psi2.cpu().numpy() - ref_psi).max() < 1e-12
-    if name in ('L5_n64', 'L7_n33'):
+    if name in ('L5_n64', 'L7_n33', 'L8_n64'):
         # second order (optimize.py:434-443, 468-469): the update sweep of the generic family, stores of this one
         rng = np.random.default_rng(5)
         sigma_vals = -(1.0 + rng.random(len(spec.tlist) - 1))
