@@ -875,7 +875,7 @@ def main():
             out['L4'] = leg(L=4, steps=3, warmup=1, pmc_case='L4')
             out['distinct'] = leg(distinct=True, steps=3, warmup=1)
             # five to eight controls: the register-tile kernels with streamed operators (kh_tile64x.h)
-            out['L8'] = leg(L=8, steps=2, warmup=1)
+            out['L8'] = leg(L=8, steps=2, warmup=1, pmc_case='L8')
             # per-objective operators beyond the N <= 64 register tiles (kh_tilen.h: the generator in registers up to N = 128)
             out['N96'] = leg(N=96, steps=3, warmup=1, pmc_case='N96')
             # an ensemble that does not fit the GPU's co-resident workgroups: one drift and scaled control operators run

@@ -22,7 +22,7 @@ c)
   hipcc --offload-arch=gfx950 -O3 scripts/ubench_gather.hip -o /tmp/ubench_gather 2>/dev/null && /tmp/ubench_gather > $OUT/ubench_gather.txt 2>&1
   bash scripts/exp_ens.sh "512 1024 2048 4096" 1001 2>&1 | grep -v amdgpu.ids > $OUT/exp_ens.txt
   # the cliffs outside the register families: per-objective operators beyond N = 128, more than four controls
-  for a in "256 160 101 1" "64 256 101 1" "256 64 501 6" "256 64 501 8" "256 100 201 6" "256 96 501 2" "256 128 201 1"; do
+  for a in "256 160 101 1" "64 256 101 1" "256 64 501 5" "256 64 501 6" "256 64 501 7" "256 64 501 8" "256 100 201 6" "256 96 501 2" "256 128 201 1"; do
     timeout 600 python scripts/perf_sweeps.py $a 2>&1 | grep -v amdgpu.ids >> $OUT/cliffs.txt
   done
   # config 4: where a round of the cooperative kernels goes (timing build)

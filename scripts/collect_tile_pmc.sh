@@ -6,7 +6,7 @@
 # (summarised into profiles/<tag>/pmc_tile.json by scripts/summarize_profiles.py; the case names are bench.py's leg names)
 set -u
 TAG=${1:-r05}
-CASES=${2:-"L2 L4 K512 K1024 K1024_distinct K2048_distinct N96 sparse sparse_n1600"}
+CASES=${2:-"L2 L4 L8 K512 K1024 K1024_distinct K2048_distinct N96 sparse sparse_n1600"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG/tile_pmc
 mkdir -p $OUT
@@ -26,6 +26,7 @@ for c in $CASES; do
   case $c in
     L2) run L2 $R/scripts/perf_sweeps.py 256 64 1001 2;;
     L4) run L4 $R/scripts/perf_sweeps.py 256 64 1001 4;;
+    L8) run L8 $R/scripts/perf_sweeps.py 256 64 501 8;;
     K512) run K512 $R/scripts/perf_sweeps.py 512 64 1001 1;;
     K1024) run K1024 $R/scripts/perf_sweeps.py 1024 64 501 1;;
     K1024_distinct) run K1024_distinct $R/scripts/perf_sweeps.py 1024 64 501 1 distinct;;

@@ -12,6 +12,10 @@ run distinct --distinct
 run L2 --L 2
 run L3 --L 3
 run L4 --L 4
+# five to eight controls: the register tiles with streamed operators (kh_tile64x.h)
+run L5 --L 5 --steps 3
+run L6 --L 6 --steps 3
+run L8 --L 8 --steps 3
 run K64 --K 64
 run K128 --K 128
 run K512 --K 512 --steps 3

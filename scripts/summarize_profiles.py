@@ -139,7 +139,7 @@ if os.path.isdir(tdir):
                 cfg_case = {'d': int(a[0]), 'N': int(a[0]) ** 2, 'nt': int(a[1]), 'K': int(a[2]), 'L': 1}
             tsum.setdefault(case, {})['_config'] = dict(cfg_case, command=' '.join([script] + a))
         for kern, ctrs in load_counters(os.path.join(tdir, sub)).items():
-            if kern.startswith(('kh_tile', 'kh_q2_sweep', 'kh_q2_forward', 'kh_ell', 'kh_gen', 'kh_ens_forward', 'kh_ens2_forward', 'kh_stream', 'kh_tn_sweep', 'kh_tn_forward')):
+            if kern.startswith(('kh_tile', 'kh_tx_', 'kh_q2_sweep', 'kh_q2_forward', 'kh_ell', 'kh_gen', 'kh_ens_forward', 'kh_ens2_forward', 'kh_stream', 'kh_tn_sweep', 'kh_tn_forward')):
                 for c, (avg, n) in ctrs.items():
                     tsum.setdefault(case, {}).setdefault(kern, {})[c] = {'avg_per_launch': avg, 'launches': n}
     json.dump(tsum, open(os.path.join(dst, 'pmc_tile.json'), 'w'), indent=1, sort_keys=True)
