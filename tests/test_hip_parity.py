@@ -1541,6 +1541,8 @@ def _two_rank_spec(case):
         return configs.config_sparse_lindblad(d=9, nt=41, K=4)
     if case == 'n80':  # per-objective operators, N = 80, two controls: the register-generator kernels, 3 + 3 objectives
         return configs.config_c5(K=6, N=80, nt=31, L=2)
+    if case == 'L6':  # six controls at N = 48: register tiles with a streamed operator (kh_tile64x.h), 3 + 2 objectives
+        return configs.config_c5(K=5, N=48, nt=25, L=6, distinct=True)
     if case == 'c4full':  # BASELINE config 4 at full size (debugging the 8-rank bench leg; not in a test list)
         return configs.config_c4()
     if case == 'c5w4L2':  # two controls (one-term-per-phase kernels), 4 x 5
@@ -1633,7 +1635,7 @@ def _two_rank_worker(rank, world, port, queue, case='c5'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'c4k25', 'k1100', 'k1100ens', 'n80', 'sparse'])
+@pytest.mark.parametrize('case', ['c5', 'c3', 'c4', 'c4so', 'c4k25', 'k1100', 'k1100ens', 'n80', 'L6', 'sparse'])
 def test_two_ranks_sharded_on_one_gpu(case):
     import socket
 
@@ -1659,12 +1661,12 @@ def test_two_ranks_sharded_on_one_gpu(case):
         ref = oracle_optimize(spec, 2, sigma=SigmaA(0.0, 2e-3))
     else:
         ref = oracle_optimize(spec, 2)
-    tol = 1e-12 if case in ('c5', 'c3', 'k1100', 'k1100ens', 'n80', 'sparse') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
+    tol = 1e-12 if case in ('c5', 'c3', 'k1100', 'k1100ens', 'n80', 'L6', 'sparse') else 1e-11  # (stiff Liouvillian, as in test_sweeps_match_oracle)
     for _, pulses, tau, used_p2p, kernel, _diag in out:
         assert np.abs(pulses - ref['all_pulses']).max() < tol * max(1.0, np.abs(ref['all_pulses']).max())
         assert np.abs(tau - ref['tau_vals']).max() < tol
         assert kernel == {'c5': 'tile64q2/512', 'c3': 'mini4/wave', 'k1100': 'tile64/stream', 'k1100ens': 'ens64/mfma',
-                          'n80': 'tile128/512', 'sparse': 'ell/csr'}.get(case, 'coop16/mfma')
+                          'n80': 'tile128/512', 'L6': 'tile64x/512', 'sparse': 'ell/csr'}.get(case, 'coop16/mfma')
     assert np.array_equal(out[0][1], out[1][1])
     # the path this test is here for: the sums crossed the ranks inside the persistent kernels, through the
     # peer-mapped windows -- not through the per-interval fallback
