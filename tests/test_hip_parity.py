@@ -2460,3 +2460,13 @@ def test_bench_gpus_8_dry_run_on_one_gpu(tmp_path):
     _check_rank_diagnostics(rec, 8)
     print("bench.py --gpus 8 dry run: %.0f s wall; weak %.1f ms, strong %.1f ms, rccl %.1f ms per iteration" % (
         wall, rec['ms_per_step'], rec['strong']['ms_per_step'], rec['rccl']['ms_per_step']))
+
+
+def test_fuzz_parity_fixed_seed():
+    """A fixed-seed slice of tests/fuzz_parity.py: 40 randomly drawn small problems around the kernel families' dispatch
+    boundaries, the three sweeps of each against the oracle (the script itself runs for as long as one lets it)."""
+    import fuzz_parity
+
+    done, failures = fuzz_parity.fuzz(seed=20260930, cases=40, verbose=False)
+    assert done == 40 and not failures, '\n'.join(failures)
+
