@@ -65,21 +65,30 @@ __global__ void kh_tn_permute(const cplx *__restrict__ in, cplx *__restrict__ ou
     ;  // (defined in the translation unit that owns it: kh_common.h, KH_DEFINES)
 #endif
 
+// The lane-order copies are padded to 128 rows; a lane whose row is beyond N (`active` false) holds zeros and does not
+// fetch them -- at N = 81 that is 37 % of an operator's bytes, and the kernels with several controls are bound by exactly
+// that stream (round 6: N = 100, L = 6: 48 / 88 -> 39 / 68 us per interval; N = 81, L = 2: 15.1 / 27.2 -> 13.8 / 22.7).
 template <int EPL>
-__device__ __forceinline__ void kh_tn_load(const cplx *__restrict__ tab, int tid, cplx (&a)[EPL]) {
+__device__ __forceinline__ void kh_tn_load(const cplx *__restrict__ tab, int tid, bool active, cplx (&a)[EPL]) {
     const unsigned t = (unsigned)kh_launder(tid);
+    if (active) {
 #pragma unroll
-    for (int j0 = 0; j0 < EPL; j0 += 4) {
+        for (int j0 = 0; j0 < EPL; j0 += 4) {
 #pragma unroll
-        for (int j = j0; j < j0 + 4; ++j) a[j] = (tab + (size_t)j * KH_TN_THREADS)[t];
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = j0; j < j0 + 4; ++j) a[j] = (tab + (size_t)j * KH_TN_THREADS)[t];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) a[j] = c_make(0.0, 0.0);
     }
 }
 
 // a += w * (operator in lane order)
 template <int EPL>
-__device__ __forceinline__ void kh_tn_axpy(const cplx *__restrict__ tab, double w, int tid, cplx (&a)[EPL]) {
+__device__ __forceinline__ void kh_tn_axpy(const cplx *__restrict__ tab, double w, int tid, bool active, cplx (&a)[EPL]) {
     const unsigned t = (unsigned)kh_launder(tid);
+    if (!active) return;
 #pragma unroll
     for (int j0 = 0; j0 < EPL; j0 += 4) {
         cplx v[4];
@@ -182,13 +191,13 @@ kh_tn_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ tabs, const dou
         const cplx *const *tab_k = tabs + (size_t)k * (1 + L);
         const double *norms_k = p.op_norms + (size_t)k * (1 + L);
         cplx a[EPL], h1[H1REG ? EPL : 1];
-        if constexpr (H1REG) kh_tn_load<EPL>(tab_k[1], tid, h1);  // (L == 1, operator present: checked by the host)
+        if constexpr (H1REG) kh_tn_load<EPL>(tab_k[1], tid, active, h1);  // (L == 1, operator present: checked by the host)
         cplx state = active ? state_in[(size_t)k * N + row] : c_make(0.0, 0.0);
         if (store != nullptr && writer) store[((size_t)k * nt + (direction > 0 ? 0 : nt - 1)) * N + row] = state;
         KhDegreeCache dc = {12, 1.0, 0.0};
         for (int step0 = 0; step0 < nt - 1; step0 += KH_TN_REFRESH) {
             __syncthreads();
-            kh_tn_load<EPL>(tab_k[0], tid, a);  // restart from the drift: rounding of the advances cannot drift
+            kh_tn_load<EPL>(tab_k[0], tid, active, a);  // restart from the drift: rounding of the advances cannot drift
             if (tid < L) s.eps_prev[tid] = 0.0;
             const int step_stop = step0 + KH_TN_REFRESH < nt - 1 ? step0 + KH_TN_REFRESH : nt - 1;
             for (int step = step0; step < step_stop; ++step) {
@@ -211,7 +220,7 @@ kh_tn_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ tabs, const dou
                 } else {
                     for (int l = 0; l < L; ++l) {
                         const double e = s.eps[l], d = e - s.eps_prev[l];
-                        if (tab_k[1 + l] != nullptr && d != 0.0) kh_tn_axpy<EPL>(tab_k[1 + l], d, tid, a);
+                        if (tab_k[1 + l] != nullptr && d != 0.0) kh_tn_axpy<EPL>(tab_k[1 + l], d, tid, active, a);
                     }
                 }
                 int nsub, m;
@@ -250,7 +259,7 @@ kh_tn_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
     // poison every row), and dynamic LDS holds whatever the previous kernel left there
     if (tid >= N && tid < KH_TN_NMAX) s.buf[0][tid] = s.buf[1][tid] = c_make(0.0, 0.0);
     cplx a[EPL], h1[H1REG ? EPL : 1];
-    if constexpr (H1REG) kh_tn_load<EPL>(tab_k[1], tid, h1);
+    if constexpr (H1REG) kh_tn_load<EPL>(tab_k[1], tid, active, h1);
     cplx state = active ? u.phi[(size_t)k * N + row] : c_make(0.0, 0.0);
     if (SO && writer) u.fw_store[((size_t)k * nt) * N + row] = state;
     double matvecs = 0.0;
@@ -316,7 +325,7 @@ kh_tn_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
     partial_pieces(0);
 
     for (int nr = 0, n_stop; nr < nt - 1; nr = n_stop) {
-        kh_tn_load<EPL>(tab_k[0], tid, a);  // restart A = H0
+        kh_tn_load<EPL>(tab_k[0], tid, active, a);  // restart A = H0
         if (tid < L) s.eps_prev[tid] = 0.0;
         n_stop = (nr / KH_TN_REFRESH + 1) * KH_TN_REFRESH;
         n_stop = n_stop < nt - 1 ? n_stop : nt - 1;
@@ -400,7 +409,7 @@ kh_tn_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
             } else {
                 for (int l = 0; l < L; ++l) {
                     const double d = s.eps[l] - s.eps_prev[l];
-                    if (tab_k[1 + l] != nullptr && d != 0.0) kh_tn_axpy<EPL>(tab_k[1 + l], d, tid, a);
+                    if (tab_k[1 + l] != nullptr && d != 0.0) kh_tn_axpy<EPL>(tab_k[1 + l], d, tid, active, a);
                 }
             }
             int nsub, m;
