@@ -64,6 +64,15 @@ __device__ __forceinline__ void kh_tx_load(const cplx *tab, int tid, cplx (&a)[8
         a[j] = c_make(v.x, v.y);
     }
 }
+// ... of a STREAMED operator: a lane whose row (tid >> 3) is beyond N holds zeros and does not fetch them
+__device__ __forceinline__ void kh_tx_load_rows(const cplx *tab, int tid, int N, cplx (&a)[8]) {
+    if ((tid >> 3) < N) {
+        kh_tx_load(tab, tid, a);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = c_make(0.0, 0.0);
+    }
+}
 
 struct KhTxOps {
     cplx reg[KH_TX_REG][8];
@@ -154,20 +163,20 @@ __device__ __forceinline__ void kh_tx_axpy(double w, const cplx (&t)[8], cplx (&
 #define KH_TX_UPDATE_PRE 0
 #endif
 template <int LT, int NPRE>
-__device__ __forceinline__ void kh_tx_prefetch(const cplx *const *tab_k, int tid, cplx (&ts0)[8], cplx (&ts1)[8]) {
+__device__ __forceinline__ void kh_tx_prefetch(const cplx *const *tab_k, int tid, int N, cplx (&ts0)[8], cplx (&ts1)[8]) {
     static_assert(LT >= KH_TX_MIN_L && LT <= 8 && KH_MAX_L == 8, "at most three streamed controls");
-    if constexpr (LT > 5 && NPRE >= 1) kh_tx_load(tab_k[6], tid, ts0);
-    if constexpr (LT > 6 && NPRE >= 2) kh_tx_load(tab_k[7], tid, ts1);
+    if constexpr (LT > 5 && NPRE >= 1) kh_tx_load_rows(tab_k[6], tid, N, ts0);
+    if constexpr (LT > 6 && NPRE >= 2) kh_tx_load_rows(tab_k[7], tid, N, ts1);
 }
 template <int LT, int NPRE>
-__device__ __forceinline__ void kh_tx_build(const KhTxOps &h, const cplx *const *tab_k, const double *eps, int tid, cplx (&ts0)[8],
-                                            cplx (&ts1)[8], cplx (&a)[1][8]) {
+__device__ __forceinline__ void kh_tx_build(const KhTxOps &h, const cplx *const *tab_k, const double *eps, int tid, int N,
+                                            cplx (&ts0)[8], cplx (&ts1)[8], cplx (&a)[1][8]) {
     constexpr int HAVE = (LT - 5) < NPRE ? (LT - 5) : NPRE;  // tiles that are on their way already
     h.template build_resident<HAVE>(eps, ts0, ts1, a);
 #pragma unroll
     for (int l = 5 + HAVE; l < LT; ++l) {
         __builtin_amdgcn_sched_barrier(0);
-        kh_tx_load(tab_k[1 + l], tid, ts0);
+        kh_tx_load_rows(tab_k[1 + l], tid, N, ts0);
         kh_tx_axpy(kh_uniform(eps[l]), ts0, a);
         kh_tx_pin(a);
     }
@@ -214,7 +223,7 @@ kh_tx_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ tabs, const dou
         int m_hint = -1;
         for (int step = 0; step < nt - 1; ++step) {
             cplx ts0[8], ts1[8];
-            kh_tx_prefetch<LT, KH_TX_STORE_PRE>(tab_k, tid, ts0, ts1);
+            kh_tx_prefetch<LT, KH_TX_STORE_PRE>(tab_k, tid, N, ts0, ts1);
             const int n = direction > 0 ? step : nt - 2 - step;
             const int sp = step & 1;
             const double dt = dt_next;
@@ -231,7 +240,7 @@ kh_tx_sweep_store(KhSweepArgs p, const cplx *const *__restrict__ tabs, const dou
             if (m != m_hint) kh_tile_load_ratios(p, inv_sh, m, tid);  // (workgroup-uniform, rare)
             m_hint = m;
             cplx a[1][8];
-            kh_tx_build<LT, KH_TX_STORE_PRE>(h, tab_k, eps_sh[sp], tid, ts0, ts1, a);
+            kh_tx_build<LT, KH_TX_STORE_PRE>(h, tab_k, eps_sh[sp], tid, N, ts0, ts1, a);
             matvecs += kh_tile_expm_action<1>(a, state, buf, inv_sh, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
             // buf[cur] now holds the new state (and the barrier that published it also published eps_sh[sp ^ 1])
             if (store != nullptr && wave == 0 && lane < N)
@@ -303,7 +312,7 @@ kh_tx_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
     for (int n = u.n_begin; n < u.n_end; ++n) {
         const int par = n & 1;
         cplx ts0[8], ts1[8];
-        kh_tx_prefetch<LT, KH_TX_UPDATE_PRE>(tab_k, tid, ts0, ts1);
+        kh_tx_prefetch<LT, KH_TX_UPDATE_PRE>(tab_k, tid, N, ts0, ts1);
         if (n + 1 < nt - 1) load_bra(n + 1);  // lands while this interval is processed
         // ---- cross-objective sum (optimize.py:470): wave 0 publishes, wave l gathers control l ----
         if (wave == 0) {
@@ -379,7 +388,7 @@ kh_tx_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
             __syncthreads();  // eps_sh
         m_hint = m;
         cplx a[1][8];
-        kh_tx_build<LT, KH_TX_UPDATE_PRE>(h, tab_k, eps_sh, tid, ts0, ts1, a);
+        kh_tx_build<LT, KH_TX_UPDATE_PRE>(h, tab_k, eps_sh, tid, N, ts0, ts1, a);
         matvecs += kh_tile_expm_action<1>(a, state, buf, inv_sh, cur, p.fre, p.fim, dt, nsub, m, wave, lane);
         // ---- partial sums of the next interval (state is in buf[cur], barrier passed) ----
         if (n + 1 < nt - 1) {
