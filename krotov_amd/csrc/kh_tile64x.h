@@ -308,11 +308,17 @@ kh_tx_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
     }
     __syncthreads();
     int m_hint = -1;
+    const double my_lambda = tid < LT ? u.lambda[tid] : 1.0;
 
     for (int n = u.n_begin; n < u.n_end; ++n) {
         const int par = n & 1;
         cplx ts0[8], ts1[8];
         kh_tx_prefetch<LT, KH_TX_UPDATE_PRE>(tab_k, tid, N, ts0, ts1);
+        double my_guess = 0.0, my_stepw = 0.0;  // (in flight while the sums are exchanged)
+        if (tid < LT) {
+            my_guess = u.guess[(size_t)tid * (nt - 1) + n];
+            my_stepw = u.shape[(size_t)tid * (nt - 1) + n] / my_lambda;
+        }
         if (n + 1 < nt - 1) load_bra(n + 1);  // lands while this interval is processed
         // ---- cross-objective sum (optimize.py:470): wave 0 publishes, wave l gathers control l ----
         if (wave == 0) {
@@ -365,27 +371,22 @@ kh_tx_forward_update(KhSweepArgs p, const cplx *const *__restrict__ tabs, KhUpda
             for (int l = 0; l < L; ++l) all_ok = all_ok && ok_sh[l] != 0.0;
             if (!all_ok) return;
         }
-        // ---- pulse update (optimize.py:471-477) ----
+        // ---- pulse update (optimize.py:471-477): thread l = control l, its guess and step width fetched before the exchange ----
+        if (tid < LT) {
+            const double d1 = D_sh[tid];
+            const double eps = my_guess + my_stepw * d1;
+            eps_sh[tid] = eps;
+            g_a_sh[tid] += my_stepw * (d1 * d1) * dt;
+            if (k == 0) u.opt[(size_t)tid * (nt - 1) + n] = eps;
+        }
+        __syncthreads();  // eps_sh
+        // ---- propagate over interval n with the updated pulses (optimize.py:479-491) ----
         double theta = nrm[0];
 #pragma unroll
-        for (int l = 0; l < LT; ++l) {
-            const double stepw = kh_uniform(u.shape[(size_t)l * (nt - 1) + n]) / kh_uniform(u.lambda[l]);
-            const double d1 = kh_uniform(D_sh[l]);
-            const double eps = kh_uniform(kh_uniform(u.guess[(size_t)l * (nt - 1) + n]) + stepw * d1);
-            if (tid == l) {
-                eps_sh[l] = eps;
-                g_a_sh[l] += stepw * (d1 * d1) * dt;
-                if (k == 0) u.opt[(size_t)l * (nt - 1) + n] = eps;
-            }
-            theta += fabs(eps) * nrm[1 + l];
-        }
-        // ---- propagate over interval n with the updated pulses (optimize.py:479-491) ----
+        for (int l = 0; l < LT; ++l) theta += fabs(kh_uniform(eps_sh[l])) * nrm[1 + l];
         int nsub, m;
         kh_degree_lookup(theta * dt, deg_sh, p.theta_max, p.inv_theta_max, m_hint < 1 ? 12 : m_hint, &nsub, &m);
-        if (m != m_hint)
-            kh_tile_load_ratios(p, inv_sh, m, tid);  // (workgroup-uniform, rare; its barriers publish eps_sh as well)
-        else
-            __syncthreads();  // eps_sh
+        if (m != m_hint) kh_tile_load_ratios(p, inv_sh, m, tid);  // (workgroup-uniform, rare)
         m_hint = m;
         cplx a[1][8];
         kh_tx_build<LT, KH_TX_UPDATE_PRE>(h, tab_k, eps_sh, tid, N, ts0, ts1, a);

@@ -1974,6 +1974,11 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
             ut.adj_store = e->d_gen_adj;
         }
         const KhUpdateArgs &u = ut;
+        // (several waves poll side by side: a later first poll, as for the tile64x kernels -- N = 100, L = 6: 68.8 -> 64.9 us per
+        // interval, N = 81, L = 4: 38.2 -> 35.5; KH_POLL_DELAY overrides)
+        KhExchange ext = ex;
+        if (!e->poll_delay_set && e->L >= 2) ext.first_poll_delay = e->L == 2 ? 32 : 64;
+        const KhExchange &ex = ext;
 #define KH_TN_UPDATE(EP, HR)                                                                                                  \
     (so ? launch_persistent<kh_tn_forward_update<EP, true, HR>>(e, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex) \
         : launch_persistent<kh_tn_forward_update<EP, false, HR>>(e, g, b, lds, st, p, (const cplx *const *)e->d_tn_fw, u, ex))
@@ -2037,6 +2042,9 @@ static int launch_update(kh_engine *e, const KhUpdateArgs &u, hipStream_t st) {
         ux.adj_store = e->d_gen_adj;
         KhExchange exx = ex;
         exx.G = e->K;
+        // (five to eight waves poll side by side: their first poll later than the register-tile kernels' -- measured best at
+        // K = 256, N = 64: 32 / 44 / 64 / 64 for L = 5 / 6 / 7 / 8, profiles/r06/ab_tile64x.txt; KH_POLL_DELAY overrides)
+        if (!e->poll_delay_set) exx.first_poll_delay = e->L <= 5 ? 32 : e->L == 6 ? 44 : 64;
         e->last_update_grid = e->K;
 #define KH_TX_UPDATE(LT)                                                                                              \
     do {                                                                                                              \
